@@ -1,0 +1,223 @@
+/*
+ * rpnet_abi.h — C ABI of librpnet_hip.so, the MI355X (gfx950) kernels behind the
+ * RP-Net hot path (uci-cbcl/RP-Net: net/rp_net.py, net/unet.py, net/modules.py).
+ *
+ * The reference has no native code and no FFI: the path is ordinary nn.Module code on
+ * stock torch operators.  Each entry point below therefore names the reference
+ * operator sequence (file:line under /root/reference) that it replaces; the
+ * reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md (rpnet_amd/hip.py is exactly that stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *     the library never allocates, frees or synchronises; work is enqueued on `stream`.
+ *   - activations are fp32 NHWC ("pixel-major": [N][H][W][C]); the module boundary
+ *     tensors of the reference (images [B,1,H,W], masks [B,H,W], logits [B,K,H,W]) are
+ *     read/written in their own NCHW layout by the kernels that touch them.
+ *   - "groups": G consecutive equal slices of the N images that keep separate
+ *     BatchNorm batch statistics (the reference calls the encoder once for the support
+ *     images and once for the query images, net/rp_net.py:248,257 — one launch here,
+ *     two statistic groups, two running-stat updates in call order).
+ *   - return value: 0 on success, a negative rpnet_status, or a positive hipError_t;
+ *     rpnet_last_error_string() gives thread-local text for the last failure.
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef RPNET_ABI_H
+#define RPNET_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rpnet_stream_t; /* hipStream_t */
+
+enum rpnet_status {
+    RPNET_OK = 0,
+    RPNET_ERR_SHAPE = -1,   /* a dimension violates the kernel's tiling contract */
+    RPNET_ERR_ARG = -2,     /* null / inconsistent argument */
+    RPNET_ERR_WORKSPACE = -3
+};
+
+int rpnet_version(void);
+const char* rpnet_last_error_string(void);
+
+/* ------------------------------------------------------------------ weight packing
+ * nn.Conv2d weight [Cout][Cin][kh][kw] (state_dict layout, net/modules.py:47) ->
+ *   wp  [taps][Cin_pad/4][Cout][4]  forward  implicit-GEMM B operand (k-quads interleaved)
+ *   wd  [taps][Cout/4][Cin_pad][4]  dgrad B operand: taps flipped, Cin/Cout swapped
+ * `cin_off`/`cin_pad`: input channel c of the weight lands on packed row cin_off + c of
+ * cin_pad rows; the other rows are zero (the 121 correlation channels are padded to 128,
+ * net/rp_net.py:65-69,81).  wd may be NULL. taps = 9 (3x3) or 1 (1x1). */
+int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int cin, int taps,
+                           int cin_off0, int cin_split, int cin_off1, int cin_pad, rpnet_stream_t stream);
+
+/* ------------------------------------------------------------- conv (implicit GEMM)
+ * Replaces nn.Conv2d(k=3,s=1,p=1,bias=True) / nn.Conv2d(k=1) forward and its
+ * autograd input-gradient (net/modules.py:47,50,67; net/rp_net.py:51,56,66), fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  One descriptor drives forward and dgrad:
+ *   A operand  = input pixels, gathered from up to two NHWC sources that are
+ *                concatenated along C (torch.cat skip connections, net/unet.py:460,464;
+ *                torch.cat([corr, fm1]), net/rp_net.py:81), optionally through a
+ *                nearest x2 up-sampling (nn.Upsample, net/modules.py:66) and optionally
+ *                scaled per input pixel by s or 1-s (x*mask, x*(1-mask), net/rp_net.py:275,283);
+ *   B operand  = packed weights;
+ *   epilogue   = +bias, optional per-channel affine+ReLU (eval-mode BatchNorm+ReLU,
+ *                net/modules.py:48-49), optional per-output-pixel scale and accumulate
+ *                (dgrad of the two masked CRE branches into one tensor), split of the
+ *                output channels over two destinations (dgrad of a concat). */
+typedef struct rpnet_conv_desc {
+    const float* x0; const float* x1;  /* NHWC sources, C0 + C1 = Cin (x1 NULL if C1 == 0) */
+    int C0, C1;
+    const float* w;                    /* packed [taps][Cin/4][Cout][4] */
+    const float* bias;                 /* [Cout] or NULL */
+    const float* in_scale;             /* [N*Hin*Win] or NULL */
+    int in_scale_mode;                 /* 0 none, 1: *s, 2: *(1-s) */
+    float* y0; float* y1;              /* NHWC destinations, Co0 + Co1 = Cout */
+    int Co0, Co1;
+    const float* ep_scale; const float* ep_shift; /* [G][Cout] eval affine or NULL */
+    int ep_relu;
+    const float* out_scale;            /* [N*H*W] or NULL */
+    int out_scale_mode;                /* 0 none, 1: *s, 2: *(1-s) */
+    int accumulate;                    /* y += result */
+    int N, H, W;                       /* output (= conv input after up-sampling) size */
+    int taps;                          /* 9 or 1 */
+    int upsample;                      /* sources are [N][H/2][W/2][C] */
+    int groups;                        /* for ep_scale/ep_shift rows */
+} rpnet_conv_desc;
+
+int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
+
+/* weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
+ * dW[cout][cin][kh][kw] = sum_pixels A[pixel+tap][cin] * dy[pixel][cout], A gathered
+ * exactly as in rpnet_conv_fwd.  Split-K over pixels into `workspace`
+ * (rpnet_conv_wgrad_workspace_bytes), then reduced and transposed into the state_dict
+ * layout.  Channels [cin_off0, cin_off0+cin_split) and [cin_off1, ...) of the gathered A
+ * map to dW input channels 0.. (skips the zero padding rows). db (bias grad, [Cout]) may be NULL. */
+size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps);
+int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int cin_w,
+                     int cin_off0, int cin_split, int cin_off1,
+                     void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+
+/* first layer, Cin = 1 (net/unet.py:407 Conv1.conv.0): direct convolution */
+int rpnet_conv1_fwd(const float* x, const float* w /*[Cout][1][3][3]*/, const float* bias, float* y,
+                    const float* ep_scale, const float* ep_shift, int N, int H, int W, int cout,
+                    rpnet_stream_t stream);
+size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cout);
+int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout,
+                      void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+
+/* ---------------------------------------------------------------------- BatchNorm
+ * Train-mode nn.BatchNorm2d + nn.ReLU(inplace) (net/modules.py:48-49,51-52,68-69),
+ * split around the grid-wide reduction:
+ *   rpnet_bn_stats   per (group, channel) batch mean / biased variance (fp64
+ *                    accumulation) -> scale = gamma*invstd, shift = beta - mean*scale,
+ *                    save mean & invstd; running_mean/var momentum update with the
+ *                    unbiased variance, one update per group in group order.
+ *   rpnet_bn_relu    z = relu(y*scale + shift)
+ *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups) and
+ *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)). */
+size_t rpnet_bn_workspace_bytes(int C, int groups);
+int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, float* mean, float* invstd,
+                   void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, int C,
+                         rpnet_stream_t stream);
+int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, int N, int HW, int C,
+                  int groups, rpnet_stream_t stream);
+int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
+                 const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
+                 int N, int HW, int C, int groups, void* workspace, size_t workspace_bytes,
+                 rpnet_stream_t stream);
+
+/* ------------------------------------------------------------ pooling / up-sampling
+ * nn.MaxPool2d(2,2) (net/unet.py:397) forward; backward routes the gradient to the
+ * first maximum of each window and adds `skip` (the gradient arriving through the
+ * U-Net skip connection) if given.  nn.Upsample(scale_factor=2) backward = 2x2 sum. */
+int rpnet_maxpool2_fwd(const float* z, float* out, int N, int H, int W, int C, rpnet_stream_t stream);
+int rpnet_maxpool2_bwd(const float* z, const float* dpool, const float* skip, float* dz, int N, int H, int W,
+                       int C, rpnet_stream_t stream);
+int rpnet_upsample2_bwd(const float* dyu, float* dx, int N, int H, int W, int C, rpnet_stream_t stream);
+
+/* --------------------------------------------------------- context-correlation block
+ * F.avg_pool2d(mask[:,None], scale) (net/rp_net.py:269-272,311): [B][H][W] -> [B][h][w] */
+int rpnet_mask_avgpool(const float* mask, float* out, int B, int H, int W, int scale, rpnet_stream_t stream);
+
+/* Correlation() (net/rp_net.py:153-181) in its exact local-window form:
+ * corr[b,y,x, a*(2r+1)+c] = <f1[b,y,x,:], f2[b,y+c-r,x+a-r,:]>/sqrt(C), zero outside;
+ * NHWC, output channel stride `cstride` >= (2r+1)^2, channels beyond the window are written 0. */
+int rpnet_local_corr_fwd(const float* f1, const float* f2, float* corr, int B, int h, int w, int C, int r,
+                         int cstride, rpnet_stream_t stream);
+size_t rpnet_local_corr_bwd_workspace_bytes(int B, int h, int w, int cstride);
+int rpnet_local_corr_bwd(const float* f1, const float* f2, const float* dcorr, float* df1, float* df2,
+                         int B, int h, int w, int C, int r, int cstride,
+                         void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+
+/* ------------------------------------------------------------------------- matcher
+ * getFeatures + the mask sums of net/rp_net.py:366-376 in adjoint form:
+ *   rpnet_mask_adjoint: am[b,k,:,:] = U^T mask_k[b] (U = bilinear up-sampler h,w -> H,W,
+ *                       align_corners=False), msum[b,k] = sum(mask_k[b]); k indexes `nmask`
+ *                       mask tensors given as an array of nmask device pointers' worth of
+ *                       contiguous [B][H][W] blocks (masks + k*B*H*W).
+ *   rpnet_masked_pool_fwd: proto[b,k,c] = sum_q f[b,q,c]*am[b,k,q] / (msum[b,k] + 1e-5)
+ *   rpnet_masked_pool_bwd: df[b,q,c]   = sum_k dproto[b,k,c]*am[b,k,q]/(msum[b,k]+1e-5) */
+int rpnet_mask_adjoint(const float* masks, float* am, float* msum, int B, int nmask, int H, int W, int h, int w,
+                       rpnet_stream_t stream);
+size_t rpnet_masked_pool_workspace_bytes(int B, int nmask, int hw, int C);
+int rpnet_masked_pool_fwd(const float* f, const float* am, const float* msum, float* proto, int B, int nmask,
+                          int hw, int C, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_masked_pool_bwd(const float* dproto, const float* am, const float* msum, float* df, int B, int nmask,
+                          int hw, int C, int accumulate, rpnet_stream_t stream);
+
+/* calDist (net/rp_net.py:353-363): pred[b,k,q] = scaler * cos(f[b,q,:], proto[b,k,:]),
+ * torch cosine_similarity semantics (each norm clamped at 1e-8).  f NHWC [B][hw][C],
+ * pred NCHW-lowres [B][K][hw]. */
+int rpnet_cosine_match_fwd(const float* f, const float* proto, float* pred, int B, int K, int hw, int C,
+                           float scaler, rpnet_stream_t stream);
+size_t rpnet_cosine_match_bwd_workspace_bytes(int B, int K, int hw, int C);
+int rpnet_cosine_match_bwd(const float* f, const float* proto, const float* dpred, float* df, float* dproto,
+                           int B, int K, int hw, int C, float scaler, int accumulate_df,
+                           void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+
+/* F.interpolate(pred, size=(H,W), mode='bilinear') (net/rp_net.py:303,337) on [BK][h][w]
+ * planes, and its adjoint. */
+int rpnet_bilinear_up_fwd(const float* in, float* out, int planes, int h, int w, int H, int W, rpnet_stream_t stream);
+int rpnet_bilinear_up_bwd(const float* dout, float* din, int planes, int h, int w, int H, int W, rpnet_stream_t stream);
+
+/* softmax(dim=1)[:,1] -> (>0.5) unless soft -> avg_pool2d(scale) (net/rp_net.py:308-311):
+ * logits [B][K][H][W] -> next mask [B][H/scale][W/scale] */
+int rpnet_softmax_thresh_pool(const float* logits, float* mask, int B, int K, int H, int W, int scale, int soft,
+                              rpnet_stream_t stream);
+
+/* -------------------------------------------------------------------------- losses
+ * dice_ce (net/rp_net.py:87-127) for K-class logits [B][K][H][W], int64 labels [B][H][W]:
+ *   loss = [with_dice] (1 - mean_k 2*I_k/(C_k + 1e-7)) + cross-entropy,
+ *   cross-entropy = sum(-log_softmax[label]) / #valid            (per_sample = 0, nn.CrossEntropyLoss)
+ *                 = (1/B) sum_b w_b * CE_b / #valid_b            (per_sample = 1: alignLoss calls
+ *                   F.cross_entropy once per episode, net/rp_net.py:438, sums and divides by B, :349;
+ *                   w_b = 0 skips an episode whose predicted foreground is empty, :414,421)
+ * forward writes loss[0] and the sums backward needs into `stats`
+ * ((B+1)*(2K+2) floats: per sample inter_k, card_k, ce_sum, #valid; then the totals).
+ * backward writes (or accumulates) dlogits = gscale[0] * d loss / d logits. */
+size_t rpnet_loss_workspace_bytes(int B, int K, int H, int W);
+int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* stats, int B, int K, int H,
+                      int W, int with_dice, int ignore_index, int per_sample, const float* sample_weight,
+                      void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gscale,
+                      float* dlogits, int B, int K, int H, int W, int with_dice, int ignore_index, int per_sample,
+                      const float* sample_weight, int accumulate, rpnet_stream_t stream);
+
+/* alignLoss pieces: arg-max class masks of the low-res prediction with their pixel
+ * counts (net/rp_net.py:412-417) — masks [B][K][hw] (0/1), counts [B][K]; and the support
+ * label map 1 = fore, 0 = back, 255 = ignore (net/rp_net.py:433-436). */
+int rpnet_argmax_masks(const float* pred, float* masks, float* counts, int B, int K, int hw, rpnet_stream_t stream);
+int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, size_t n, rpnet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPNET_ABI_H */

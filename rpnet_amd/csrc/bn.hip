@@ -1,0 +1,280 @@
+// Train-mode BatchNorm2d + ReLU around the grid-wide reduction, NHWC fp32 (HBM-bound
+// kernels: float4 accesses along C, fp64 accumulation for the statistics).
+// Replaces nn.BatchNorm2d + nn.ReLU(inplace) of net/modules.py:48-49,51-52,68-69 and
+// net/rp_net.py:52-53,57-58,67-68 and their autograd.
+#include "common.h"
+
+namespace rpnet {
+
+struct BnGeom {
+    int C4;        // float4 columns
+    int rows_it;   // rows handled per block iteration
+    int nblk;      // blocks per group
+    int rows_blk;  // rows per block
+};
+
+static BnGeom bn_geom(long R, int C) {
+    BnGeom g;
+    g.C4 = C / 4;
+    g.rows_it = 256 / g.C4;
+    long nb = (R + (long)g.rows_it * 4 - 1) / ((long)g.rows_it * 4);
+    g.nblk = (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    g.rows_blk = (int)((R + g.nblk - 1) / g.nblk);
+    return g;
+}
+
+// partial[(g*nblk + blk)][C][2] doubles: sum, sumsq
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ y, double* __restrict__ partial,
+                                                         long R, int C, BnGeom gm) {
+    __shared__ double red[256 * 8];
+    const int t = threadIdx.x;
+    const int tc = t % gm.C4, tr = t / gm.C4;
+    const int g = blockIdx.y, blk = blockIdx.x;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < gm.rows_it) {
+        const long r0 = (long)blk * gm.rows_blk;
+        const long r1 = min(r0 + gm.rows_blk, R);
+        const float* base = y + ((size_t)g * R) * C + tc * 4;
+        for (long r = r0 + tr; r < r1; r += gm.rows_it) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += v[k]; q[k] += (double)v[k] * v[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s[k]; red[t * 8 + 4 + k] = q[k]; }
+    __syncthreads();
+    if (tr == 0) {
+        for (int rr = 1; rr < gm.rows_it; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[(rr * gm.C4 + tc) * 8 + k]; q[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k]; }
+        double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = q[k]; }
+    }
+}
+
+__global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  float* running_mean, float* running_var, float momentum, float eps,
+                                  float* scale, float* shift, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {  // sequential: one running-stat update per group, in call order
+        double s = 0, q = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
+            s += p[0]; q += p[1];
+        }
+        const double m = s / (double)R;
+        double var = q / (double)R - m * m;
+        if (var < 0) var = 0;
+        const float istd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * istd;
+        scale[g * C + c] = sc;
+        shift[g * C + c] = beta[c] - (float)m * sc;
+        mean[g * C + c] = (float)m;
+        invstd[g * C + c] = istd;
+        const float unb = (float)(R > 1 ? var * (double)R / (double)(R - 1) : var);
+        rm = (1.f - momentum) * rm + momentum * (float)m;
+        rv = (1.f - momentum) * rv + momentum * unb;
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ z,
+                                                       size_t total4, int C4, size_t group4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int g = (int)(i / group4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[g * C4 + c4];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[g * C4 + c4];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+        reinterpret_cast<f32x4*>(z)[i] = o;
+    }
+}
+
+// partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const float* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       double* __restrict__ partial, long R, int C, BnGeom gm) {
+    __shared__ double red[256 * 8];
+    const int t = threadIdx.x;
+    const int tc = t % gm.C4, tr = t / gm.C4;
+    const int g = blockIdx.y, blk = blockIdx.x;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (tr < gm.rows_it) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + g * C + tc * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + g * C + tc * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tc * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * C + tc * 4);
+        const long r0 = (long)blk * gm.rows_blk;
+        const long r1 = min(r0 + gm.rows_blk, R);
+        const size_t base = ((size_t)g * R) * C + tc * 4;
+        for (long r = r0 + tr; r < r1; r += gm.rows_it) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
+                s1[k] += dm;
+                s2[k] += (double)dm * ((v[k] - mu[k]) * is[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; }
+    __syncthreads();
+    if (tr == 0) {
+        for (int rr = 1; rr < gm.rows_it; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[k] += red[(rr * gm.C4 + tc) * 8 + k]; s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k]; }
+        double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s1[k]; o[k * 2 + 1] = s2[k]; }
+    }
+}
+
+// coef[g][C][2] floats = (s1/R, s2/R); dgamma/dbeta summed over groups
+__global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G, float* coef,
+                                float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0, tb = 0;
+    for (int g = 0; g < G; ++g) {
+        double s1 = 0, s2 = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
+            s1 += p[0]; s2 += p[1];
+        }
+        coef[(g * C + c) * 2] = (float)(s1 / (double)R);
+        coef[(g * C + c) * 2 + 1] = (float)(s2 / (double)R);
+        tb += s1; tg += s2;
+    }
+    dgamma[c] = (float)tg;
+    dbeta[c] = (float)tb;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz, const float* __restrict__ y,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ coef, float* __restrict__ dy,
+                                                     size_t total4, int C, size_t group4) {
+    const int C4 = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int g = (int)(i / group4);
+        const int o = g * C + c4 * 4;
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
+            const float xh = (v[k] - mu[k]) * is[k];
+            r[k] = sc[k] * (dm - coef[(o + k) * 2] - xh * coef[(o + k) * 2 + 1]);
+        }
+        reinterpret_cast<f32x4*>(dy)[i] = r;
+    }
+}
+
+static int elt_grid(size_t total4) {
+    size_t b = (total4 + 255) / 256;
+    return (int)(b > 2048 * 4 ? 2048 * 4 : (b < 1 ? 1 : b));
+}
+
+}  // namespace rpnet
+
+extern "C" size_t rpnet_bn_workspace_bytes(int C, int groups) {
+    return (size_t)groups * 256 * C * 2 * sizeof(double) + (size_t)groups * C * 2 * sizeof(float);
+}
+
+static int bn_check(const char* who, int N, int HW, int C, int groups) {
+    using namespace rpnet;
+    RPNET_REQUIRE(C % 4 == 0 && C / 4 <= 256, RPNET_ERR_SHAPE, "%s: C=%d must be a multiple of 4 and <= 1024", who, C);
+    RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "%s: N=%d not divisible by groups=%d", who, N, groups);
+    (void)HW;
+    return 0;
+}
+
+extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                              float* shift, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
+                              rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(y && gamma && beta && scale && shift && mean && invstd && workspace, RPNET_ERR_ARG, "bn_stats: null pointer");
+    if (int rc = bn_check("bn_stats", N, HW, C, groups)) return rc;
+    RPNET_REQUIRE(workspace_bytes >= rpnet_bn_workspace_bytes(C, groups), RPNET_ERR_WORKSPACE, "bn_stats: workspace too small");
+    const long R = (long)(N / groups) * HW;
+    const BnGeom gm = bn_geom(R, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, gm.nblk, R, C,
+                       groups, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    return check_launch("bn_stats");
+}
+
+extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* scale, float* shift, int C,
+                                    rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, RPNET_ERR_ARG, "bn_eval_affine: null pointer");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, scale, shift, C);
+    return check_launch("bn_eval_affine");
+}
+
+extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, int N, int HW, int C,
+                             int groups, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(y && scale && shift && z, RPNET_ERR_ARG, "bn_relu: null pointer");
+    if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
+    const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z,
+                       total4, C / 4, group4);
+    return check_launch("bn_relu");
+}
+
+extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, int N, int HW,
+                            int C, int groups, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    (void)gamma;
+    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && dy && dgamma && dbeta && workspace, RPNET_ERR_ARG,
+                  "bn_bwd: null pointer");
+    if (int rc = bn_check("bn_bwd", N, HW, C, groups)) return rc;
+    RPNET_REQUIRE(workspace_bytes >= rpnet_bn_workspace_bytes(C, groups), RPNET_ERR_WORKSPACE, "bn_bwd: workspace too small");
+    const long R = (long)(N / groups) * HW;
+    const BnGeom gm = bn_geom(R, C);
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    float* coef = (float*)((char*)workspace + (size_t)groups * 256 * C * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                       R, C, gm);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, (const double*)partial, gm.nblk, R, C, groups,
+                       coef, dgamma, dbeta);
+    const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+                       (const float*)coef, dy, total4, C, group4);
+    return check_launch("bn_bwd");
+}

@@ -1,0 +1,58 @@
+// Shared helpers for the rpnet HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rpnet_abi.h"
+
+namespace rpnet {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define RPNET_REQUIRE(cond, code, ...)      \
+    do {                                    \
+        if (!(cond)) {                      \
+            rpnet::set_error(__VA_ARGS__);  \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 64-lane wavefront reductions (CDNA: wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ double block_sum256(double v, double* smem4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem4[wv] = v;
+    __syncthreads();
+    return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+// XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private
+// L2); give every XCD a contiguous run of logical tiles so neighbouring tiles (which share
+// an operand panel) hit the same L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_swizzle(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace rpnet

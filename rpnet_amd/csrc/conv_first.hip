@@ -1,0 +1,133 @@
+// First U-Net layer, Cin = 1 (encoder.Conv1.conv.0, net/unet.py:407 with img_ch = 1):
+// K = 9 is no GEMM — a direct convolution that is bound by writing the [N,H,W,Cout]
+// output (forward) or reading dy (weight gradient).  One thread = one pixel x 4 output
+// channels, so a pixel's Cout channels are one coalesced float4 row; the 9 x Cout filter
+// sits in LDS.  The input image needs no gradient.
+#include "common.h"
+
+namespace rpnet {
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ ep_scale,
+                                                         const float* __restrict__ ep_shift, int N, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout]
+    const int t = threadIdx.x;
+    for (int i = t; i < 9 * Cout; i += 256) { const int co = i / 9, tap = i - co * 9; wl[tap * Cout + co] = w[i]; }
+    for (int i = t; i < Cout; i += 256) wl[9 * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int Q = Cout / 4, ppb = 256 / Q;
+    const int q = t % Q, pl = t / Q;
+    if (pl >= ppb) return;
+    const size_t M = (size_t)N * H * W;
+    for (size_t p = (size_t)blockIdx.x * ppb + pl; p < M; p += (size_t)gridDim.x * ppb) {
+        const int ox = (int)(p % W), oy = (int)((p / W) % H);
+        const size_t nb = p - (size_t)oy * W - ox;  // n*H*W
+        f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[9 * Cout + q * 4]);
+#pragma unroll
+        for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+            for (int kx = -1; kx <= 1; ++kx) {
+                const int iy = oy + ky, ix = ox + kx;
+                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[nb + (size_t)iy * W + ix] : 0.f;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[((ky + 1) * 3 + kx + 1) * Cout + q * 4]);
+                acc += xv * wv;
+            }
+        if (ep_scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + q * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + q * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k] * sc[k] + sh[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + p * Cout + q * 4) = acc;
+    }
+}
+
+// partial[blk][Cout][9]
+__global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partial, int N, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][Cout][9]
+    const int t = threadIdx.x;
+    const int Q = Cout / 4, ppb = 256 / Q;
+    const int q = t % Q, pl = t / Q;
+    float acc[9][4];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[a][k] = 0.f;
+    const size_t M = (size_t)N * H * W;
+    if (pl < ppb) {
+        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < M; p += (size_t)gridDim.x * ppb) {
+            const int ox = (int)(p % W), oy = (int)((p / W) % H);
+            const size_t nb = p - (size_t)oy * W - ox;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * Cout + q * 4);
+#pragma unroll
+            for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+                for (int kx = -1; kx <= 1; ++kx) {
+                    const int iy = oy + ky, ix = ox + kx;
+                    const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[nb + (size_t)iy * W + ix] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[(ky + 1) * 3 + kx + 1][k] += xv * g[k];
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[(pl * Cout + q * 4 + k) * 9 + a] = acc[a][k];
+    }
+    __syncthreads();
+    for (int i = t; i < Cout * 9; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < ppb; ++r) s += red[r * Cout * 9 + i];
+        partial[(size_t)blockIdx.x * Cout * 9 + i] = s;
+    }
+}
+
+__global__ void conv1_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
+    dw[i] = (float)s;
+}
+
+constexpr int kConv1WgradBlocks = 1024;
+
+}  // namespace rpnet
+
+extern "C" int rpnet_conv1_fwd(const float* x, const float* w, const float* bias, float* y, const float* ep_scale,
+                               const float* ep_shift, int N, int H, int W, int cout, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && w && y, RPNET_ERR_ARG, "conv1_fwd: null pointer");
+    RPNET_REQUIRE(cout % 4 == 0 && cout <= 1024 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_fwd: cout=%d", cout);
+    const int ppb = 256 / (cout / 4);
+    const size_t M = (size_t)N * H * W;
+    size_t nb = (M + ppb - 1) / ppb;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((int)nb), dim3(256), (size_t)10 * cout * sizeof(float), (hipStream_t)stream, x,
+                       w, bias, y, ep_scale, ep_shift, N, H, W, cout);
+    return check_launch("conv1_fwd");
+}
+
+extern "C" size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cout) {
+    (void)N; (void)H; (void)W;
+    return (size_t)rpnet::kConv1WgradBlocks * cout * 9 * sizeof(float);
+}
+
+extern "C" int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout, void* workspace,
+                                 size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && dy && dw && workspace, RPNET_ERR_ARG, "conv1_wgrad: null pointer");
+    RPNET_REQUIRE(cout % 4 == 0 && cout <= 256 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_wgrad: cout=%d", cout);
+    RPNET_REQUIRE(workspace_bytes >= rpnet_conv1_wgrad_workspace_bytes(N, H, W, cout), RPNET_ERR_WORKSPACE, "conv1_wgrad: workspace");
+    const int ppb = 256 / (cout / 4);
+    const size_t M = (size_t)N * H * W;
+    int nb = (int)((M + ppb - 1) / ppb);
+    if (nb > kConv1WgradBlocks) nb = kConv1WgradBlocks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1_wgrad_partial, dim3(nb), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
+                       (float*)workspace, N, H, W, cout);
+    hipLaunchKernelGGL(conv1_wgrad_final, dim3(cdiv(cout * 9, 128)), dim3(128), 0, s, (const float*)workspace, dw, nb, cout * 9);
+    return check_launch("conv1_wgrad");
+}

@@ -1,0 +1,276 @@
+// Weight gradient of the 3x3 / 1x1 convolutions on the fp32 matrix cores, plus the weight
+// (re)packing kernels.  See include/rpnet_abi.h for the reference operators replaced.
+//
+// wgrad GEMM view, one per filter tap:  dWp[cin][cout] = sum_p A[p + tap][cin] * dy[p][cout]
+//   M = Cin (gathered, incl. padding rows), N = Cout, K = N*H*W pixels (split across blocks).
+// With NHWC activations both operands are K-major in memory (a pixel's channels are
+// contiguous), which is exactly what the MFMA fragments want from LDS ([k][m] / [k][n] rows,
+// conflict-free ds_read_b32), so tiles are staged by straight float4 row copies.
+// grid = (tiles_m * tiles_n, taps, ksplit); each block writes its partial tile to the
+// workspace [ksplit][taps][Cin][Cout]; rpnet_wgrad_reduce sums the splits and transposes
+// into the nn.Conv2d state_dict layout [Cout][Cin][kh][kw] through LDS so that both the
+// reads (along cout) and the writes (along cin,tap) are coalesced.
+#include "common.h"
+
+namespace rpnet {
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d, const float* __restrict__ dy,
+                                                          float* __restrict__ partial, const int M, const int Cin,
+                                                          const int Cout, const int tiles_n, const int steps_per_split) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
+    constexpr int A_F4 = BM / 32, B_F4 = BN / 32;
+    constexpr int A_RW = BM / 4, B_RW = BN / 4;  // float4 per pixel row
+    __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
+    float* As = smem;
+    float* Bs = smem + BK * BM;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int cm0 = tm * BM, n0 = tn * BN;
+    const int tap = blockIdx.y;
+    int ky = 0, kx = 0;
+    if (d.taps == 9) { ky = tap / 3 - 1; kx = tap - (tap / 3) * 3 - 1; }
+
+    const int H = d.H, W = d.W, HW = H * W;
+    const int ups = d.upsample;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const float* src; int Cs, cc;
+    if (cm0 < d.C0) { src = d.x0; Cs = d.C0; cc = cm0; } else { src = d.x1; Cs = d.C1; cc = cm0 - d.C0; }
+
+    const int total_steps = (M + BK - 1) / BK;
+    const int s_begin = blockIdx.z * steps_per_split;
+    const int s_end = min(s_begin + steps_per_split, total_steps);
+
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](int st) {
+        const int p0 = st * BK;
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int idx = t + 256 * j;
+            const int prow = idx / A_RW, c4 = idx - prow * A_RW;
+            const int p = p0 + prow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < M) {
+                const int n = p / HW, rem = p - n * HW;
+                const int oy = rem / W, ox = rem - oy * W;
+                const int iy = oy + ky, ix = ox + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const size_t pix = ((size_t)n * Hs + (iy >> ups)) * Ws + (ix >> ups);
+                    v = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4);
+                    if (d.in_scale_mode) {
+                        float s = d.in_scale[pix];
+                        if (d.in_scale_mode == 2) s = 1.f - s;
+                        v *= s;
+                    }
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int idx = t + 256 * j;
+            const int prow = idx / B_RW, c4 = idx - prow * B_RW;
+            const int p = p0 + prow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + n0 + c4 * 4);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) *reinterpret_cast<f32x4*>(&As[(t + 256 * j) * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) *reinterpret_cast<f32x4*>(&Bs[(t + 256 * j) * 4]) = rb[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_tile(s_begin);
+        store_tile();
+        __syncthreads();
+        for (int st = s_begin; st < s_end; ++st) {
+            const bool more = st + 1 < s_end;
+            if (more) load_tile(st + 1);
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                const int k = kp * 2 + h;
+                float af[WM], bf[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = As[k * BM + wm * WM * 32 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bf[j] = Bs[k * BN + wn * WN * 32 + j * 32 + li];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) store_tile();
+            __syncthreads();
+        }
+    }
+
+    float* out = partial + ((size_t)(blockIdx.z * d.taps + tap) * Cin) * Cout;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * WN * 32 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cm0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * Cout + col] = acc[i][j][r];
+            }
+        }
+}
+
+// partial [ksplit][taps][Cin_g][Cout]  ->  dw [Cout][cin_w][taps]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                            int ksplit, int taps, int Cin_g, int Cout, int cin_w,
+                                                            int off0, int split, int off1) {
+    __shared__ float tile[9][32][33];
+    const int t = threadIdx.x;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int cl = t & 31;
+    for (int tap = 0; tap < taps; ++tap) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int rr = (t >> 5) + 8 * jj;
+            const int cin = ci0 + rr;
+            float s = 0.f;
+            if (cin < cin_w) {
+                const int row = cin < split ? off0 + cin : off1 + (cin - split);
+                const float* p = partial + ((size_t)tap * Cin_g + row) * Cout + co0 + cl;
+                const size_t zstride = (size_t)taps * Cin_g * Cout;
+                for (int z = 0; z < ksplit; ++z) s += p[z * zstride];
+            }
+            tile[tap][rr][cl] = s;
+        }
+    }
+    __syncthreads();
+    const int ncin = min(32, cin_w - ci0);
+    const int nel = ncin * taps;
+    for (int col = 0; col < 32; ++col) {
+        float* o = dw + ((size_t)(co0 + col) * cin_w + ci0) * taps;
+        for (int e = t; e < nel; e += 256) {
+            const int c = e / taps, tap = e - c * taps;
+            o[e] = tile[tap][c][col];
+        }
+    }
+}
+
+// w [Cout][cin_w][taps] -> wp [taps][Cin_g/4][Cout][4] (+ wd [taps][Cout/4][Cin_g][4], taps flipped)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                           float* __restrict__ wd, int taps, int Cin_g, int Cout,
+                                                           int cin_w, int off0, int split, int off1) {
+    __shared__ float tile[9][32][33];  // [tap][cin_l][cout_l]
+    const int t = threadIdx.x;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ncin = min(32, cin_w - ci0);
+    const int nel = ncin * taps;
+    for (int col = 0; col < 32; ++col) {
+        const float* src = w + ((size_t)(co0 + col) * cin_w + ci0) * taps;
+        for (int e = t; e < nel; e += 256) {
+            const int c = e / taps, tap = e - c * taps;
+            tile[tap][c][col] = src[e];
+        }
+    }
+    __syncthreads();
+    // wp: for (tap, cin_l): 32 consecutive cout, element [row/4][cout][row%4]
+    for (int e = t; e < taps * 32 * 32; e += 256) {
+        const int cl = e & 31, c = (e >> 5) & 31, tap = e >> 10;
+        if (c < ncin) {
+            const int cin = ci0 + c;
+            const int row = cin < split ? off0 + cin : off1 + (cin - split);
+            wp[(((size_t)tap * (Cin_g >> 2) + (row >> 2)) * Cout + co0 + cl) * 4 + (row & 3)] = tile[tap][c][cl];
+        }
+    }
+    if (wd) {
+        // wd: GEMM K = cout, N = gathered cin: element [tapflip][cout/4][row][cout%4]
+        for (int e = t; e < taps * 32 * 32; e += 256) {
+            const int q = e & 3, c = (e >> 2) & 31, cq = (e >> 7) & 7, tap = e >> 10;
+            if (c < ncin) {
+                const int cin = ci0 + c;
+                const int row = cin < split ? off0 + cin : off1 + (cin - split);
+                const int cout = co0 + cq * 4 + q;
+                const int tf = taps - 1 - tap;  // (2-ky, 2-kx) for 3x3; 0 for 1x1
+                wd[(((size_t)tf * (Cout >> 2) + (cout >> 2)) * Cin_g + row) * 4 + q] = tile[tap][c][cq * 4 + q];
+            }
+        }
+    }
+}
+
+static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int* ksplit, int* steps_per_split) {
+    *bm = (Cin % 128 == 0) ? 128 : 64;
+    *bn = (Cout % 128 == 0) ? 128 : 64;
+    const long tiles = (long)(Cin / *bm) * (Cout / *bn) * taps;
+    const int total_steps = (M + 31) / 32;
+    int ks = (int)((768 + tiles - 1) / tiles);          // aim at >= ~3 blocks per CU
+    ks = max(1, min(ks, max(1, total_steps / 8)));       // at least 8 K-steps per block
+    *steps_per_split = (total_steps + ks - 1) / ks;
+    *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
+}
+
+}  // namespace rpnet
+
+extern "C" size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps) {
+    int bm, bn, ks, sps;
+    rpnet::wgrad_plan(N * H * W, cin_gathered, cout, taps, &bm, &bn, &ks, &sps);
+    return (size_t)ks * taps * cin_gathered * cout * sizeof(float);
+}
+
+extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int cin_w, int cin_off0,
+                                int cin_split, int cin_off1, void* workspace, size_t workspace_bytes,
+                                rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(d && d->x0 && dy && dw && workspace, RPNET_ERR_ARG, "conv_wgrad: null pointer");
+    const int Cin = d->C0 + d->C1, Cout = d->Co0 + d->Co1;
+    RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
+    RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
+    const int M = d->N * d->H * d->W;
+    int bm, bn, ks, sps;
+    wgrad_plan(M, Cin, Cout, d->taps, &bm, &bn, &ks, &sps);
+    RPNET_REQUIRE(d->C1 == 0 || d->C0 % bm == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to tile %d", d->C0, bm);
+    const size_t need = (size_t)ks * d->taps * Cin * Cout * sizeof(float);
+    RPNET_REQUIRE(workspace_bytes >= need, RPNET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_n = Cout / bn, tiles = (Cin / bm) * tiles_n;
+    dim3 grid(tiles, d->taps, ks);
+    float* part = (float*)workspace;
+    if (bm == 128 && bn == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
+    else if (bm == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
+    else if (bn == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
+    int rc = check_launch("conv_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32), dim3(256), 0, s, part, dw, ks, d->taps,
+                       Cin, Cout, cin_w, cin_off0, cin_split, cin_off1);
+    return check_launch("wgrad_reduce");
+}
+
+extern "C" int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int cin, int taps, int cin_off0,
+                                      int cin_split, int cin_off1, int cin_pad, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(w && wp, RPNET_ERR_ARG, "pack_conv_weight: null pointer");
+    RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 4 == 0 && (taps == 9 || taps == 1), RPNET_ERR_SHAPE,
+                  "pack_conv_weight: cout %d cin_pad %d taps %d", cout, cin_pad, taps);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w, wp, wd,
+                       taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1);
+    return check_launch("pack_conv_weight");
+}

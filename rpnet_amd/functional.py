@@ -1,0 +1,377 @@
+"""Autograd bindings of the HIP kernels (host side of the C ABI).
+
+Activations are fp32 NHWC tensors [N, H, W, C]; the module-boundary tensors of the
+reference (images, masks, logits) keep their NCHW layout.  Every Function calls
+librpnet_hip.so through rpnet_amd.hip — there is no torch-operator fallback.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import hip
+from .hip import ConvDesc, call, ptr, query
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _ws(nbytes, like):
+    return torch.empty((max(int(nbytes), 16) + 7) // 8, device=like.device, dtype=torch.float64)
+
+
+# ------------------------------------------------------------------ weight packing
+class PackedWeight:
+    """Packed copies of one nn.Conv2d weight (see rpnet_pack_conv_weight)."""
+
+    def __init__(self, weight, split=None):
+        cout, cin, kh, kw = weight.shape
+        self.taps = kh * kw
+        if split is None:
+            self.off0, self.split, self.off1, self.cin_pad = 0, cin, cin, cin
+        else:  # (first-source channels, padded first-source channels): concat [corr(121->128), fm1]
+            n0, n0_pad = split
+            self.off0, self.split, self.off1, self.cin_pad = 0, n0, n0_pad, n0_pad + (cin - n0)
+        self.cout, self.cin = cout, cin
+        padded = self.cin_pad != cin
+        mk = torch.zeros if padded else torch.empty
+        self.wp = mk(self.taps * self.cin_pad * cout, device=weight.device, dtype=torch.float32)
+        self.wd = mk(self.taps * self.cin_pad * cout, device=weight.device, dtype=torch.float32) if cin >= 32 else None
+        call("rpnet_pack_conv_weight", ptr(weight), ptr(self.wp), ptr(self.wd), cout, cin, self.taps, self.off0,
+             self.split, self.off1, self.cin_pad)
+
+
+class WeightCache:
+    """Per-forward cache of packed weights: cleared at the start of every RP_Net.forward, so
+    weights are repacked once per step (never reused across optimizer steps)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def clear(self):
+        self._d.clear()
+
+    def get(self, weight, split=None):
+        key = (weight.data_ptr(), weight._version)
+        pw = self._d.get(key)
+        if pw is None:
+            pw = PackedWeight(weight.detach(), split)
+            self._d[key] = pw
+        return pw
+
+
+def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups=1, ep_scale=None, ep_shift=None,
+          ep_relu=0, out_scale=None, out_mode=0, accumulate=0, co_split=None):
+    d = ConvDesc()
+    d.x0, d.x1 = ptr(x0), ptr(x1)
+    d.C0 = x0.shape[-1]
+    d.C1 = x1.shape[-1] if x1 is not None else 0
+    d.w, d.bias = ptr(w), ptr(bias)
+    d.in_scale, d.in_scale_mode = ptr(in_scale), in_mode if in_scale is not None else 0
+    d.y0, d.y1 = ptr(y0), ptr(y1)
+    d.Co0 = y0.shape[-1] if co_split is None else co_split[0]
+    d.Co1 = (y1.shape[-1] if y1 is not None else 0) if co_split is None else co_split[1]
+    d.ep_scale, d.ep_shift, d.ep_relu = ptr(ep_scale), ptr(ep_shift), ep_relu
+    d.out_scale, d.out_scale_mode, d.accumulate = ptr(out_scale), out_mode if out_scale is not None else 0, accumulate
+    d.N, d.H, d.W, d.taps, d.upsample, d.groups = N, H, W, taps, ups, groups
+    return d
+
+
+# ------------------------------------------------------------- conv + BN + ReLU
+class ConvBnRelu(Function):
+    """Conv2d(3x3 p1 | 1x1, bias) -> BatchNorm2d -> ReLU on NHWC activations
+    (net/modules.py:47-49,66-69; net/rp_net.py:50-59,65-69).
+
+    x0 (,x1): sources concatenated along C; `in_scale` [N,h,w] with mode 1 (x*s) / 2 (x*(1-s));
+    `upsample`: nearest x2 in front of the conv; `groups`: BatchNorm statistic groups.
+    """
+
+    @staticmethod
+    def forward(ctx, x0, x1, in_scale, weight, bias, gamma, beta, running_mean, running_var, nbt, pw, training,
+                groups, upsample, in_mode):
+        hip.require_gpu(x0, weight)
+        N, Hs, Ws, _ = x0.shape
+        H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+        cout = weight.shape[0]
+        first = weight.shape[1] == 1 and weight.shape[2] == 3  # Cin = 1 direct convolution
+        z = _empty((N, H, W, cout), x0)
+        if not training:
+            scale, shift = _empty((cout,), x0), _empty((cout,), x0)
+            call("rpnet_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(scale),
+                 ptr(shift), cout)
+            if first:
+                call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout)
+            else:
+                d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
+                call("rpnet_conv_fwd", C.byref(d))
+            ctx.eval_mode = True
+            return z
+        y = _empty((N, H, W, cout), x0)
+        if first:
+            call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
+        else:
+            d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample)
+            call("rpnet_conv_fwd", C.byref(d))
+        stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
+        wsb = query("rpnet_bn_workspace_bytes", cout, groups)
+        ws = _ws(wsb, x0)
+        call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws), wsb)
+        if nbt is not None:
+            nbt += groups
+        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), N, H * W, cout, groups)
+        ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
+        ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        if ctx.eval_mode:
+            raise NotImplementedError("rpnet_amd: backward through eval-mode BatchNorm is not implemented "
+                                      "(the reference only evaluates under torch.no_grad, test_rpnet.py:163)")
+        x0, x1, in_scale, weight, gamma, y, stats = ctx.saved_tensors
+        pw = ctx.pw
+        groups, upsample, in_mode, first = ctx.cfg
+        dz = dz.contiguous()
+        N, H, W, cout = y.shape
+        wsb = query("rpnet_bn_workspace_bytes", cout, groups)
+        ws = _ws(wsb, y)
+        dy = torch.empty_like(y)
+        dgamma, dbeta = _empty((cout,), y), _empty((cout,), y)
+        call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             ptr(dy), ptr(dgamma), ptr(dbeta), N, H * W, cout, groups, ptr(ws), wsb)
+        dw = torch.empty_like(weight)
+        dx0 = dx1 = None
+        if first:
+            wb = query("rpnet_conv1_wgrad_workspace_bytes", N, H, W, cout)
+            ws2 = _ws(wb, y)
+            call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
+        else:
+            d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
+            d.y0 = None
+            d.Co0, d.Co1 = cout, 0
+            wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
+            ws2 = _ws(wb, y)
+            d.y0 = ptr(dy)  # unused by wgrad; keeps the descriptor self-consistent
+            call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+            need0 = ctx.needs_input_grad[0]
+            need1 = x1 is not None and ctx.needs_input_grad[1]
+            if need0 or need1:
+                c0, c1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+                g0 = _empty((N, H, W, c0), y)
+                g1 = _empty((N, H, W, c1), y) if x1 is not None else None
+                # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
+                dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
+                           out_scale=in_scale, out_mode=in_mode)
+                call("rpnet_conv_fwd", C.byref(dd))
+                if upsample:
+                    h0 = _empty(x0.shape, y)
+                    call("rpnet_upsample2_bwd", ptr(g0), ptr(h0), N, H, W, c0)
+                    g0 = h0
+                dx0 = g0 if need0 else None
+                dx1 = g1 if need1 else None
+        # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
+        db = torch.zeros_like(gamma)
+        return dx0, dx1, None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None):
+    pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
+    return ConvBnRelu.apply(x0, x1, in_scale, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                            bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
+                            1 if upsample else 0, in_mode)
+
+
+# ------------------------------------------------------------------------ pooling
+class MaxPool2(Function):
+    """nn.MaxPool2d(2, 2) (net/unet.py:397) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, z):
+        N, H, W, Cc = z.shape
+        out = _empty((N, H // 2, W // 2, Cc), z)
+        call("rpnet_maxpool2_fwd", ptr(z), ptr(out), N, H, W, Cc)
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpool):
+        (z,) = ctx.saved_tensors
+        N, H, W, Cc = z.shape
+        dz = torch.empty_like(z)
+        call("rpnet_maxpool2_bwd", ptr(z), ptr(dpool.contiguous()), None, ptr(dz), N, H, W, Cc)
+        return dz
+
+
+def mask_avgpool(mask, scale):
+    """F.avg_pool2d(mask[:, None], scale) (net/rp_net.py:269-272): [B,H,W] -> [B,h,w]; no gradient."""
+    B, H, W = mask.shape
+    out = _empty((B, H // scale, W // scale), mask)
+    call("rpnet_mask_avgpool", ptr(mask.contiguous().float()), ptr(out), B, H, W, scale)
+    return out
+
+
+# -------------------------------------------------------------------- correlation
+CORR_STRIDE = 128  # (2*5+1)^2 = 121 window channels padded to a GEMM-friendly 128
+
+
+class LocalCorr(Function):
+    """Correlation(fm1, fm2, r) (net/rp_net.py:153-181), NHWC, output [B,h,w,128] (zero padded)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, r):
+        B, h, w, Cc = f1.shape
+        corr = _empty((B, h, w, CORR_STRIDE), f1)
+        call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
+        ctx.save_for_backward(f1, f2)
+        ctx.r = r
+        return corr
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcorr):
+        f1, f2 = ctx.saved_tensors
+        B, h, w, Cc = f1.shape
+        df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+        wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
+        ws = _ws(wb, f1)
+        call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
+             CORR_STRIDE, ptr(ws), wb)
+        return df1, df2, None
+
+
+# ------------------------------------------------------------------------ matcher
+def mask_adjoint(masks, h, w):
+    """masks [nmask,B,H,W] -> (am [B,nmask,h*w], msum [B,nmask]): the bilinear-adjoint pooling
+    weights of getFeatures (net/rp_net.py:366-376), computed once per forward; no gradient."""
+    nmask, B, H, W = masks.shape
+    am, msum = _empty((B, nmask, h * w), masks), _empty((B, nmask), masks)
+    call("rpnet_mask_adjoint", ptr(masks.contiguous()), ptr(am), ptr(msum), B, nmask, H, W, h, w)
+    return am, msum
+
+
+class MaskedPool(Function):
+    """proto[b,k,:] = sum_q f[b,q,:]*am[b,k,q] / (msum[b,k] + 1e-5) (getFeatures, net/rp_net.py:366-376)."""
+
+    @staticmethod
+    def forward(ctx, f, am, msum):
+        B, h, w, Cc = f.shape
+        nmask = am.shape[1]
+        proto = _empty((B, nmask, Cc), f)
+        wb = query("rpnet_masked_pool_workspace_bytes", B, nmask, h * w, Cc)
+        ws = _ws(wb, f)
+        call("rpnet_masked_pool_fwd", ptr(f), ptr(am), ptr(msum), ptr(proto), B, nmask, h * w, Cc, ptr(ws), wb)
+        ctx.save_for_backward(am, msum)
+        ctx.shape = f.shape
+        return proto
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dproto):
+        am, msum = ctx.saved_tensors
+        B, h, w, Cc = ctx.shape
+        df = _empty(ctx.shape, dproto)
+        call("rpnet_masked_pool_bwd", ptr(dproto.contiguous()), ptr(am), ptr(msum), ptr(df), B, am.shape[1], h * w, Cc, 0)
+        return df, None, None
+
+
+class CosineMatchUp(Function):
+    """calDist x (1+Wa) -> stack -> F.interpolate(bilinear) (net/rp_net.py:301-303):
+    f [B,h,w,C], proto [B,K,C] -> (logits [B,K,H,W], pred [B,K,h,w] (not differentiable here))."""
+
+    @staticmethod
+    def forward(ctx, f, proto, H, W, scaler):
+        B, h, w, Cc = f.shape
+        K = proto.shape[1]
+        proto = proto.contiguous()
+        pred = _empty((B, K, h, w), f)
+        call("rpnet_cosine_match_fwd", ptr(f), ptr(proto), ptr(pred), B, K, h * w, Cc, float(scaler))
+        logits = _empty((B, K, H, W), f)
+        call("rpnet_bilinear_up_fwd", ptr(pred), ptr(logits), B * K, h, w, H, W)
+        ctx.save_for_backward(f, proto)
+        ctx.cfg = (H, W, float(scaler))
+        ctx.mark_non_differentiable(pred)
+        return logits, pred
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dlogits, _dpred):
+        f, proto = ctx.saved_tensors
+        H, W, scaler = ctx.cfg
+        B, h, w, Cc = f.shape
+        K = proto.shape[1]
+        dpred = _empty((B, K, h, w), f)
+        call("rpnet_bilinear_up_bwd", ptr(dlogits.contiguous()), ptr(dpred), B * K, h, w, H, W)
+        df, dproto = torch.empty_like(f), torch.empty_like(proto)
+        wb = query("rpnet_cosine_match_bwd_workspace_bytes", B, K, h * w, Cc)
+        ws = _ws(wb, f)
+        call("rpnet_cosine_match_bwd", ptr(f), ptr(proto), ptr(dpred), ptr(df), ptr(dproto), B, K, h * w, Cc, scaler, 0,
+             ptr(ws), wb)
+        return df, dproto, None, None, None
+
+
+def softmax_thresh_pool(logits, scale, soft):
+    """softmax(1)[:,1] -> (>0.5) unless soft -> avg_pool2d(scale) (net/rp_net.py:308-311); no gradient."""
+    B, K, H, W = logits.shape
+    out = _empty((B, H // scale, W // scale), logits)
+    call("rpnet_softmax_thresh_pool", ptr(logits), ptr(out), B, K, H, W, scale, 1 if soft else 0)
+    return out
+
+
+# ------------------------------------------------------------------------- losses
+class DiceCE(Function):
+    """dice_ce (net/rp_net.py:123-127); with_dice=False/ignore_index/per_sample give the
+    F.cross_entropy(ignore_index=255) term of alignLoss (net/rp_net.py:438)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, with_dice, ignore_index, per_sample, sample_weight):
+        B, K, H, W = logits.shape
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        loss = _empty((), logits)
+        stats = _empty(((B + 1) * (2 * K + 2),), logits)
+        wb = query("rpnet_loss_workspace_bytes", B, K, H, W)
+        ws = _ws(wb, logits)
+        call("rpnet_dice_ce_fwd", ptr(logits), ptr(labels), ptr(loss), ptr(stats), B, K, H, W, int(with_dice),
+             int(ignore_index), int(per_sample), ptr(sample_weight), ptr(ws), wb)
+        ctx.save_for_backward(logits, labels, stats, sample_weight)
+        ctx.cfg = (int(with_dice), int(ignore_index), int(per_sample))
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, stats, sample_weight = ctx.saved_tensors
+        with_dice, ignore_index, per_sample = ctx.cfg
+        B, K, H, W = logits.shape
+        dl = torch.empty_like(logits)
+        call("rpnet_dice_ce_bwd", ptr(logits), ptr(labels), ptr(stats), ptr(g.contiguous()), ptr(dl), B, K, H, W, with_dice,
+             ignore_index, per_sample, ptr(sample_weight), 0)
+        return dl, None, None, None, None, None
+
+
+def dice_ce(logits, true, eps=1e-7):
+    """Drop-in for net.rp_net.dice_ce on GPU tensors (eps is fixed at the reference's 1e-7)."""
+    return DiceCE.apply(logits, true, True, -1, False, None)
+
+
+def argmax_masks(pred):
+    """pred [B,K,h,w] -> (masks [B,K,h*w] one-hot of argmax, counts [B,K]) (net/rp_net.py:412-415)."""
+    B, K, h, w = pred.shape
+    masks, counts = _empty((B, K, h * w), pred), _empty((B, K), pred)
+    call("rpnet_argmax_masks", ptr(pred), ptr(masks), ptr(counts), B, K, h * w)
+    return masks, counts
+
+
+def align_labels(fore, back):
+    """1 = fore, 0 = back (wins), 255 = ignore (net/rp_net.py:433-436)."""
+    lab = torch.empty(fore.shape, device=fore.device, dtype=torch.int64)
+    call("rpnet_align_labels", ptr(fore.contiguous()), ptr(back.contiguous()), ptr(lab), fore.numel())
+    return lab

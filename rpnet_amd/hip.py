@@ -1,0 +1,111 @@
+"""ctypes binding of librpnet_hip.so (C ABI: include/rpnet_abi.h).
+
+This is the whole FFI surface: plain pointers, ints and a stream.  torch is used only
+to own device memory and to give the current HIP stream.  There is NO fallback: if the
+library is missing or a call fails, a RuntimeError is raised (the product path never
+routes through the CPU oracle).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librpnet_hip.so")
+_lib = None
+
+vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """struct rpnet_conv_desc"""
+    _fields_ = [("x0", vp), ("x1", vp), ("C0", ci), ("C1", ci), ("w", vp), ("bias", vp), ("in_scale", vp),
+                ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
+                ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
+                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci)]
+
+
+_SIGS = {
+    "rpnet_version": (ci, []),
+    "rpnet_last_error_string": (C.c_char_p, []),
+    "rpnet_pack_conv_weight": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
+    "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
+    "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
+    "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
+    "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
+    "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
+    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_maxpool2_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_maxpool2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_upsample2_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_mask_avgpool": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_local_corr_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_local_corr_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
+    "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_mask_adjoint": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_masked_pool_workspace_bytes": (cs, [ci, ci, ci, ci]),
+    "rpnet_masked_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_masked_pool_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_cosine_match_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, cf, vp]),
+    "rpnet_cosine_match_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
+    "rpnet_cosine_match_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci, vp, cs, vp]),
+    "rpnet_bilinear_up_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_bilinear_up_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_softmax_thresh_pool": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_loss_workspace_bytes": (cs, [ci, ci, ci, ci]),
+    "rpnet_dice_ce_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
+    "rpnet_dice_ce_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "rpnet_argmax_masks": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
+}
+ABI_SYMBOLS = tuple(_SIGS)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """dlopen librpnet_hip.so once; loud failure if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: build it with `make -C rpnet_amd/csrc` "
+                               "(or __graft_entry__.build()); rpnet_amd has no CPU fallback")
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current stream; raise on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.rpnet_last_error_string().decode()}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("rpnet_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback; "
+                               "the CPU restatement lives in oracle/ and is test infrastructure)")

@@ -1,0 +1,307 @@
+"""Host-side mirror of the reference's nn.Module surface for the RP-Net hot path.
+
+Same class names, constructor/forward signatures, yaml keys and state_dict keys as
+/root/reference/net/{modules,unet,rp_net}.py, so `test_rpnet.py` and reference
+checkpoints drop in unchanged; the arithmetic runs in librpnet_hip.so (fp32 MFMA /
+LDS-tiled HIP kernels) through rpnet_amd.functional.  The nn.Conv2d / nn.BatchNorm2d
+children are parameter containers only — they are never called.
+
+Internal activation layout is NHWC; NCHW tensors appear only at the module boundary.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as RF
+
+
+def _to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _to_nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _norm(normalization_type, ch):
+    if normalization_type != "BatchNorm2d":
+        raise NotImplementedError(f"unet_normalize_type={normalization_type!r}: only BatchNorm2d "
+                                  "(yamls/example.yml:41) has HIP kernels")
+    return nn.BatchNorm2d(ch)
+
+
+class conv_block(nn.Module):
+    """net/modules.py:42-58 — 2 x [Conv3x3(s1,p1,bias) -> BatchNorm2d -> ReLU]."""
+
+    def __init__(self, ch_in, ch_out, normalization_type, kernel=3, padding=1):
+        super().__init__()
+        assert kernel == 3 and padding == 1
+        self.ch_in, self.ch_out = ch_in, ch_out
+        self.conv = nn.Sequential(
+            nn.Conv2d(ch_in, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
+            _norm(normalization_type, ch_out), nn.ReLU(inplace=True),
+            nn.Conv2d(ch_out, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
+            _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
+
+    def forward_nhwc(self, x0, cache, x1=None, groups=1):
+        t = self.training
+        x = RF.conv_bn_relu(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups)
+        return RF.conv_bn_relu(x, self.conv[3], self.conv[4], cache, t, groups=groups)
+
+    def forward(self, x):
+        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
+
+
+class up_conv(nn.Module):
+    """net/modules.py:61-75 — nearest x2 -> Conv3x3 -> BatchNorm2d -> ReLU (up-sampling fused into the gather)."""
+
+    def __init__(self, ch_in, ch_out, normalization_type, kernel=3, padding=1):
+        super().__init__()
+        assert kernel == 3 and padding == 1
+        self.ch_in, self.ch_out = ch_in, ch_out
+        self.up = nn.Sequential(
+            nn.Upsample(scale_factor=2),
+            nn.Conv2d(ch_in, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
+            _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
+
+    def forward_nhwc(self, x, cache, groups=1):
+        return RF.conv_bn_relu(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True)
+
+    def forward(self, x):
+        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
+
+
+class Unet_2D(nn.Module):
+    """net/unet.py:351-360 (constructor state only; the losses there belong to LGCANet)."""
+
+    def __init__(self, cfg, img_ch=5, output_ch=6, t=2, pretrained=True, resnet_type="resnet18"):
+        super().__init__()
+        self.cfg = cfg
+        self.img_ch, self.t, self.pretrained, self.resnet_type = img_ch, t, pretrained, resnet_type
+        self.final_activation = cfg["final_activation"]
+        self.output_ch = output_ch
+
+    def set_mode(self, mode):
+        assert mode in ["train", "valid", "eval", "test"]
+        self.mode = mode
+        self.train(mode == "train")
+
+
+class U_Net(Unet_2D):
+    """net/unet.py:393-467 — encoder + half decoder, returns the 1/4-resolution 256-channel `d4`."""
+
+    def __init__(self, cfg, img_ch=1, output_ch=6, resnet_type=None):
+        super().__init__(cfg, img_ch, output_ch)
+        if cfg["mask_feature_map"]:
+            raise NotImplementedError(f"mask_feature_map={cfg['mask_feature_map']!r}: only the default "
+                                      "`no` (yamls/example.yml:103) is implemented on MI355X")
+        nt = cfg["unet_normalize_type"]
+        self.Maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
+        f = [64, 128, 256, 512, 1024]
+        self.Conv1 = conv_block(self.img_ch, f[0], nt)
+        self.Conv2 = conv_block(f[0], f[1], nt)
+        self.Conv3 = conv_block(f[1], f[2], nt)
+        self.Conv4 = conv_block(f[2], f[3], nt)
+        self.Conv5 = conv_block(f[3], f[4], nt)
+        self.Up5 = up_conv(f[4], f[3], nt)
+        self.Up_conv5 = conv_block(f[3] * 2, f[3], nt)
+        self.Up4 = up_conv(f[3], f[2], nt)
+        self.Up_conv4 = conv_block(f[2] * 2, f[2], nt)
+
+    def forward_nhwc(self, x, cache, groups=1):
+        """x [N,H,W,1]; `groups` consecutive image groups keep separate BatchNorm statistics
+        (= that many reference calls, in order)."""
+        if x.shape[1] % 16 or x.shape[2] % 16:
+            raise ValueError(f"U_Net needs H, W multiples of 16, got {tuple(x.shape[1:3])}")
+        pool = RF.MaxPool2.apply
+        x1 = self.Conv1.forward_nhwc(x, cache, groups=groups)
+        x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups)
+        x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups)
+        x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups)
+        x5 = self.Conv5.forward_nhwc(pool(x4), cache, groups=groups)
+        d5 = self.Up5.forward_nhwc(x5, cache, groups=groups)
+        d5 = self.Up_conv5.forward_nhwc(x4, cache, x1=d5, groups=groups)      # cat((x4, d5), 1) as two sources
+        d4 = self.Up4.forward_nhwc(d5, cache, groups=groups)
+        return self.Up_conv4.forward_nhwc(x3, cache, x1=d4, groups=groups)    # cat((x3, d4), 1)
+
+    def forward(self, x, mask=None, do_last_conv=True):
+        n, c, h, w = x.shape
+        assert c == 1
+        return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache()))}
+
+
+class ContextCorrelationEncoder(nn.Module):
+    """net/rp_net.py:45-84.  w_context / out are constructed (state_dict parity) and never used."""
+
+    def __init__(self, cfg, in_channels=3, radius=5):
+        super().__init__()
+        self.radius = cfg["mask_refinement_correlation_radius"]
+        num_feat = 64
+        cbr = lambda ci, co, k: nn.Sequential(nn.Conv2d(ci, co, k, padding=k // 2), nn.BatchNorm2d(co),  # noqa: E731
+                                              nn.ReLU(inplace=True))
+        self.w_k = cbr(in_channels, in_channels, 3)
+        self.w_q = cbr(in_channels, in_channels, 3)
+        self.w_context = cbr(in_channels * 2, in_channels, 1)
+        self.q = cbr(in_channels + (self.radius * 2 + 1) ** 2, num_feat, 1)
+        self.out = cbr(2 * in_channels, num_feat, 1)
+        if (2 * self.radius + 1) ** 2 > RF.CORR_STRIDE:
+            raise NotImplementedError("mask_refinement_correlation_radius > 5")
+
+    def forward_masked(self, fts, mask, cache):
+        """cre(fts*mask, fts*(1-mask)) with the mask multiply fused into the conv gather
+        (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC, mask [B,h,w] or None."""
+        t = self.training
+        m1, m2 = (1, 2) if mask is not None else (0, 0)
+        fm1 = RF.conv_bn_relu(fts, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1)
+        fm2 = RF.conv_bn_relu(fts, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2)
+        return self._tail(fm1, fm2, cache)
+
+    def _tail(self, fm1, fm2, cache):
+        corr = RF.LocalCorr.apply(fm1, fm2, self.radius)
+        kk = (2 * self.radius + 1) ** 2
+        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1, split=(kk, RF.CORR_STRIDE))
+
+    def forward(self, fm1, fm2):
+        cache = RF.WeightCache()
+        t = self.training
+        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t)
+        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t)
+        return _to_nchw(self._tail(a, b, cache))
+
+
+class RP_Net(nn.Module):
+    """net/rp_net.py:184-440 — few-shot segmentation with recurrent mask refinement.
+
+    cfg: {'align': bool, 'backbone': 'UNet'}; backbone_cfg: the whole yaml dict.
+    """
+
+    def __init__(self, in_channels=3, pretrained_path=None, cfg=None, backbone_cfg=None):
+        super().__init__()
+        self.pretrained_path = pretrained_path
+        self.config = cfg or {"align": False}
+        self.backbone_cfg = backbone_cfg
+        self.scale = backbone_cfg.get("scale", 4)
+        self.num_iter = backbone_cfg["n_iter_refinement"]
+        self.use_relation_enc = backbone_cfg.get("use_relation_enc", "relation")
+        backbone = self.config.get("backbone")
+        if backbone == "UNet":
+            self.encoder = U_Net(backbone_cfg)
+            num_feat = 256
+            if pretrained_path:
+                dic = torch.load(self.pretrained_path, map_location="cpu")["state_dict"]
+                self.load_state_dict(dic, strict=False)  # the reference loads before `cre` exists (:212-214)
+        elif backbone in ("vgg", "resnet"):
+            raise NotImplementedError(f"backbone={backbone!r}: unreachable in the reference too "
+                                      "(vgg.Encoder returns a tensor but RP_Net indexes ['d4'], net/rp_net.py:248-249)")
+        else:
+            raise NotImplementedError
+        if self.use_relation_enc != "relation":
+            raise NotImplementedError("use_relation_enc='concat' needs SimpleConcat, which the reference never defines "
+                                      "(net/rp_net.py:224)")
+        if self.scale != 4:
+            raise NotImplementedError("scale != 4: the UNet d4 map is 1/4 resolution")
+        self.cre = ContextCorrelationEncoder(backbone_cfg, in_channels=num_feat)
+        self._cache = RF.WeightCache()
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, registration_field=None, grid=None,
+                query_labels=None, appr_query_labels=None):
+        n_ways, n_shots, n_queries = len(supp_imgs), len(supp_imgs[0]), len(qry_imgs)
+        if n_queries != 1:
+            raise NotImplementedError("n_queries != 1 (the reference's reader only produces one, few_shot_reader.py:80)")
+        if self.num_iter < 1:
+            raise ValueError("n_iter_refinement must be >= 1")
+        B = supp_imgs[0][0].shape[0]
+        H, W = qry_imgs[0].shape[-2:]
+        h, w = H // self.scale, W // self.scale
+        cache = self._cache
+        cache.clear()  # packed weights live for one forward only
+
+        # ---- features: support and query through the encoder, separate BN statistics (:245-258)
+        supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
+        qry = qry_imgs[0].float()
+        ns = supp.shape[0]
+        if ns == B:
+            d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
+            supp_d4, qry_d4 = d4[:ns], d4[ns:]
+        else:
+            supp_d4 = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
+            qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
+        supp_d4 = supp_d4.reshape(n_ways, n_shots, B, h, w, -1)
+
+        # ---- support relation features, per (way, shot) with that shot's own mask (:269-275)
+        fore = [[m.float().contiguous() for m in way] for way in fore_mask]
+        back = [[m.float().contiguous() for m in way] for way in back_mask]
+        supp_fts = [[self.cre.forward_masked(supp_d4[wa, s], RF.mask_avgpool(fore[wa][s], self.scale), cache)
+                     for s in range(n_shots)] for wa in range(n_ways)]
+
+        # ---- prototypes: constant across iterations, computed once (:288-300)
+        fg_protos, bg_sum = [], 0
+        adj = {}
+        for wa in range(n_ways):
+            fg_w, bg_w = 0, 0
+            for s in range(n_shots):
+                am, msum = RF.mask_adjoint(torch.stack([back[wa][s], fore[wa][s]], 0), h, w)
+                adj[wa, s] = (am, msum)
+                p = RF.MaskedPool.apply(supp_fts[wa][s], am, msum)          # [B,2,C]: bg, fg
+                bg_w, fg_w = bg_w + p[:, 0], fg_w + p[:, 1]
+            fg_protos.append(fg_w / n_shots)
+            bg_sum = bg_sum + bg_w / n_shots
+        protos = torch.stack([bg_sum / n_ways] + fg_protos, 1).contiguous()  # [B,1+Wa,C]
+
+        # ---- refinement loop (:281-312)
+        soft = self.backbone_cfg["soft_mask"] != False  # noqa: E712 (the reference compares with ==)
+        if soft and torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("soft_mask=True: the gradient through the fed-back mask is not implemented")
+        qry_mask = RF.mask_avgpool(appr_query_labels.float(), self.scale)
+        refinement = {}
+        inter = pred = None
+        for i in range(self.num_iter):
+            inter = self.cre.forward_masked(qry_d4, qry_mask, cache)
+            logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
+            qry_mask = RF.softmax_thresh_pool(logits, self.scale, soft)
+            refinement[i] = logits
+        # final pass (:314-337) recomputes refinement[T-1] bit for bit: alias it
+        output = refinement[self.num_iter - 1]
+
+        align_loss = 0
+        if self.config["align"] and self.training:
+            align_loss = self.alignLoss(inter, pred, supp_fts, fore, back)
+        return {"output": output, "align_loss": align_loss, "refinement": refinement}
+
+    def alignLoss(self, qry_fts, pred, supp_fts, fore_mask, back_mask):
+        """net/rp_net.py:394-440, all B episodes at once; returns sum_epi(loss_epi) / B (:349).
+        qry_fts [B,h,w,C]; pred [B,1+Wa,h,w]; supp_fts[wa][s] [B,h,w,C]; masks[wa][s] [B,H,W]."""
+        n_ways, n_shots = len(fore_mask), len(fore_mask[0])
+        H, W = fore_mask[0][0].shape[-2:]
+        masks, counts = RF.argmax_masks(pred)                                # :412-415
+        qp = RF.MaskedPool.apply(qry_fts, masks, counts)                     # :416-417  [B,1+Wa,C]
+        loss = 0
+        for wa in range(n_ways):
+            keep = (counts[:, wa + 1] > 0).float()                           # skip_ways (:414,421), per episode
+            protos = torch.stack([qp[:, 0], qp[:, wa + 1]], 1).contiguous()
+            for s in range(n_shots):
+                logits, _ = RF.CosineMatchUp.apply(supp_fts[wa][s], protos, H, W, 20.0)   # :425-431
+                lab = RF.align_labels(fore_mask[wa][s], back_mask[wa][s])                 # :433-436
+                loss = loss + RF.DiceCE.apply(logits, lab, False, 255, True, keep) / n_shots / n_ways
+        return loss
+
+    # reference-named helpers kept for API parity (NCHW tensors, single episode)
+    def calDist(self, fts, prototype, scaler=20):
+        f = _to_nhwc(fts)
+        n, h, w, _ = f.shape
+        logits, _ = RF.CosineMatchUp.apply(f, prototype.reshape(1, 1, -1).expand(n, 1, -1).contiguous(), h, w, scaler)
+        return logits[:, 0]  # H == h: the bilinear stage is the identity
+
+    def getFeatures(self, fts, mask):
+        f = _to_nhwc(fts)
+        am, msum = RF.mask_adjoint(mask.float().reshape(1, *mask.shape), f.shape[1], f.shape[2])
+        return RF.MaskedPool.apply(f, am, msum)[:, 0]
+
+    def getPrototype(self, fg_fts, bg_fts):
+        n_ways, n_shots = len(fg_fts), len(fg_fts[0])
+        fg = [sum(way) / n_shots for way in fg_fts]
+        bg = sum([sum(way) / n_shots for way in bg_fts]) / n_ways
+        return fg, bg
+
+
+model_factory = {"RP_Net": RP_Net}

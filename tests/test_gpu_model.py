@@ -1,0 +1,193 @@
+"""GPU parity, model level: rpnet_amd.RP_Net (HIP path) against the golden vectors the
+reference produced (tests/golden/*.npz) and against the CPU oracle on the same seeded
+inputs; full-size runs are checked through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import episode_tensors, in_checksum, load_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3   # BASELINE.json north_star: outputs within 1e-3 relative fp32
+
+
+def build(cfg, training):
+    from rpnet_amd.modules import RP_Net
+    from rpnet_amd.utils.seeding import seed_module_
+    net = RP_Net(cfg={"align": True, "backbone": "UNet"}, backbone_cfg=cfg).to(DEV)
+    seed_module_(net)
+    net.train(training)
+    return net
+
+
+def total_loss(out, ql, scaler):
+    from rpnet_amd.functional import dice_ce
+    loss = dice_ce(out["output"], ql)
+    for v in out["refinement"].values():
+        loss = loss + dice_ce(v, ql)
+    return loss + scaler * out["align_loss"]
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def test_unet_and_cre_vs_oracle():
+    """encoder d4 (train: 2 statistic groups == 2 reference calls; eval) and one CRE call."""
+    from oracle import rpnet_oracle as O
+    from rpnet_amd import functional as RF
+    cfg = load_cfg(1)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(77, 2, 32)
+    for training in (True, False):
+        net = build(cfg, training)
+        P = O.seeded_params()
+        with torch.no_grad():
+            ref_s = O.unet_d4(P, si[0][0], training)
+            ref_q = O.unet_d4(P, qi[0], training)
+            x = torch.cat([si[0][0], qi[0]], 0).to(DEV)
+            d4 = net.encoder.forward_nhwc(x.reshape(4, 32, 32, 1), RF.WeightCache(), groups=2 if training else 1)
+            assert rel_err(nchw(d4[:2]), ref_s) < TOL and rel_err(nchw(d4[2:]), ref_q) < TOL
+            m = RF.mask_avgpool(fg[0][0].to(DEV), 4)
+            got = net.cre.forward_masked(d4[:2].contiguous(), m, RF.WeightCache())
+            sm = torch.nn.functional.avg_pool2d(fg[0][0][:, None], 4)
+            ref = O.cre(P, ref_s * sm, ref_s * (1 - sm), training, 5, False)
+            assert rel_err(nchw(got), ref) < TOL
+        if training:
+            sd = net.state_dict()
+            for k in ("encoder.Conv1.conv.1.running_mean", "encoder.Conv5.conv.4.running_var", "encoder.Up_conv4.conv.4.running_var",
+                      "cre.q.1.running_mean"):
+                assert rel_err(sd[k], P[k]) < 1e-4, k
+            assert int(sd["encoder.Conv3.conv.1.num_batches_tracked"]) == 2 and int(sd["cre.w_k.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("tag", ["m64_train", "m64_eval", "m128_train", "m256_train"])
+def test_model_vs_golden(golden, tag):
+    g = golden(tag)
+    size, B, T, training, seed = (int(v) for v in g["meta"])
+    training = bool(training)
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), ep = episode_tensors(seed, B, size, DEV)
+    assert np.allclose(in_checksum(ep), g["in_checksum"], rtol=0, atol=1e-6), "synthetic inputs drifted"
+    s_out, s_d4, s_f = (int(v) for v in g["strides"])
+    net = build(cfg, training)
+    with torch.set_grad_enabled(training):
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        loss = total_loss(out, ql, cfg["align_loss_scaler"])
+    assert out["output"] is out["refinement"][T - 1]
+    flips = 0
+    for i in range(T):
+        got = out["refinement"][i]
+        assert rel_err(got[..., ::s_out, ::s_out], g[f"refinement_{i}"]) < TOL, f"refinement[{i}]"
+        p = got.softmax(1)[:, 1]
+        assert abs(float((p > 0.5).float().mean()) - float(g[f"fg_frac_{i}"])) <= 1e-3
+        pred = (p > 0.5).long()
+        dice = 2.0 * (pred * ql).sum() / (pred.sum() + ql.sum() + 1e-7)
+        assert abs(float(dice) - float(g[f"dice_{i}"])) <= 1e-3, f"Dice deviation at iteration {i}"   # north_star bar
+        nm = torch.nn.functional.avg_pool2d((p > 0.5).float()[:, None], 4)
+        flips += int((nm.cpu() != torch.from_numpy(g[f"next_mask_{i}"])).sum())
+    assert rel_err(loss, g["loss"]) < TOL
+    if training:
+        assert rel_err(out["align_loss"], g["align_loss"]) < TOL
+        loss.backward()
+        unused = set(str(u) for u in g["unused"])
+        params = dict(net.named_parameters())
+        worst = 0.0
+        for n, ref, head in zip(g["grad_names"], g["grad_norms"], g["grad_heads"]):
+            n = str(n)
+            gr = params[n].grad
+            if n in unused:
+                assert gr is None, n
+                continue
+            if ref < 1e-4:          # conv biases in front of train-mode BN: analytically zero
+                assert gr.abs().max() < 1e-4
+                continue
+            e = abs(gr.double().norm().item() - ref) / ref
+            worst = max(worst, e)
+            assert e < 2e-3, f"grad norm {n}: rel {e:.2e}"
+            k = min(32, gr.numel())
+            assert (gr.flatten()[:k].cpu() - torch.from_numpy(head[:k])).abs().max() < 2e-3 * max(ref, 1e-3), n
+        sd = net.state_dict()
+        for k in g:
+            if k.startswith("sd."):
+                assert rel_err(sd[k[3:]].float(), g[k]) < 1e-4, k
+    print(f"{tag}: threshold flips vs reference {flips}")
+
+
+def test_teacher_forced_iterations(golden):
+    """Each refinement iteration reproduced independently from the reference's own mask
+    (hard-threshold flips cannot compound)."""
+    from rpnet_amd import functional as RF
+    g = golden("m64_train")
+    size, B, T, _, seed = (int(v) for v in g["meta"])
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV)
+    net = build(cfg, True)
+    with torch.no_grad():
+        out = net(si, fg, bg, qi, appr_query_labels=appr)          # also builds BN state like the reference step
+        net2 = build(cfg, True)
+        cache = RF.WeightCache()
+        x = torch.cat([si[0][0], qi[0]], 0).reshape(2 * B, size, size, 1)
+        d4 = net2.encoder.forward_nhwc(x, cache, groups=2)
+        sm = RF.mask_avgpool(fg[0][0], 4)
+        sf = net2.cre.forward_masked(d4[:B].contiguous(), sm, cache)
+        am, msum = RF.mask_adjoint(torch.stack([bg[0][0], fg[0][0]], 0), size // 4, size // 4)
+        protos = RF.MaskedPool.apply(sf, am, msum)
+        assert rel_err(protos, g["protos"]) < TOL
+        mask = RF.mask_avgpool(appr, 4)
+        for i in range(T):
+            inter = net2.cre.forward_masked(d4[B:].contiguous(), mask, cache)
+            logits, _ = RF.CosineMatchUp.apply(inter, protos, size, size, 20.0)
+            assert rel_err(logits, g[f"refinement_{i}"]) < TOL
+            assert rel_err(nchw(inter), g[f"inter_{i}"]) < TOL
+            mask = torch.from_numpy(g[f"next_mask_{i}"])[:, 0].to(DEV)   # the REFERENCE's mask
+    assert rel_err(out["output"], g["output"]) < TOL
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shape (1-way 1-shot, 256x256, T=5, batch 8): size-independent checks."""
+    cfg = load_cfg(5)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(1234, 8, 256, DEV)
+    net = build(cfg, True)
+    out = net(si, fg, bg, qi, appr_query_labels=appr)
+    loss = total_loss(out, ql, 1.0)
+    loss.backward()
+    assert out["output"].shape == (8, 2, 256, 256) and len(out["refinement"]) == 5
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert (out["output"].abs() <= 20.0 + 1e-3).all()                         # logits are 20 * cosine
+    sd = net.state_dict()
+    assert int(sd["encoder.Conv1.conv.1.num_batches_tracked"]) == 2            # support call + query call
+    assert int(sd["cre.w_k.1.num_batches_tracked"]) == 6                        # 1 + T CRE calls
+    assert int(sd["cre.out.1.num_batches_tracked"]) == 0                        # never used
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # episodes are independent given fixed BN statistics: in eval mode a batch equals its halves
+    net.eval()
+    with torch.no_grad():
+        full = net(si, fg, bg, qi, appr_query_labels=appr)["output"]
+        half = net([[si[0][0][:4]]], [[fg[0][0][:4]]], [[bg[0][0][:4]]], [qi[0][:4]], appr_query_labels=appr[:4])["output"]
+    assert rel_err(full[:4], half) < 1e-5
+    # determinism: same step twice -> bit-identical gradients (no atomics anywhere)
+    net2 = build(cfg, True)
+    out2 = net2(si, fg, bg, qi, appr_query_labels=appr)
+    total_loss(out2, ql, 1.0).backward()
+    for n, p in net2.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g1[n]), n
+
+
+def test_five_shot_extension_vs_composed_oracle():
+    """BASELINE config 3 shape class (multi-shot): no reference behaviour (net/rp_net.py:275,288
+    raise for n_shots > 1); pinned by the oracle composed from the reference's own pieces."""
+    from oracle import rpnet_oracle as O
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(55, 2, 64, "cpu", n_shots=3)
+    P = O.seeded_params()
+    with torch.no_grad():
+        ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=False)
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    with torch.no_grad():
+        out = net([[mv(s) for s in w] for w in si], [[mv(s) for s in w] for w in fg], [[mv(s) for s in w] for w in bg],
+                  [mv(qi[0])], appr_query_labels=mv(appr))
+    for i in range(2):
+        assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL

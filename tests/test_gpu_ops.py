@@ -1,0 +1,294 @@
+"""GPU parity, op level: every HIP kernel family through the C ABI against the CPU oracle
+(oracle/rpnet_oracle.py, pinned to the reference) and the committed golden vectors.
+Tolerance: fp32, 1e-3 relative as BASELINE.json's north_star states (most ops sit at 1e-5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err, rnd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def RF():
+    from rpnet_amd import functional
+    return functional
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _mk_layer(cin, cout, k, seed):
+    conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2)
+    bn = torch.nn.BatchNorm2d(cout)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        conv.weight.copy_((torch.rand(conv.weight.shape, generator=g) - 0.5) * (2.0 / (cin * k * k) ** 0.5))
+        conv.bias.copy_((torch.rand(cout, generator=g) - 0.5) * 0.2)
+        bn.weight.copy_(0.8 + 0.4 * torch.rand(cout, generator=g))
+        bn.bias.copy_((torch.rand(cout, generator=g) - 0.5) * 0.4)
+        bn.running_mean.copy_((torch.rand(cout, generator=g) - 0.5) * 0.2)
+        bn.running_var.copy_(0.5 + torch.rand(cout, generator=g))
+    return conv, bn
+
+
+def _ref_layer(conv, bn, x, training, upsample=False):
+    """torch CPU fp32 reference of Conv -> BN -> ReLU with the same parameters (fresh buffers)."""
+    import copy
+    c, b = copy.deepcopy(conv).cpu(), copy.deepcopy(bn).cpu()
+    b.train(training)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return F.relu(b(c(x))), c, b
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k
+    (2, 12, 10, 32, 64, 3),     # ragged M (240 pixels): tail rows of the 64x64 tile
+    (3, 16, 16, 64, 128, 3),
+    (1, 8, 8, 128, 256, 3),
+    (2, 16, 16, 256, 64, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,k", CONV_CASES)
+@pytest.mark.parametrize("training", [False, True])
+def test_conv_bn_relu(RF, N, H, W, cin, cout, k, training):
+    conv, bn = _mk_layer(cin, cout, k, 7)
+    x = rnd(1, N, cin, H, W)
+    go = rnd(2, N, cout, H, W)
+    xr = x.clone().requires_grad_(True)
+    ref, c_ref, b_ref = _ref_layer(conv, bn, xr, training)
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    bn.train(training)
+    xg = nhwc(x).to(DEV).requires_grad_(training)
+    with torch.set_grad_enabled(training):
+        z = RF.conv_bn_relu(xg, conv, bn, RF.WeightCache(), training)
+    assert rel_err(nchw(z), ref) < TOL
+    if training:
+        ref.backward(go)
+        z.backward(nhwc(go).to(DEV))
+        assert rel_err(nchw(xg.grad), xr.grad) < TOL
+        assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+        assert rel_err(bn.weight.grad, b_ref.weight.grad) < TOL
+        assert rel_err(bn.bias.grad, b_ref.bias.grad) < TOL
+        assert conv.bias.grad.abs().max() == 0          # analytically zero in front of train-mode BN
+        assert c_ref.bias.grad.abs().max() < 1e-4 * max(1.0, c_ref.weight.grad.abs().max().item())
+        assert rel_err(bn.running_mean, b_ref.running_mean) < 1e-5
+        assert rel_err(bn.running_var, b_ref.running_var) < 1e-5
+        assert int(bn.num_batches_tracked) == 1
+
+
+def test_conv_two_sources_upsample_and_groups(RF):
+    """cat((skip, up), 1) as two gathered sources; nearest x2 fused in the gather; two BN
+    statistic groups == two separate reference calls (support call, query call)."""
+    N, H, W = 4, 8, 8
+    conv, bn = _mk_layer(96, 64, 3, 11)
+    a, b = rnd(3, N, 64, H, W), rnd(4, N, 32, H, W)
+    go = rnd(5, N, 64, H, W)
+    import copy
+    c_ref, b_ref = copy.deepcopy(conv), copy.deepcopy(bn)
+    b_ref.train()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    outs = [F.relu(b_ref(c_ref(torch.cat([ar[i:i + 2], br[i:i + 2]], 1)))) for i in (0, 2)]   # two calls
+    ref = torch.cat(outs, 0)
+    ref.backward(go)
+    conv, bn = conv.to(DEV), bn.to(DEV).train()
+    ag, bg = nhwc(a).to(DEV).requires_grad_(True), nhwc(b).to(DEV).requires_grad_(True)
+    z = RF.conv_bn_relu(ag, conv, bn, RF.WeightCache(), True, x1=bg, groups=2)
+    z.backward(nhwc(go).to(DEV))
+    assert rel_err(nchw(z), ref) < TOL
+    assert rel_err(nchw(ag.grad), ar.grad) < TOL and rel_err(nchw(bg.grad), br.grad) < TOL
+    assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+    assert rel_err(bn.running_mean, b_ref.running_mean) < 1e-5 and rel_err(bn.running_var, b_ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 2
+    # up_conv: nearest x2 -> conv
+    conv2, bn2 = _mk_layer(64, 64, 3, 12)
+    xr = a.clone().requires_grad_(True)
+    ref2, c2, b2 = _ref_layer(conv2, bn2, xr, True, upsample=True)
+    go2 = rnd(6, N, 64, 2 * H, 2 * W)
+    ref2.backward(go2)
+    conv2, bn2 = conv2.to(DEV), bn2.to(DEV).train()
+    xg = nhwc(a).to(DEV).requires_grad_(True)
+    z2 = RF.conv_bn_relu(xg, conv2, bn2, RF.WeightCache(), True, upsample=True)
+    z2.backward(nhwc(go2).to(DEV))
+    assert rel_err(nchw(z2), ref2) < TOL
+    assert rel_err(nchw(xg.grad), xr.grad) < TOL and rel_err(conv2.weight.grad, c2.weight.grad) < TOL
+
+
+def test_conv_masked_inputs(RF):
+    """w_k(x*m) and w_q(x*(1-m)) with the mask multiply fused into the gather (net/rp_net.py:275)."""
+    N, H, W, Cc = 2, 8, 8, 64
+    x, m = rnd(7, N, Cc, H, W), torch.rand(N, H, W, generator=torch.Generator().manual_seed(8))
+    go = rnd(9, N, 64, H, W)
+    for mode in (1, 2):
+        conv, bn = _mk_layer(Cc, 64, 3, 13 + mode)
+        xr = x.clone().requires_grad_(True)
+        mm = m if mode == 1 else 1 - m
+        ref, c_ref, b_ref = _ref_layer(conv, bn, xr * mm[:, None], True)
+        ref.backward(go)
+        conv, bn = conv.to(DEV), bn.to(DEV).train()
+        xg = nhwc(x).to(DEV).requires_grad_(True)
+        z = RF.conv_bn_relu(xg, conv, bn, RF.WeightCache(), True, in_scale=m.to(DEV), in_mode=mode)
+        z.backward(nhwc(go).to(DEV))
+        assert rel_err(nchw(z), ref) < TOL
+        assert rel_err(nchw(xg.grad), xr.grad) < TOL and rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_first_conv_cin1(RF, training):
+    N, H, W = 2, 16, 24
+    conv, bn = _mk_layer(1, 64, 3, 21)
+    x, go = rnd(10, N, 1, H, W), rnd(11, N, 64, H, W)
+    ref, c_ref, b_ref = _ref_layer(conv, bn, x, training)
+    conv, bn = conv.to(DEV), bn.to(DEV).train(training)
+    with torch.set_grad_enabled(training):
+        z = RF.conv_bn_relu(x.reshape(N, H, W, 1).to(DEV), conv, bn, RF.WeightCache(), training)
+    assert rel_err(nchw(z), ref) < TOL
+    if training:
+        ref.backward(go)
+        z.backward(nhwc(go).to(DEV))
+        assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+        assert rel_err(bn.weight.grad, b_ref.weight.grad) < TOL
+
+
+def test_maxpool(RF):
+    x = rnd(12, 2, 32, 8, 12)
+    x[0, :, 0:2, 0:2] = 0.0  # a tie window: gradient goes to the first maximum
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2)
+    go = rnd(13, *ref.shape)
+    ref.backward(go)
+    xg = nhwc(x).to(DEV).requires_grad_(True)
+    out = RF.MaxPool2.apply(xg)
+    out.backward(nhwc(go).to(DEV))
+    assert torch.equal(nchw(out).cpu(), ref.detach())
+    assert torch.equal(nchw(xg.grad).cpu(), xr.grad)
+
+
+def test_mask_avgpool_and_threshold(RF):
+    m = (torch.rand(3, 32, 48, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    assert torch.equal(RF.mask_avgpool(m.to(DEV), 4).cpu(), F.avg_pool2d(m[:, None], 4)[:, 0])
+    lg = rnd(14, 3, 2, 32, 48)
+    for soft in (False, True):
+        p = lg.softmax(1)[:, 1]
+        ref = F.avg_pool2d(((p > 0.5).float() if not soft else p)[:, None], 4)[:, 0]
+        got = RF.softmax_thresh_pool(lg.to(DEV), 4, soft).cpu()
+        assert (got - ref).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dims", [(2, 32, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5)])
+def test_local_correlation(RF, dims):
+    from oracle import rpnet_oracle as O
+    b, c, h, w, r = dims
+    f1, f2 = rnd(11, b, c, h, w).requires_grad_(True), rnd(12, b, c, h, w).requires_grad_(True)
+    kk = (2 * r + 1) ** 2
+    go = rnd(13, b, kk, h, w)
+    ref = O.local_correlation(f1, f2, r)
+    g1, g2 = torch.autograd.grad(ref, [f1, f2], go)
+    a, bb = nhwc(f1.detach()).to(DEV).requires_grad_(True), nhwc(f2.detach()).to(DEV).requires_grad_(True)
+    out = RF.LocalCorr.apply(a, bb, r)
+    assert out.shape[-1] == 128 and out[..., kk:].abs().max() == 0      # zero padded window channels
+    gop = torch.zeros(b, h, w, 128)
+    gop[..., :kk] = go.permute(0, 2, 3, 1)
+    out.backward(gop.to(DEV))
+    assert rel_err(nchw(out[..., :kk]), ref) < 1e-4
+    assert rel_err(nchw(a.grad), g1) < 1e-4 and rel_err(nchw(bb.grad), g2) < 1e-4
+
+
+def test_local_correlation_golden(RF, golden):
+    g = golden("ops")
+    b, c, h, w, r = (int(v) for v in g["corr_r5_dims"])
+    f1, f2, go = rnd(11, b, c, h, w), rnd(12, b, c, h, w), rnd(13, b, 121, h, w)
+    a, bb = nhwc(f1).to(DEV).requires_grad_(True), nhwc(f2).to(DEV).requires_grad_(True)
+    out = RF.LocalCorr.apply(a, bb, r)
+    gop = torch.zeros(b, h, w, 128)
+    gop[..., :121] = go.permute(0, 2, 3, 1)
+    out.backward(gop.to(DEV))
+    assert rel_err(nchw(out[..., :121]), g["corr_r5_out"]) < 1e-4        # the reference's own Correlation()
+    assert rel_err(nchw(a.grad), g["corr_r5_g1"]) < 1e-4 and rel_err(nchw(bb.grad), g["corr_r5_g2"]) < 1e-4
+
+
+def test_masked_pool_golden_and_grad(RF, golden):
+    from oracle import rpnet_oracle as O
+    g = golden("ops")
+    fts, masks = torch.from_numpy(g["gf_fts"]), torch.from_numpy(g["gf_masks"])      # [1,8,6,5], [3,1,24,20]
+    f = nhwc(fts).to(DEV)
+    am, msum = RF.mask_adjoint(masks.to(DEV), 6, 5)                                   # nmask=3, B=1
+    proto = RF.MaskedPool.apply(f, am, msum)
+    assert rel_err(proto[0], g["gf_out"]) < 1e-4
+    assert proto[0, 2].abs().max() == 0                                               # empty mask
+    # gradient vs the as-written form, batch of 2, C = 64
+    ft = rnd(31, 2, 64, 8, 8).requires_grad_(True)
+    mk = (torch.rand(2, 2, 32, 32, generator=torch.Generator().manual_seed(2)) > 0.5).float()   # [nmask,B,H,W]
+    ref = torch.stack([torch.cat([O.get_features_as_written(ft[[e]], mk[k, [e]]) for k in range(2)], 0) for e in range(2)], 0)
+    go = rnd(32, 2, 2, 64)
+    (gr,) = torch.autograd.grad(ref, ft, go)
+    fg = nhwc(ft.detach()).to(DEV).requires_grad_(True)
+    am, msum = RF.mask_adjoint(mk.to(DEV), 8, 8)
+    out = RF.MaskedPool.apply(fg, am, msum)
+    out.backward(go.to(DEV))
+    assert rel_err(out, ref) < 1e-4 and rel_err(nchw(fg.grad), gr) < 1e-4
+
+
+def test_cosine_match_upsample(RF, golden):
+    from oracle import rpnet_oracle as O
+    B, Cc, h, w, H, W = 2, 64, 8, 6, 32, 24
+    f = rnd(41, B, Cc, h, w)
+    f[0, :, 0, 0] = 0                                     # zero feature vector -> cosine 0
+    p = rnd(42, B, 2, Cc)
+    fr, pr = f.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    pred = torch.stack([torch.stack([O.cal_dist(fr[[e]], pr[e, [k]]) for k in range(2)], 1)[0] for e in range(B)], 0)
+    ref = F.interpolate(pred, size=(H, W), mode="bilinear")
+    go = rnd(43, B, 2, H, W)
+    # keep the zero vector out of the gradient check (its reference gradient is 1/eps-scaled)
+    ref.backward(go)
+    fg, pg = nhwc(f).to(DEV).requires_grad_(True), p.to(DEV).requires_grad_(True)
+    logits, lo = RF.CosineMatchUp.apply(fg, pg, H, W, 20.0)
+    logits.backward(go.to(DEV))
+    assert rel_err(lo, pred) < 1e-4 and rel_err(logits, ref) < 1e-4
+    assert lo[0, :, 0, 0].abs().max() == 0
+    gf, gr = nchw(fg.grad).cpu(), fr.grad.clone()
+    gf[0, :, 0, 0] = 0; gr[0, :, 0, 0] = 0
+    assert rel_err(gf, gr) < 1e-3 and rel_err(pg.grad, pr.grad) < 1e-3
+    g = golden("ops")                                      # the reference's own calDist values
+    q = torch.from_numpy(g["cd_q"])
+    pp = torch.cat([torch.from_numpy(g["proto_bg"]), torch.from_numpy(g["proto_fg"])], 0)[None]
+    _, lo2 = RF.CosineMatchUp.apply(nhwc(q).to(DEV), pp.to(DEV), 6, 5, 20.0)
+    assert rel_err(lo2[0, 0], g["cd_bg"][0]) < 1e-4 and rel_err(lo2[0, 1], g["cd_fg"][0]) < 1e-4
+
+
+def test_dice_ce_golden(RF, golden):
+    g = golden("ops")
+    lg = torch.from_numpy(g["dce_logits"]).to(DEV).requires_grad_(True)
+    lab = torch.from_numpy(g["dce_labels"]).to(DEV)
+    loss = RF.dice_ce(lg, lab)
+    (loss * 1.5).backward()
+    assert rel_err(loss, g["dce_loss"]) < 1e-5
+    assert rel_err(lg.grad, 1.5 * g["dce_grad"]) < 1e-4
+
+
+def test_align_loss(golden):
+    """alignLoss against the reference's value and gradients (tests/golden/ops.npz) incl. the skip-way case."""
+    from rpnet_amd.modules import RP_Net
+    g = golden("ops")
+    net = RP_Net.__new__(RP_Net)
+    qf = nhwc(torch.from_numpy(g["al_qf"])).to(DEV).requires_grad_(True)             # [1,6,5,8]
+    sf = nhwc(torch.from_numpy(g["al_sf"])[0]).to(DEV).requires_grad_(True)          # [1,6,5,8]
+    fm = torch.from_numpy(g["al_fm"])[0].to(DEV)                                      # [1,24,20]
+    pred = torch.from_numpy(g["al_pred"]).to(DEV)
+    al = RP_Net.alignLoss(net, qf, pred, [[sf]], [[fm[0][None]]], [[1 - fm[0][None]]])
+    al.backward()
+    assert rel_err(al, g["al_loss"]) < 1e-4
+    assert rel_err(nchw(qf.grad), g["al_gq"]) < 1e-3 and rel_err(nchw(sf.grad)[None], g["al_gs"]) < 1e-3
+    pred_bg = pred.clone(); pred_bg[:, 0] = 10; pred_bg[:, 1] = -10
+    assert float(RP_Net.alignLoss(net, qf, pred_bg, [[sf]], [[fm[0][None]]], [[1 - fm[0][None]]])) == 0.0

@@ -1,0 +1,111 @@
+"""CPU tests of the host logic: C-ABI library loads and exports what include/rpnet_abi.h
+declares, module surface / state_dict parity, no-fallback behaviour, and the world-size-2
+gradient exchange over gloo."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from tests.helpers import load_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from rpnet_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "rpnet_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rpnet_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    assert os.path.exists(hip.lib_path()), "build librpnet_hip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(hip.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in rpnet_abi.h but not exported"
+    assert declared == set(hip.ABI_SYMBOLS), declared ^ set(hip.ABI_SYMBOLS)
+    lib.rpnet_version.restype = ctypes.c_int
+    assert lib.rpnet_version() >= 100                      # no compute call without a GPU
+
+
+def test_module_surface_and_state_dict():
+    from net.model import model_factory
+    from oracle.rpnet_oracle import param_shapes
+    cfg = load_cfg()
+    net = model_factory["RP_Net"](pretrained_path=None, cfg={"align": True, "backbone": "UNet"}, backbone_cfg=cfg)
+    sd = net.state_dict()
+    ps = param_shapes()
+    assert list(sd.keys()) == list(ps.keys()) and len(sd) == 147
+    assert all(tuple(sd[k].shape) == tuple(ps[k]) for k in ps)
+    assert sum(p.numel() for p in net.parameters()) == 34972800
+    import inspect
+    sig = inspect.signature(net.forward)
+    assert list(sig.parameters) == ["supp_imgs", "fore_mask", "back_mask", "qry_imgs", "registration_field", "grid",
+                                    "query_labels", "appr_query_labels"]
+    for bad in ("vgg", "resnet"):
+        with pytest.raises(NotImplementedError):
+            model_factory["RP_Net"](cfg={"align": True, "backbone": bad}, backbone_cfg=cfg)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing somewhere else."""
+    from rpnet_amd.modules import RP_Net
+    cfg = load_cfg(1)
+    net = RP_Net(cfg={"align": False, "backbone": "UNet"}, backbone_cfg=cfg)
+    x = torch.zeros(1, 1, 32, 32)
+    m = torch.zeros(1, 32, 32)
+    with pytest.raises(RuntimeError):
+        net([[x]], [[m]], [[1 - m]], [x], appr_query_labels=m)
+    src = open(os.path.join(ROOT, "rpnet_amd", "functional.py")).read() + open(os.path.join(ROOT, "rpnet_amd", "modules.py")).read()
+    assert "oracle" not in src.replace("CPU oracle", "").replace("oracle/", "")
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters, shard_episodes
+    torch.manual_seed(rank)                                  # different init per rank ...
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    broadcast_parameters(net)                                # ... replicated from rank 0
+    bucket = FlatGradBucket(net, skip_prefixes=("1.bias",))  # one tensor left out, like cre.w_context/out
+    xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    lo, hi = shard_episodes(8, rank, world)
+    bucket.zero()
+    net(xs[lo:hi]).square().sum().backward()
+    skipped = net[1].bias.grad.clone()
+    bucket.allreduce()
+    q.put((rank, lo, hi, bucket.flat.clone(), net[0].weight.detach().clone(), skipped, bucket.numel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, lo0, hi0, f0, w0, s0, n0), (r1, lo1, hi1, f1, w1, s1, n1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 8)
+    assert torch.equal(w0, w1)                               # broadcast replicated the weights
+    assert torch.equal(f0, f1) and n0 == 6 * 5 + 5 + 5 * 3   # identical averaged gradients, bias of layer 1 left out
+    # reference: single process over all 8 episodes, gradient / world
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    net(xs).square().sum().backward()
+    ref = torch.cat([net[0].weight.grad.flatten(), net[0].bias.grad.flatten(), net[1].weight.grad.flatten()]) / 2
+    assert torch.allclose(f0, ref, rtol=1e-5, atol=1e-6)
+    assert not torch.equal(s0, s1)                           # the skipped tensor was not exchanged
+
+
+def test_shard_episodes_ragged():
+    from rpnet_amd.parallel import shard_episodes
+    spans = [shard_episodes(10, r, 4) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_episodes(0, 0, 2) == (0, 0)
