@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: support/query pairs per second, forward+backward, 1-way 1-shot,
+256x256, T=5 refinement iterations, batch 8 per GPU (BASELINE.json configs[1]; configs[3] =
+the same per-GPU work on 8 GPUs with the RCCL gradient all-reduce -> weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = RP_Net.forward (train mode, align loss on) + the harness loss
+dice_ce(output) + sum_i dice_ce(refinement[i]) + align_loss (the reference has no train
+loop) + backward + the flat-bucket gradient all-reduce.  Synthetic CT-shaped
+episodes are generated once and are resident in HBM before the timed region; weights are
+name-seeded random init (no dataset / checkpoint exists offline).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: every C-ABI call of one extra
+step is bracketed by HIP events on the launch stream; the dominant kernel is the fp32-MFMA
+implicit-GEMM convolution (rpnet_conv_fwd: forward + dgrad launches).  `cpu_baseline` is
+the CPU oracle in as-written mode (= the reference's operator sequence) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GF_PER_PAIR = {(256, 5): 675.4, (128, 1): 138.5}  # algorithmic fwd+bwd GFLOP per pair
+
+
+def algorithmic_gf_per_pair(size, T, n_shots=1):
+    """encoder 82.22 GF/image fwd at 256^2, CRE 10.12 GF/call, backward = 2x forward."""
+    s = (size / 256.0) ** 2
+    imgs, cre_calls = n_shots + 1, n_shots + T
+    return 3.0 * (imgs * 82.22 + cre_calls * 10.12) * s
+
+
+def build_model(cfg, dev):
+    from rpnet_amd.modules import RP_Net
+    from rpnet_amd.utils.seeding import seed_module_
+    net = RP_Net(cfg={"align": True, "backbone": "UNet"}, backbone_cfg=cfg).to(dev)
+    seed_module_(net)
+    net.train()
+    return net
+
+
+def make_inputs(seed, B, size, dev):
+    from rpnet_amd.utils.synth import make_episode
+    ep = make_episode(seed, B, size)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    return ([[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], [[t(ep["support_bg"][0][0])]],
+            [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"]))
+
+
+def step(net, bucket, inp, scaler):
+    from rpnet_amd.functional import dice_ce
+    si, fg, bg, qi, ql, appr = inp
+    bucket.zero()
+    out = net(si, fg, bg, qi, appr_query_labels=appr)
+    loss = dice_ce(out["output"], ql)
+    for v in out["refinement"].values():
+        loss = loss + dice_ce(v, ql)
+    loss = loss + scaler * out["align_loss"]
+    loss.backward()
+    bucket.allreduce()
+    return loss
+
+
+def profile_step(net, bucket, inp, scaler):
+    """One extra step with every C-ABI call bracketed by HIP events on the launch stream."""
+    from rpnet_amd import hip
+    records = []
+    orig = hip.call
+
+    def timed(name, *args):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        flops = 0.0
+        if name in ("rpnet_conv_fwd", "rpnet_conv_wgrad"):
+            d = args[0]._obj
+            flops = 2.0 * d.N * d.H * d.W * (d.C0 + d.C1) * (d.Co0 + d.Co1) * d.taps
+        a.record()
+        orig(name, *args)
+        b.record()
+        records.append((name, flops, a, b))
+
+    hip.call = timed
+    import rpnet_amd.functional as RF
+    RF.call = timed
+    try:
+        step(net, bucket, inp, scaler)
+        torch.cuda.synchronize()
+    finally:
+        hip.call = orig
+        RF.call = orig
+    agg = {}
+    for name, flops, a, b in records:
+        e = agg.setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += a.elapsed_time(b) * 1e-3
+        e[2] += flops
+    return agg
+
+
+def cpu_baseline(cfg, size, T, seconds_budget=25.0):
+    """The CPU oracle in as-written mode (the reference's operator sequence: all-pairs
+    correlation + grid_sample, explicit bilinear up-sampling in getFeatures, prototypes per
+    iteration) fwd+bwd on the host cores, batch 1, same loss.  Bounded sample."""
+    from oracle import rpnet_oracle as O
+    from rpnet_amd.utils.synth import make_episode
+    ep = make_episode(1234, 1, size)
+    t = torch.from_numpy
+    si, fg, bg = [[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], [[t(ep["support_bg"][0][0])]]
+    qi, ql, appr = [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"])
+    P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True)
+
+    def one():
+        for p in P.values():
+            p.grad = None
+        out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True, as_written=True)
+        O.total_loss(out, ql, cfg["align_loss_scaler"]).backward()
+
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 8:
+            break
+    return {"value": n / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} fwd+bwd steps of batch 1 at {size}x{size}, T={T}, oracle as-written mode "
+                      f"(reference operator sequence), {el / n:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="episodes (support/query pairs) per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5, help="T refinement iterations")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
+    cfg["n_iter_refinement"] = args.iters
+    scaler = cfg["align_loss_scaler"]
+
+    from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
+    net = build_model(cfg, dev)
+    broadcast_parameters(net)
+    bucket = FlatGradBucket(net)
+    inp = make_inputs(1234 + rank, args.batch, args.size, dev)   # resident in HBM before timing
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(net, bucket, inp, scaler)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(net, bucket, inp, scaler)
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert torch.isfinite(loss).item()
+
+    pairs = world * args.batch * args.steps
+    value = pairs / el
+    gf_pair = algorithmic_gf_per_pair(args.size, args.iters)
+
+    result = None
+    if rank == 0:
+        agg = profile_step(net, bucket, inp, scaler)
+        conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0])
+        wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0])
+        achieved = conv[2] / conv[1] / 1e12
+        kern_total = sum(v[1] for v in agg.values())
+        result = {
+            "metric": "support/query pairs/sec (fwd+bwd, 1-shot 256x256, T=5)",
+            "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"1-way 1-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
+                                   f"(BASELINE configs[{1 if world == 1 else 3}]), train mode, align loss on, "
+                                   "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (rpnet_conv_fwd: conv forward + dgrad launches)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
+                         "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
+                         "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
+                         "whole_step_frac": round(value / world * gf_pair * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                         "gflop_per_pair": round(gf_pair, 1),
+                         "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
+                                               sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
+                         "sum_kernel_ms_per_step": round(1e3 * kern_total, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters)
+            result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

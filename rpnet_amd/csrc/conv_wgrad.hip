@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int* ksplit, int* steps_per_split) {
     *bm = (Cin % 128 == 0) ? 128 : 64;
     *bn = (Cout % 128 == 0) ? 128 : 64;
-    const long tiles = (long)(Cin / *bm) * (Cout / *bn) * taps;
+    long tiles = (long)(Cin / *bm) * (Cout / *bn) * taps;
+    if (tiles < 1) tiles = 1;  // unsupported shape: rpnet_conv_wgrad rejects it, keep the plan finite
     const int total_steps = (M + 31) / 32;
     int ks = (int)((768 + tiles - 1) / tiles);          // aim at >= ~3 blocks per CU
     ks = max(1, min(ks, max(1, total_steps / 8)));       // at least 8 K-steps per block

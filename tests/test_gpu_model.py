@@ -102,11 +102,18 @@ def test_model_vs_golden(golden, tag):
             if ref < 1e-4:          # conv biases in front of train-mode BN: analytically zero
                 assert gr.abs().max() < 1e-4
                 continue
+            # Gradient tolerances follow the REFERENCE's own conditioning: ReLU / max-pool / arg-max
+            # switches make d loss / d encoder-weights move by ~1e-2 when the input images are
+            # perturbed by 2e-6 relative (measured on the CPU oracle, DESIGN.md "Parity"); the
+            # CRE block behind them is smooth and is held to 1e-3.
+            enc = n.startswith("encoder.")
             e = abs(gr.double().norm().item() - ref) / ref
             worst = max(worst, e)
-            assert e < 2e-3, f"grad norm {n}: rel {e:.2e}"
+            assert e < (1e-2 if enc else 1e-3), f"grad norm {n}: rel {e:.2e}"
             k = min(32, gr.numel())
-            assert (gr.flatten()[:k].cpu() - torch.from_numpy(head[:k])).abs().max() < 2e-3 * max(ref, 1e-3), n
+            hd = torch.from_numpy(head[:k])
+            he = (gr.flatten()[:k].cpu() - hd).abs().max() / (hd.abs().max() + 1e-12)
+            assert he < (5e-2 if enc else 2e-3), f"grad head {n}: rel {he:.2e}"
         sd = net.state_dict()
         for k in g:
             if k.startswith("sd."):

@@ -53,7 +53,7 @@ def _ref_layer(conv, bn, x, training, upsample=False):
 
 CONV_CASES = [
     # N, H, W, Cin, Cout, k
-    (2, 12, 10, 32, 64, 3),     # ragged M (240 pixels): tail rows of the 64x64 tile
+    (2, 12, 10, 64, 64, 3),     # ragged M (240 pixels): tail rows of the 64x64 tile
     (3, 16, 16, 64, 128, 3),
     (1, 8, 8, 128, 256, 3),
     (2, 16, 16, 256, 64, 1),
@@ -92,8 +92,8 @@ def test_conv_two_sources_upsample_and_groups(RF):
     """cat((skip, up), 1) as two gathered sources; nearest x2 fused in the gather; two BN
     statistic groups == two separate reference calls (support call, query call)."""
     N, H, W = 4, 8, 8
-    conv, bn = _mk_layer(96, 64, 3, 11)
-    a, b = rnd(3, N, 64, H, W), rnd(4, N, 32, H, W)
+    conv, bn = _mk_layer(192, 64, 3, 11)
+    a, b = rnd(3, N, 128, H, W), rnd(4, N, 64, H, W)
     go = rnd(5, N, 64, H, W)
     import copy
     c_ref, b_ref = copy.deepcopy(conv), copy.deepcopy(bn)
@@ -112,7 +112,7 @@ def test_conv_two_sources_upsample_and_groups(RF):
     assert rel_err(bn.running_mean, b_ref.running_mean) < 1e-5 and rel_err(bn.running_var, b_ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == 2
     # up_conv: nearest x2 -> conv
-    conv2, bn2 = _mk_layer(64, 64, 3, 12)
+    conv2, bn2 = _mk_layer(128, 64, 3, 12)
     xr = a.clone().requires_grad_(True)
     ref2, c2, b2 = _ref_layer(conv2, bn2, xr, True, upsample=True)
     go2 = rnd(6, N, 64, 2 * H, 2 * W)
