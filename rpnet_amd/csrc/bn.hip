@@ -54,34 +54,39 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
+// one 64-lane wave per channel: lanes stride over the per-block partials, xor-shuffle sum
+__global__ __launch_bounds__(64) void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* running_mean, float* running_var, float momentum, float eps,
                                   float* scale, float* shift, float* mean, float* invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {  // sequential: one running-stat update per group, in call order
         double s = 0, q = 0;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = lane; b < nblk; b += 64) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s += p[0]; q += p[1];
         }
+        s = wave_sum(s); q = wave_sum(q);
         const double m = s / (double)R;
         double var = q / (double)R - m * m;
         if (var < 0) var = 0;
         const float istd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * istd;
-        scale[g * C + c] = sc;
-        shift[g * C + c] = beta[c] - (float)m * sc;
-        mean[g * C + c] = (float)m;
-        invstd[g * C + c] = istd;
+        if (lane == 0) {
+            scale[g * C + c] = sc;
+            shift[g * C + c] = beta[c] - (float)m * sc;
+            mean[g * C + c] = (float)m;
+            invstd[g * C + c] = istd;
+        }
         const float unb = (float)(R > 1 ? var * (double)R / (double)(R - 1) : var);
         rm = (1.f - momentum) * rm + momentum * (float)m;
         rv = (1.f - momentum) * rv + momentum * unb;
     }
-    if (running_mean) running_mean[c] = rm;
-    if (running_var) running_var[c] = rv;
+    if (lane == 0) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -152,23 +157,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 }
 
 // coef[g][C][2] floats = (s1/R, s2/R); dgamma/dbeta summed over groups
-__global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G, float* coef,
-                                float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
+                                float* coef, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     for (int g = 0; g < G; ++g) {
         double s1 = 0, s2 = 0;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = lane; b < nblk; b += 64) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
         }
-        coef[(g * C + c) * 2] = (float)(s1 / (double)R);
-        coef[(g * C + c) * 2 + 1] = (float)(s2 / (double)R);
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            coef[(g * C + c) * 2] = (float)(s1 / (double)R);
+            coef[(g * C + c) * 2 + 1] = (float)(s2 / (double)R);
+        }
         tb += s1; tg += s2;
     }
-    dgamma[c] = (float)tg;
-    dbeta[c] = (float)tb;
+    if (lane == 0) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz, const float* __restrict__ y,
@@ -229,7 +235,7 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     const BnGeom gm = bn_geom(R, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace, gm.nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, s, (const double*)workspace, gm.nblk, R, C,
                        groups, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     return check_launch("bn_stats");
 }
@@ -271,7 +277,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     float* coef = (float*)((char*)workspace + (size_t)groups * 256 * C * 2 * sizeof(double));
     hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
                        R, C, gm);
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, (const double*)partial, gm.nblk, R, C, groups,
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(64), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                        coef, dgamma, dbeta);
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,

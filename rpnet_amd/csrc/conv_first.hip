@@ -84,12 +84,12 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
     }
 }
 
-__global__ void conv1_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(64) void conv1_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int n) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
-    dw[i] = (float)s;
+    for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * n + i];
+    s = wave_sum(s);
+    if (lane == 0) dw[i] = (float)s;
 }
 
 constexpr int kConv1WgradBlocks = 1024;
@@ -128,6 +128,6 @@ extern "C" int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv1_wgrad_partial, dim3(nb), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
                        (float*)workspace, N, H, W, cout);
-    hipLaunchKernelGGL(conv1_wgrad_final, dim3(cdiv(cout * 9, 128)), dim3(128), 0, s, (const float*)workspace, dw, nb, cout * 9);
+    hipLaunchKernelGGL(conv1_wgrad_final, dim3(cout * 9), dim3(64), 0, s, (const float*)workspace, dw, nb, cout * 9);
     return check_launch("conv1_wgrad");
 }

@@ -10,6 +10,8 @@
 // workspace [ksplit][taps][Cin][Cout]; rpnet_wgrad_reduce sums the splits and transposes
 // into the nn.Conv2d state_dict layout [Cout][Cin][kh][kw] through LDS so that both the
 // reads (along cout) and the writes (along cin,tap) are coalesced.
+#include <algorithm>
+
 #include "common.h"
 
 namespace rpnet {
@@ -136,38 +138,216 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 weight gradient, all nine taps in one block.  The single-tap kernel above streams the x
+// and dy pixel rows once per tap (arithmetic intensity 16-32 FLOP/B at the L2: bandwidth-bound,
+// 32-80 TF measured).  Here a block owns a 64(cin) x 64(cout) tile for ALL taps: per K-step of
+// 32 pixels it stages three x strips S_ky[j] = x[p0 - 1 + j + ky*W] (j = 0..33; rows whose
+// source image row is outside the image are zero) and the dy rows once, and runs 9 x 16 MFMAs
+// per wave against nine accumulators (144 registers): A(tap ky,kx)[k] = S_ky[k + kx + 1].  The
+// horizontal border (ox + kx outside the row) cannot be folded into the strips because one
+// strip row serves three taps; it is a per-pixel 0/1 factor on the kx = +-1 fragments.
+// 69 FLOP per staged byte, two blocks per CU.
+template <bool POW2>
+__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_desc d, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, const int M, const int Cin,
+                                                              const int Cout, const int tiles, const int tiles_n,
+                                                              const int ksplit, const int steps_per_split,
+                                                              const int lw, const int lh) {
+    constexpr int BM = 64, BN = 64, BK = 32, SJ = BK + 2;
+    constexpr int A_IT = (3 * SJ * (BM / 4) + 255) / 256;  // 7
+    __shared__ __attribute__((aligned(16))) float smem[3 * SJ * BM + BK * BN + 2 * BK];
+    float* As = smem;                    // [3][34][64]
+    float* Bs = smem + 3 * SJ * BM;      // [32][64]
+    float* vm = Bs + BK * BN;            // [2][32]: kx = -1 / kx = +1 validity of pixel k
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    // XCD-aware order: the blocks of one pixel chunk (all tiles) run on the same XCD, so the
+    // x / dy rows they share are fetched into that XCD's L2 once.
+    int tile, z;
+    if ((ksplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        z = (j / tiles) * 8 + xcd;
+        tile = j - (j / tiles) * tiles;
+    } else {
+        z = blockIdx.x / tiles;
+        tile = blockIdx.x - z * tiles;
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int cm0 = tm * BM, n0 = tn * BN;
+
+    const int H = d.H, W = d.W, HW = H * W;
+    const int ups = d.upsample;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const float* src; int Cs, cc;
+    if (cm0 < d.C0) { src = d.x0; Cs = d.C0; cc = cm0; } else { src = d.x1; Cs = d.C1; cc = cm0 - d.C0; }
+
+    const int total_steps = (M + BK - 1) / BK;
+    const int s_begin = z * steps_per_split;
+    const int s_end = min(s_begin + steps_per_split, total_steps);
+
+    f32x4 ra[A_IT], rb[2];
+    float rv = 0.f;
+    auto load_tile = [&](int st) {
+        const int p0 = st * BK;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int e = t + 256 * i;
+            const int c4 = e & 15, r = e >> 4;          // r in [0, 3*34)
+            const int kyi = r / SJ, j = r - kyi * SJ;   // strip, position
+            const int q = p0 - 1 + j + (kyi - 1) * W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < 3 * SJ && q >= 0 && q < M) {
+                int n, yq, xq;
+                if (POW2) { xq = q & (W - 1); yq = (q >> lw) & (H - 1); n = q >> (lw + lh); }
+                else { n = q / HW; const int rem = q - n * HW; yq = rem / W; xq = rem - yq * W; }
+                const int yp = yq - (kyi - 1);              // row of the output pixel this source serves
+                if (yp >= 0 && yp < H) {
+                    const size_t pix = ((size_t)n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+                    v = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4);
+                    if (d.in_scale_mode) {
+                        float s = d.in_scale[pix];
+                        if (d.in_scale_mode == 2) s = 1.f - s;
+                        v *= s;
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = t + 256 * i;
+            const int prow = e >> 4, c4 = e & 15;
+            const int p = p0 + prow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + n0 + c4 * 4);
+            rb[i] = v;
+        }
+        if (t < 2 * BK) {
+            const int k = t & (BK - 1), p = p0 + k;
+            const int ox = POW2 ? (p & (W - 1)) : (p % W);
+            rv = (t < BK) ? (ox >= 1 ? 1.f : 0.f) : (ox <= W - 2 ? 1.f : 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int e = t + 256 * i;
+            if (e < 3 * SJ * (BM / 4)) *reinterpret_cast<f32x4*>(&As[e * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[(t + 256 * i) * 4]) = rb[i];
+        if (t < 2 * BK) vm[t] = rv;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_tile(s_begin);
+        store_tile();
+        __syncthreads();
+        for (int st = s_begin; st < s_end; ++st) {
+            const bool more = st + 1 < s_end;
+            if (more) load_tile(st + 1);
+            const float* ap = As + wm * 32 + li;
+            const float* bp = Bs + wn * 32 + li;
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                const int k = kp * 2 + h;
+                const float b = bp[k * BN];
+                const float mm = vm[k], mp = vm[BK + k];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float am = ap[(ky * SJ + k) * BM] * mm;
+                    const float a0 = ap[(ky * SJ + k + 1) * BM];
+                    const float a1 = ap[(ky * SJ + k + 2) * BM] * mp;
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[ky * 3 + 2], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) store_tile();
+            __syncthreads();
+        }
+    }
+    if (z >= ksplit) return;
+    const int col = n0 + wn * 32 + li;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* out = partial + ((size_t)(z * 9 + tap) * Cin) * Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = cm0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)row * Cout + col] = acc[tap][r];
+        }
+    }
+}
+
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// split-K plan of the nine-tap kernel: ~1024 blocks, >= 8 K-steps each, <= 64 MiB of partials
+static void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
+    const int tiles = (Cin / 64) * (Cout / 64);
+    const int total_steps = (M + 31) / 32;
+    long ks = (1024 + tiles - 1) / tiles;
+    ks = std::min<long>(ks, std::max(1, total_steps / 8));
+    ks = std::min<long>(ks, std::max<long>(1, (64L << 20) / ((long)9 * Cin * Cout * 4)));
+    if (ks >= 8) ks = (ks / 8) * 8;
+    *steps_per_split = (int)((total_steps + ks - 1) / ks);
+    int k2 = (total_steps + *steps_per_split - 1) / *steps_per_split;
+    if (ks >= 8) k2 = ((k2 + 7) / 8) * 8;  // keep the XCD mapping; surplus chunks are empty
+    *ksplit = k2;
+}
+
 // partial [ksplit][taps][Cin_g][Cout]  ->  dw [Cout][cin_w][taps]
+// grid (cin/32, cout/32, taps): a block sums one 32x32 tile of one tap over the K splits
+// (8 row groups x 32 lanes read 128-byte rows of every split) and writes it transposed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                             int ksplit, int taps, int Cin_g, int Cout, int cin_w,
                                                             int off0, int split, int off1) {
-    __shared__ float tile[9][32][33];
+    __shared__ float tile[32][33];
     const int t = threadIdx.x;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
     const int cl = t & 31;
-    for (int tap = 0; tap < taps; ++tap) {
+    const size_t zstride = (size_t)taps * Cin_g * Cout;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int rr = (t >> 5) + 8 * jj;
-            const int cin = ci0 + rr;
-            float s = 0.f;
-            if (cin < cin_w) {
-                const int row = cin < split ? off0 + cin : off1 + (cin - split);
-                const float* p = partial + ((size_t)tap * Cin_g + row) * Cout + co0 + cl;
-                const size_t zstride = (size_t)taps * Cin_g * Cout;
-                for (int z = 0; z < ksplit; ++z) s += p[z * zstride];
+    for (int jj = 0; jj < 4; ++jj) {
+        const int rr = (t >> 5) + 8 * jj;
+        const int cin = ci0 + rr;
+        float s = 0.f;
+        if (cin < cin_w) {
+            const int row = cin < split ? off0 + cin : off1 + (cin - split);
+            const float* p = partial + ((size_t)tap * Cin_g + row) * Cout + co0 + cl;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int z = 0;
+            for (; z + 4 <= ksplit; z += 4) {
+                s0 += p[(size_t)z * zstride]; s1 += p[(size_t)(z + 1) * zstride];
+                s2 += p[(size_t)(z + 2) * zstride]; s3 += p[(size_t)(z + 3) * zstride];
             }
-            tile[tap][rr][cl] = s;
+            for (; z < ksplit; ++z) s0 += p[(size_t)z * zstride];
+            s = (s0 + s1) + (s2 + s3);
         }
+        tile[rr][cl] = s;
     }
     __syncthreads();
-    const int ncin = min(32, cin_w - ci0);
-    const int nel = ncin * taps;
-    for (int col = 0; col < 32; ++col) {
-        float* o = dw + ((size_t)(co0 + col) * cin_w + ci0) * taps;
-        for (int e = t; e < nel; e += 256) {
-            const int c = e / taps, tap = e - c * taps;
-            o[e] = tile[tap][c][col];
-        }
+    // thread -> (cout = t >> 3, 4 consecutive cin): writes are taps*4 B apart along cin
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int col = t >> 3, c = (t & 7) * 4 + jj;
+        if (ci0 + c < cin_w) dw[((size_t)(co0 + col) * cin_w + ci0 + c) * taps + tap] = tile[c][col];
     }
 }
 
@@ -227,6 +407,11 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
 }  // namespace rpnet
 
 extern "C" size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps) {
+    if (taps == 9 && cin_gathered % 64 == 0 && cout % 64 == 0) {
+        int ks9, sps9;
+        rpnet::wgrad9_plan(N * H * W, cin_gathered, cout, &ks9, &sps9);
+        return (size_t)ks9 * 9 * cin_gathered * cout * sizeof(float);
+    }
     int bm, bn, ks, sps;
     rpnet::wgrad_plan(N * H * W, cin_gathered, cout, taps, &bm, &bn, &ks, &sps);
     return (size_t)ks * taps * cin_gathered * cout * sizeof(float);
@@ -241,12 +426,33 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
     RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
     const int M = d->N * d->H * d->W;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->taps == 9) {
+        RPNET_REQUIRE(d->C1 == 0 || d->C0 % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to 64", d->C0);
+        int ks9, sps9;
+        wgrad9_plan(M, Cin, Cout, &ks9, &sps9);
+        const size_t need9 = (size_t)ks9 * 9 * Cin * Cout * sizeof(float);
+        RPNET_REQUIRE(workspace_bytes >= need9, RPNET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", workspace_bytes, need9);
+        const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;
+        const int lw = ilog2_exact(d->W), lh = ilog2_exact(d->H);
+        float* part9 = (float*)workspace;
+        if (lw >= 0 && lh >= 0)
+            hipLaunchKernelGGL((conv_wgrad9_kernel<true>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout,
+                               tiles9, tiles_n9, ks9, sps9, lw, lh);
+        else
+            hipLaunchKernelGGL((conv_wgrad9_kernel<false>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout,
+                               tiles9, tiles_n9, ks9, sps9, 0, 0);
+        int rc9 = check_launch("conv_wgrad9");
+        if (rc9) return rc9;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
+                           Cout, cin_w, cin_off0, cin_split, cin_off1);
+        return check_launch("wgrad_reduce");
+    }
     int bm, bn, ks, sps;
     wgrad_plan(M, Cin, Cout, d->taps, &bm, &bn, &ks, &sps);
     RPNET_REQUIRE(d->C1 == 0 || d->C0 % bm == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to tile %d", d->C0, bm);
     const size_t need = (size_t)ks * d->taps * Cin * Cout * sizeof(float);
     RPNET_REQUIRE(workspace_bytes >= need, RPNET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", workspace_bytes, need);
-    hipStream_t s = (hipStream_t)stream;
     const int tiles_n = Cout / bn, tiles = (Cin / bm) * tiles_n;
     dim3 grid(tiles, d->taps, ks);
     float* part = (float*)workspace;
@@ -260,7 +466,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32), dim3(256), 0, s, part, dw, ks, d->taps,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, d->taps), dim3(256), 0, s, part, dw, ks, d->taps,
                        Cin, Cout, cin_w, cin_off0, cin_split, cin_off1);
     return check_launch("wgrad_reduce");
 }

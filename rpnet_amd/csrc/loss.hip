@@ -47,21 +47,30 @@ __global__ __launch_bounds__(256) void dice_ce_partial(const float* __restrict__
 }
 
 // stats: [B][2K+2] per sample, then [2K+2] totals.  loss[0] = dice + ce.
-__global__ void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats, float* __restrict__ loss, int B,
-                              int K, int nblk, int with_dice, int per_sample, const float* __restrict__ sample_weight) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One 256-thread block: each wave sums the per-block partials of one (sample, slot) pair at a
+// time; thread 0 then does the O(B*K) scalar combine.
+__global__ __launch_bounds__(256) void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats,
+                                                      float* __restrict__ loss, int B, int K, int nblk, int with_dice,
+                                                      int per_sample, const float* __restrict__ sample_weight) {
+    extern __shared__ double sums[];  // [B][S]
     const int S = 2 * K + 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int idx = wv; idx < B * S; idx += 4) {
+        const int b = idx / S, j = idx - b * S;
+        double v = 0;
+        for (int blk = lane; blk < nblk; blk += 64) v += partial[((size_t)b * nblk + blk) * S + j];
+        v = wave_sum(v);
+        if (lane == 0) sums[idx] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double tot[2 * kMaxCls + 2];
     for (int j = 0; j < S; ++j) tot[j] = 0;
     double ce_ps = 0;
     for (int b = 0; b < B; ++b) {
-        double sb[2 * kMaxCls + 2];
-        for (int j = 0; j < S; ++j) sb[j] = 0;
-        for (int blk = 0; blk < nblk; ++blk)
-            for (int j = 0; j < S; ++j) sb[j] += partial[((size_t)b * nblk + blk) * S + j];
-        for (int j = 0; j < S; ++j) { stats[b * S + j] = (float)sb[j]; tot[j] += sb[j]; }
+        for (int j = 0; j < S; ++j) { stats[b * S + j] = (float)sums[b * S + j]; tot[j] += sums[b * S + j]; }
         const double wgt = sample_weight ? (double)sample_weight[b] : 1.0;
-        if (wgt != 0.0) ce_ps += wgt * sb[2 * K] / sb[2 * K + 1];
+        if (wgt != 0.0) ce_ps += wgt * sums[b * S + 2 * K] / sums[b * S + 2 * K + 1];
     }
     for (int j = 0; j < S; ++j) stats[B * S + j] = (float)tot[j];
     double l = per_sample ? ce_ps / (double)B : tot[2 * K] / tot[2 * K + 1];
@@ -170,7 +179,7 @@ extern "C" int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, flo
     RPNET_REQUIRE(workspace_bytes >= rpnet_loss_workspace_bytes(B, K, H, W), RPNET_ERR_WORKSPACE, "dice_ce_fwd: workspace");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B), dim3(256), 0, s, logits, labels, (double*)workspace, K, H * W, ignore_index);
-    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(64), 0, s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
+    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(256), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
                        per_sample, sample_weight);
     return check_launch("dice_ce_fwd");
 }
