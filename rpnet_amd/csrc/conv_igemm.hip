@@ -16,21 +16,25 @@
 // B as [8][BN][4].  Register-prefetch pipeline: global loads for step s+1 are issued before
 // the 16*WM*WN MFMAs of step s and written to LDS after them; >= 2 blocks per CU overlap one
 // block's staging with the other's matrix work.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace rpnet {
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const rpnet_conv_desc d, const int M,
+template <int WM, int WN, bool INSCALE>
+__global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) void conv_igemm_kernel(const rpnet_conv_desc d, const int M,
                                                           const int Cin, const int Cout,
                                                           const int tiles_n, const int ntiles) {
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
     constexpr int ASTR = BK + 4;
     constexpr int A_F4 = BM / 32;  // float4 per thread per K-step
     constexpr int B_F4 = BN / 32;
+    // single LDS stage (34 KB at 128x128): three blocks per CU.  A double-buffered variant (one
+    // barrier per K-step, 70 KB, two blocks per CU) measured 15 % SLOWER: occupancy hides the
+    // barrier better than removing it does.
     __shared__ __attribute__((aligned(16))) float smem[BM * ASTR + BK * BN];
-    float* As = smem;
-    float* Bs = smem + BM * ASTR;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -64,42 +68,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const rpnet_conv_desc d
     const int nsteps = d.taps * kchunks;
     const int Cin4 = Cin >> 2;
 
-    f32x4 ra[A_F4], rb[B_F4];
-    auto load_tile = [&](int ks) {
-        const int tap = ks / kchunks;
-        const int c0 = (ks - tap * kchunks) << 5;
+    // Load stream state: (tap, channel chunk) of the NEXT tile to fetch.  Everything that depends
+    // only on the tap (source pixel of each staged row, border validity, the x*mask factor) is
+    // computed once per tap, not once per K-step.
+    // The channel-chunk loop of every block starts at a different chunk (rot): co-resident blocks
+    // otherwise walk the same 128-byte column of their (C*4-byte pitched) pixel rows in lockstep and
+    // pile onto the same L2 channels.  A GEMM may sum K in any order; the order is fixed per tile.
+    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    int l_tap = 0, l_c0 = rot << 5, l_kc = 0;
+    int roff[A_F4];      // source pixel of each staged row (0 when the tap falls outside the image)
+    float rsc[A_F4];     // 0 outside the image, else 1 or the x*mask factor
+    // NB: every global load below is unconditional (clamped address + multiply by 0): a load
+    // inside a divergent branch makes hipcc wait for it before issuing the next one.
+    auto tap_setup = [&](int tap) {
         int ky = 0, kx = 0;
         if (d.taps == 9) { ky = tap / 3 - 1; kx = tap - (tap / 3) * 3 - 1; }
-        const float* src; int Cs, cc;
-        if (c0 < d.C0) { src = d.x0; Cs = d.C0; cc = c0; } else { src = d.x1; Cs = d.C1; cc = c0 - d.C0; }
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int iy = ry[j] + ky, ix = rx[j] + kx;
             const bool inb = rn[j] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (inb) {
-                const size_t pix = ((size_t)rn[j] * Hs + (iy >> ups)) * Ws + (ix >> ups);
-                v = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + acol);
-                if (d.in_scale_mode) {
-                    float s = d.in_scale[pix];
-                    if (d.in_scale_mode == 2) s = 1.f - s;
-                    v *= s;
-                }
+            roff[j] = inb ? (rn[j] * Hs + (iy >> ups)) * Ws + (ix >> ups) : 0;
+            float sc = 1.f;
+            if (INSCALE) {
+                const float sv = d.in_scale[roff[j]];
+                sc = d.in_scale_mode == 2 ? 1.f - sv : sv;
             }
-            ra[j] = v;
+            rsc[j] = inb ? sc : 0.f;
         }
-        const float* wbase = d.w + ((size_t)(tap * Cin4 + (c0 >> 2)) * Cout + n0) * 4;
+    };
+    tap_setup(0);
+
+    f32x4 ra[A_F4], rb[B_F4];
+    float rsc_st[A_F4];  // factor of the tile held in ra (tap_setup may already have moved on)
+    auto load_tile = [&]() {
+        const float* src; int Cs, cc;
+        if (l_c0 < d.C0) { src = d.x0; Cs = d.C0; cc = l_c0; } else { src = d.x1; Cs = d.C1; cc = l_c0 - d.C0; }
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)roff[j] * Cs + cc + acol);
+            rsc_st[j] = rsc[j];
+        }
+        const float* wbase = d.w + ((size_t)(l_tap * Cin4 + (l_c0 >> 2)) * Cout + n0) * 4;
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int idx = t + 256 * j;
             const int k4 = idx / BN, nn = idx - k4 * BN;
             rb[j] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)k4 * Cout + nn) * 4);
         }
+        l_c0 += 32;
+        if (l_c0 == Cin) l_c0 = 0;
+        if (++l_kc == kchunks) {
+            l_kc = 0;
+            if (++l_tap < d.taps) tap_setup(l_tap);
+        }
     };
     auto store_tile = [&]() {
+        float* As = smem;
+        float* Bs = As + BM * ASTR;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j)
-            *reinterpret_cast<f32x4*>(&As[((t >> 3) + 32 * j) * ASTR + acol]) = ra[j];
+            *reinterpret_cast<f32x4*>(&As[((t >> 3) + 32 * j) * ASTR + acol]) = ra[j] * rsc_st[j];
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) *reinterpret_cast<f32x4*>(&Bs[(t + 256 * j) * 4]) = rb[j];
     };
@@ -112,29 +140,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const rpnet_conv_desc d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int ks = 0; ks < nsteps; ++ks) {
-        const bool more = ks + 1 < nsteps;
-        if (more) load_tile(ks + 1);
+    auto mma_group = [&](const float* As, const float* Bs, int g) {
+        f32x4 af[WM], bf[WN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 af[WM], bf[WN];
+        for (int i = 0; i < WM; ++i)
+            af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM * 32 + i * 32 + li) * ASTR + g * 8 + h * 4]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + h) * BN + wn * WN * 32 + j * 32 + li) * 4]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM * 32 + i * 32 + li) * ASTR + g * 8 + h * 4]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((g * 2 + h) * BN + wn * WN * 32 + j * 32 + li) * 4]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+    };
+
+    // Pipeline: tile s+1 is fetched into registers while the MFMAs of tile s run from LDS, and is
+    // written to LDS between the two barriers that close the step.
+    load_tile();
+    store_tile();
+    __syncthreads();
+    const float* As = smem;
+    const float* Bs = As + BM * ASTR;
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const bool more = ks + 1 < nsteps;
+        if (more) load_tile();
+        mma_group(As, Bs, 0);
+        mma_group(As, Bs, 1);
+        mma_group(As, Bs, 2);
+        mma_group(As, Bs, 3);
         __syncthreads();
         if (more) store_tile();
         __syncthreads();
@@ -174,13 +210,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const rpnet_conv_desc d
     }
 }
 
-template <int WM, int WN>
-static int launch_igemm(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+template <int WM, int WN, bool INSCALE>
+static int launch_igemm_t(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tiles_m = cdiv(M, BM), tiles_n = Cout / BN;
     const int ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN>), dim3(ntiles), dim3(256), 0, s, *d, M, Cin, Cout, tiles_n, ntiles);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, INSCALE>), dim3(ntiles), dim3(256), 0, s, *d, M, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm");
+}
+
+template <int WM, int WN>
+static int launch_igemm(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+    if (d->in_scale_mode) return launch_igemm_t<WM, WN, true>(d, M, Cin, Cout, s);
+    return launch_igemm_t<WM, WN, false>(d, M, Cin, Cout, s);
 }
 
 }  // namespace rpnet
@@ -198,6 +240,14 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
+    if (const char* ov = getenv("RPNET_IGEMM_TILE")) {  // tuning aid only
+        if (!strcmp(ov, "22")) return launch_igemm<2, 2>(d, M, Cin, Cout, s);
+        if (!strcmp(ov, "12")) return launch_igemm<1, 2>(d, M, Cin, Cout, s);
+        if (!strcmp(ov, "21")) return launch_igemm<2, 1>(d, M, Cin, Cout, s);
+        if (!strcmp(ov, "11")) return launch_igemm<1, 1>(d, M, Cin, Cout, s);
+        if (!strcmp(ov, "24")) return launch_igemm<2, 4>(d, M, Cin, Cout, s);
+        if (!strcmp(ov, "42")) return launch_igemm<4, 2>(d, M, Cin, Cout, s);
+    }
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     // pick the largest tile that still gives >= ~2 blocks per CU (256 CUs)
     const long t128 = (long)cdiv(M, 128) * (Cout / 128);

@@ -54,32 +54,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d
         for (int j = 0; j < A_F4; ++j) {
             const int idx = t + 256 * j;
             const int prow = idx / A_RW, c4 = idx - prow * A_RW;
-            const int p = p0 + prow;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < M) {
-                const int n = p / HW, rem = p - n * HW;
-                const int oy = rem / W, ox = rem - oy * W;
-                const int iy = oy + ky, ix = ox + kx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    const size_t pix = ((size_t)n * Hs + (iy >> ups)) * Ws + (ix >> ups);
-                    v = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4);
-                    if (d.in_scale_mode) {
-                        float s = d.in_scale[pix];
-                        if (d.in_scale_mode == 2) s = 1.f - s;
-                        v *= s;
-                    }
-                }
+            const int p = min(p0 + prow, M - 1);   // clamped: loads stay unconditional (no branch, no per-load wait)
+            const int n = p / HW, rem = p - n * HW;
+            const int oy = rem / W, ox = rem - oy * W;
+            const int iy = oy + ky, ix = ox + kx;
+            const bool ok = p0 + prow < M && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const size_t pix = ok ? ((size_t)n * Hs + (iy >> ups)) * Ws + (ix >> ups) : 0;
+            float sc = ok ? 1.f : 0.f;
+            if (d.in_scale_mode) {
+                const float sv = d.in_scale[pix];
+                sc *= d.in_scale_mode == 2 ? 1.f - sv : sv;
             }
-            ra[j] = v;
+            ra[j] = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4) * sc;
         }
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int idx = t + 256 * j;
             const int prow = idx / B_RW, c4 = idx - prow * B_RW;
             const int p = p0 + prow;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + n0 + c4 * 4);
-            rb[j] = v;
+            rb[j] = *reinterpret_cast<const f32x4*>(dy + (size_t)min(p, M - 1) * Cout + n0 + c4 * 4) * (p < M ? 1.f : 0.f);
         }
     };
     auto store_tile = [&]() {
@@ -149,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d
 // horizontal border (ox + kx outside the row) cannot be folded into the strips because one
 // strip row serves three taps; it is a per-pixel 0/1 factor on the kx = +-1 fragments.
 // 69 FLOP per staged byte, two blocks per CU.
-template <bool POW2>
+template <bool POW2, bool INSCALE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_desc d, const float* __restrict__ dy,
                                                               float* __restrict__ partial, const int M, const int Cin,
                                                               const int Cout, const int tiles, const int tiles_n,
@@ -157,10 +150,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
                                                               const int lw, const int lh) {
     constexpr int BM = 64, BN = 64, BK = 32, SJ = BK + 2;
     constexpr int A_IT = (3 * SJ * (BM / 4) + 255) / 256;  // 7
-    __shared__ __attribute__((aligned(16))) float smem[3 * SJ * BM + BK * BN + 2 * BK];
-    float* As = smem;                    // [3][34][64]
-    float* Bs = smem + 3 * SJ * BM;      // [32][64]
-    float* vm = Bs + BK * BN;            // [2][32]: kx = -1 / kx = +1 validity of pixel k
+    constexpr int STAGE = 3 * SJ * BM + BK * BN + 2 * BK;   // As [3][34][64], Bs [32][64], vm [2][32]
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // double buffered: one barrier per K-step
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -199,33 +190,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
             const int e = t + 256 * i;
             const int c4 = e & 15, r = e >> 4;          // r in [0, 3*34)
             const int kyi = r / SJ, j = r - kyi * SJ;   // strip, position
-            const int q = p0 - 1 + j + (kyi - 1) * W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < 3 * SJ && q >= 0 && q < M) {
-                int n, yq, xq;
-                if (POW2) { xq = q & (W - 1); yq = (q >> lw) & (H - 1); n = q >> (lw + lh); }
-                else { n = q / HW; const int rem = q - n * HW; yq = rem / W; xq = rem - yq * W; }
-                const int yp = yq - (kyi - 1);              // row of the output pixel this source serves
-                if (yp >= 0 && yp < H) {
-                    const size_t pix = ((size_t)n * Hs + (yq >> ups)) * Ws + (xq >> ups);
-                    v = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4);
-                    if (d.in_scale_mode) {
-                        float s = d.in_scale[pix];
-                        if (d.in_scale_mode == 2) s = 1.f - s;
-                        v *= s;
-                    }
-                }
+            const int q0 = p0 - 1 + j + (kyi - 1) * W;
+            const int q = min(max(q0, 0), M - 1);        // clamped: the load below is unconditional
+            int n, yq, xq;
+            if (POW2) { xq = q & (W - 1); yq = (q >> lw) & (H - 1); n = q >> (lw + lh); }
+            else { n = q / HW; const int rem = q - n * HW; yq = rem / W; xq = rem - yq * W; }
+            const int yp = yq - (kyi - 1);                  // row of the output pixel this source serves
+            const bool ok = q0 >= 0 && q0 < M && yp >= 0 && yp < H;
+            const size_t pix = ((size_t)n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+            float sc = ok ? 1.f : 0.f;
+            if (INSCALE) {
+                const float sv = d.in_scale[pix];
+                sc *= d.in_scale_mode == 2 ? 1.f - sv : sv;
             }
-            ra[i] = v;
+            ra[i] = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4) * sc;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = t + 256 * i;
             const int prow = e >> 4, c4 = e & 15;
             const int p = p0 + prow;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + n0 + c4 * 4);
-            rb[i] = v;
+            rb[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)min(p, M - 1) * Cout + n0 + c4 * 4) * (p < M ? 1.f : 0.f);
         }
         if (t < 2 * BK) {
             const int k = t & (BK - 1), p = p0 + k;
@@ -233,7 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
             rv = (t < BK) ? (ox >= 1 ? 1.f : 0.f) : (ox <= W - 2 ? 1.f : 0.f);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + 3 * SJ * BM;
+        float* vm = Bs + BK * BN;            // kx = -1 / kx = +1 validity of pixel k
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int e = t + 256 * i;
@@ -250,33 +238,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
+    auto mma_range = [&](const float* As, int kp0, int kp1) {
+        const float* Bs = As + 3 * SJ * BM;
+        const float* vm = Bs + BK * BN;
+        const float* ap = As + wm * 32 + li;
+        const float* bp = Bs + wn * 32 + li;
+#pragma unroll
+        for (int kp = kp0; kp < kp1; ++kp) {
+            const int k = kp * 2 + h;
+            const float b = bp[k * BN];
+            const float mm = vm[k], mp = vm[BK + k];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float am = ap[(ky * SJ + k) * BM] * mm;
+                const float a0 = ap[(ky * SJ + k + 1) * BM];
+                const float a1 = ap[(ky * SJ + k + 2) * BM] * mp;
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+    };
     if (s_begin < s_end) {
         load_tile(s_begin);
-        store_tile();
+        store_tile(0);
         __syncthreads();
+        int cur = 0;
         for (int st = s_begin; st < s_end; ++st) {
             const bool more = st + 1 < s_end;
             if (more) load_tile(st + 1);
-            const float* ap = As + wm * 32 + li;
-            const float* bp = Bs + wn * 32 + li;
-#pragma unroll
-            for (int kp = 0; kp < BK / 2; ++kp) {
-                const int k = kp * 2 + h;
-                const float b = bp[k * BN];
-                const float mm = vm[k], mp = vm[BK + k];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float am = ap[(ky * SJ + k) * BM] * mm;
-                    const float a0 = ap[(ky * SJ + k + 1) * BM];
-                    const float a1 = ap[(ky * SJ + k + 2) * BM] * mp;
-                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[ky * 3 + 0], 0, 0, 0);
-                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[ky * 3 + 1], 0, 0, 0);
-                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[ky * 3 + 2], 0, 0, 0);
-                }
-            }
+            const float* As = smem + cur * STAGE;
+            mma_range(As, 0, 12);
+            if (more) store_tile(cur ^ 1);     // the other stage was last read one barrier ago
+            mma_range(As, 12, 16);
             __syncthreads();
-            if (more) store_tile();
-            __syncthreads();
+            cur ^= 1;
         }
     }
     if (z >= ksplit) return;
@@ -436,12 +432,15 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;
         const int lw = ilog2_exact(d->W), lh = ilog2_exact(d->H);
         float* part9 = (float*)workspace;
-        if (lw >= 0 && lh >= 0)
-            hipLaunchKernelGGL((conv_wgrad9_kernel<true>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout,
-                               tiles9, tiles_n9, ks9, sps9, lw, lh);
-        else
-            hipLaunchKernelGGL((conv_wgrad9_kernel<false>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout,
-                               tiles9, tiles_n9, ks9, sps9, 0, 0);
+#define RPNET_W9(P2, IS, LW, LH)                                                                                   \
+    hipLaunchKernelGGL((conv_wgrad9_kernel<P2, IS>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout, \
+                       tiles9, tiles_n9, ks9, sps9, LW, LH)
+        const bool p2 = lw >= 0 && lh >= 0, is = d->in_scale_mode != 0;
+        if (p2 && is) RPNET_W9(true, true, lw, lh);
+        else if (p2) RPNET_W9(true, false, lw, lh);
+        else if (is) RPNET_W9(false, true, 0, 0);
+        else RPNET_W9(false, false, 0, 0);
+#undef RPNET_W9
         int rc9 = check_launch("conv_wgrad9");
         if (rc9) return rc9;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
