@@ -71,15 +71,22 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
     // Load stream state: (tap, channel chunk) of the NEXT tile to fetch.  Everything that depends
     // only on the tap (source pixel of each staged row, border validity, the x*mask factor) is
     // computed once per tap, not once per K-step.
-    // The channel-chunk loop of every block starts at a different chunk (rot): co-resident blocks
-    // otherwise walk the same 128-byte column of their (C*4-byte pitched) pixel rows in lockstep and
-    // pile onto the same L2 channels.  A GEMM may sum K in any order; the order is fixed per tile.
+    // The channel-chunk loop of every block starts at a different chunk (rot) so that co-resident
+    // blocks do not walk the same 128-byte column of their pixel rows in lockstep.  A GEMM may sum
+    // K in any order; the order is fixed per tile, so results stay deterministic.
     const int rot = (int)(blockIdx.x % (unsigned)kchunks);
     int l_tap = 0, l_c0 = rot << 5, l_kc = 0;
-    int roff[A_F4];      // source pixel of each staged row (0 when the tap falls outside the image)
-    float rsc[A_F4];     // 0 outside the image, else 1 or the x*mask factor
-    // NB: every global load below is unconditional (clamped address + multiply by 0): a load
-    // inside a divergent branch makes hipcc wait for it before issuing the next one.
+    // Tile loads are buffer loads (SRD in SGPRs + 32-bit per-lane offset + scalar offset): no 64-bit
+    // address arithmetic per K-step, and a row that falls outside the image simply gets an offset
+    // beyond num_records — the hardware bounds check returns zeros, no branch, no select.
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.x0), (short)0, (int)((size_t)d.N * Hs * Ws * d.C0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.x1 ? d.x1 : d.x0), (short)0, (int)((size_t)d.N * Hs * Ws * (d.x1 ? d.C1 : d.C0) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.w), (short)0, (int)((size_t)d.taps * Cin * Cout * 4), 0x00020000);
+    int roff[A_F4];      // source pixel of each staged row, -1 when the tap falls outside the image
+    float rsc[A_F4];     // x*mask factor of that pixel (INSCALE only)
     auto tap_setup = [&](int tap) {
         int ky = 0, kx = 0;
         if (d.taps == 9) { ky = tap / 3 - 1; kx = tap - (tap / 3) * 3 - 1; }
@@ -87,34 +94,42 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
         for (int j = 0; j < A_F4; ++j) {
             const int iy = ry[j] + ky, ix = rx[j] + kx;
             const bool inb = rn[j] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            roff[j] = inb ? (rn[j] * Hs + (iy >> ups)) * Ws + (ix >> ups) : 0;
-            float sc = 1.f;
+            const int pix = (rn[j] * Hs + (iy >> ups)) * Ws + (ix >> ups);
+            roff[j] = inb ? pix : -1;
             if (INSCALE) {
-                const float sv = d.in_scale[roff[j]];
-                sc = d.in_scale_mode == 2 ? 1.f - sv : sv;
+                const float sv = d.in_scale[inb ? pix : 0];
+                rsc[j] = d.in_scale_mode == 2 ? 1.f - sv : sv;
             }
-            rsc[j] = inb ? sc : 0.f;
         }
     };
     tap_setup(0);
+    int wvoff[B_F4];     // per-lane byte offset inside the 8 x BN x 4 weight slab
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+        const int idx = t + 256 * j;
+        const int k4 = idx / BN, nn = idx - k4 * BN;
+        wvoff[j] = (k4 * Cout + nn) * 16;
+    }
 
     f32x4 ra[A_F4], rb[B_F4];
     float rsc_st[A_F4];  // factor of the tile held in ra (tap_setup may already have moved on)
     auto load_tile = [&]() {
-        const float* src; int Cs, cc;
-        if (l_c0 < d.C0) { src = d.x0; Cs = d.C0; cc = l_c0; } else { src = d.x1; Cs = d.C1; cc = l_c0 - d.C0; }
+        const bool first = l_c0 < d.C0;
+        const int Cs = first ? d.C0 : d.C1;
+        const int cc = first ? l_c0 : l_c0 - d.C0;
+        const int soff = cc * 4;
+        const int cs4 = Cs * 4, ac4 = acol * 4;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
-            ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)roff[j] * Cs + cc + acol);
-            rsc_st[j] = rsc[j];
+            const int voff = roff[j] * cs4 + ac4;   // roff == -1 -> beyond num_records -> zeros
+            ra[j] = first ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, soff, 0))
+                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, soff, 0));
+            if (INSCALE) rsc_st[j] = rsc[j];
         }
-        const float* wbase = d.w + ((size_t)(l_tap * Cin4 + (l_c0 >> 2)) * Cout + n0) * 4;
+        const int wsoff = ((l_tap * Cin4 + (l_c0 >> 2)) * Cout + n0) * 16;
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) {
-            const int idx = t + 256 * j;
-            const int k4 = idx / BN, nn = idx - k4 * BN;
-            rb[j] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)k4 * Cout + nn) * 4);
-        }
+        for (int j = 0; j < B_F4; ++j)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[j], wsoff, 0));
         l_c0 += 32;
         if (l_c0 == Cin) l_c0 = 0;
         if (++l_kc == kchunks) {
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
         float* Bs = As + BM * ASTR;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j)
-            *reinterpret_cast<f32x4*>(&As[((t >> 3) + 32 * j) * ASTR + acol]) = ra[j] * rsc_st[j];
+            *reinterpret_cast<f32x4*>(&As[((t >> 3) + 32 * j) * ASTR + acol]) = INSCALE ? ra[j] * rsc_st[j] : ra[j];
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) *reinterpret_cast<f32x4*>(&Bs[(t + 256 * j) * 4]) = rb[j];
     };
@@ -238,6 +253,9 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
                   "conv_fwd: Cout (%d+%d) must be a multiple of 64 per destination", d->Co0, d->Co1);
     RPNET_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), RPNET_ERR_SHAPE, "conv_fwd: odd size with upsample");
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
+    RPNET_REQUIRE((size_t)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) &&
+                      (size_t)d->taps * Cin * Cout * 4 < (1UL << 31),
+                  RPNET_ERR_SHAPE, "conv_fwd: a source tensor exceeds the 2 GiB buffer-descriptor range");
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
     if (const char* ov = getenv("RPNET_IGEMM_TILE")) {  // tuning aid only

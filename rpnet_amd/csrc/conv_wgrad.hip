@@ -181,6 +181,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
     const int s_begin = z * steps_per_split;
     const int s_end = min(s_begin + steps_per_split, total_steps);
 
+    // buffer loads: SRD + 32-bit lane offset + scalar offset; anything outside the tensor (pixels
+    // past M, rows outside the image) gets an offset beyond num_records and reads as zero.
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src), (short)0, (int)((size_t)d.N * Hs * Ws * Cs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dy), (short)0, (int)((size_t)M * Cout * 4), 0x00020000);
+    const int cs4 = Cs * 4;
     f32x4 ra[A_IT], rb[2];
     float rv = 0.f;
     auto load_tile = [&](int st) {
@@ -190,27 +197,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
             const int e = t + 256 * i;
             const int c4 = e & 15, r = e >> 4;          // r in [0, 3*34)
             const int kyi = r / SJ, j = r - kyi * SJ;   // strip, position
-            const int q0 = p0 - 1 + j + (kyi - 1) * W;
-            const int q = min(max(q0, 0), M - 1);        // clamped: the load below is unconditional
+            const int q = p0 - 1 + j + (kyi - 1) * W;
             int n, yq, xq;
             if (POW2) { xq = q & (W - 1); yq = (q >> lw) & (H - 1); n = q >> (lw + lh); }
             else { n = q / HW; const int rem = q - n * HW; yq = rem / W; xq = rem - yq * W; }
             const int yp = yq - (kyi - 1);                  // row of the output pixel this source serves
-            const bool ok = q0 >= 0 && q0 < M && yp >= 0 && yp < H;
-            const size_t pix = ((size_t)n * Hs + (yq >> ups)) * Ws + (xq >> ups);
-            float sc = ok ? 1.f : 0.f;
+            const bool ok = q >= 0 && q < M && yp >= 0 && yp < H;
+            const int pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+            const int voff = ok ? pix * cs4 + c4 * 16 : (int)0x80000000;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff, cc * 4, 0));
             if (INSCALE) {
-                const float sv = d.in_scale[pix];
-                sc *= d.in_scale_mode == 2 ? 1.f - sv : sv;
+                const float sv = d.in_scale[ok ? pix : 0];
+                ra[i] *= d.in_scale_mode == 2 ? 1.f - sv : sv;
             }
-            ra[i] = *reinterpret_cast<const f32x4*>(src + pix * Cs + cc + c4 * 4) * sc;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = t + 256 * i;
             const int prow = e >> 4, c4 = e & 15;
-            const int p = p0 + prow;
-            rb[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)min(p, M - 1) * Cout + n0 + c4 * 4) * (p < M ? 1.f : 0.f);
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (p0 + prow) * Cout * 4 + c4 * 16, n0 * 4, 0));
         }
         if (t < 2 * BK) {
             const int k = t & (BK - 1), p = p0 + k;
