@@ -266,11 +266,25 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
         if (!strcmp(ov, "24")) return launch_igemm<2, 4>(d, M, Cin, Cout, s);
         if (!strcmp(ov, "42")) return launch_igemm<4, 2>(d, M, Cin, Cout, s);
     }
+    // Tile choice = fewest idle block slots.  Resident blocks per CU follow from the VGPR budget of each
+    // variant (128x128: 3, 128x64 / 64x128: 4, 64x64: 6); a grid that is not close to a whole number
+    // of machine waves leaves CUs idle for the whole tail (measured 100 -> 131 TF on the wgrad grid),
+    // so the variant with the best fill wins, ties go to the larger tile.
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
-    // pick the largest tile that still gives >= ~2 blocks per CU (256 CUs)
-    const long t128 = (long)cdiv(M, 128) * (Cout / 128);
-    if (n128 && t128 >= 512) return launch_igemm<2, 2>(d, M, Cin, Cout, s);
-    if (n128 && (long)cdiv(M, 64) * (Cout / 128) >= 512) return launch_igemm<1, 2>(d, M, Cin, Cout, s);
-    if ((long)cdiv(M, 128) * (Cout / 64) >= 512) return launch_igemm<2, 1>(d, M, Cin, Cout, s);
-    return launch_igemm<1, 1>(d, M, Cin, Cout, s);
+    struct Cand { int wm, wn, slots; } cands[4] = {{2, 2, 768}, {2, 1, 1024}, {1, 2, 1024}, {1, 1, 1536}};
+    int best = -1;
+    double best_fill = -1.0;
+    for (int c = 0; c < 4; ++c) {
+        if (cands[c].wn == 2 && !n128) continue;
+        const long tiles = (long)cdiv(M, 64 * cands[c].wm) * (Cout / (64 * cands[c].wn));
+        const long waves = (tiles + cands[c].slots - 1) / cands[c].slots;
+        const double fill = (double)tiles / (double)(waves * cands[c].slots);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = c; }
+    }
+    switch (best) {
+        case 0: return launch_igemm<2, 2>(d, M, Cin, Cout, s);
+        case 1: return launch_igemm<2, 1>(d, M, Cin, Cout, s);
+        case 2: return launch_igemm<1, 2>(d, M, Cin, Cout, s);
+        default: return launch_igemm<1, 1>(d, M, Cin, Cout, s);
+    }
 }

@@ -11,6 +11,7 @@
 // into the nn.Conv2d state_dict layout [Cout][Cin][kh][kw] through LDS so that both the
 // reads (along cout) and the writes (along cin,tap) are coalesced.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -140,8 +141,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d
 // source image row is outside the image are zero) and the dy rows once, and runs 9 x 16 MFMAs
 // per wave against nine accumulators (144 registers): A(tap ky,kx)[k] = S_ky[k + kx + 1].  The
 // horizontal border (ox + kx outside the row) cannot be folded into the strips because one
-// strip row serves three taps; it is a per-pixel 0/1 factor on the kx = +-1 fragments.
-// 69 FLOP per staged byte, two blocks per CU.
+// strip row serves three taps; it is folded into the OTHER operand instead: dy is staged three
+// times (as is, zeroed where ox = 0, zeroed where ox = W-1) and tap kx reads its own copy, so the
+// MFMA loop is LDS reads + matrix instructions only.  69 FLOP per staged byte, two blocks per CU.
 template <bool POW2, bool INSCALE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_desc d, const float* __restrict__ dy,
                                                               float* __restrict__ partial, const int M, const int Cin,
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
                                                               const int lw, const int lh) {
     constexpr int BM = 64, BN = 64, BK = 32, SJ = BK + 2;
     constexpr int A_IT = (3 * SJ * (BM / 4) + 255) / 256;  // 7
-    constexpr int STAGE = 3 * SJ * BM + BK * BN + 2 * BK;   // As [3][34][64], Bs [32][64], vm [2][32]
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // double buffered: one barrier per K-step
+    constexpr int A_SZ = 3 * SJ * BM, B_SZ = BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[A_SZ + 3 * B_SZ];   // As [3][34][64], Bs [3 variants][32][64]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -188,23 +190,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(dy), (short)0, (int)((size_t)M * Cout * 4), 0x00020000);
     const int cs4 = Cs * 4;
+    // per-thread constants of the seven strip elements it stages: q = p0 + qoff[i]
+    int qoff[A_IT], kyv[A_IT], c16[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int e = t + 256 * i;
+        const int r = e >> 4;
+        const int kyi = r / SJ, j = r - kyi * SJ;
+        kyv[i] = kyi - 1;
+        qoff[i] = j - 1 + (kyi - 1) * W;
+        c16[i] = (e & 15) * 16;
+    }
     f32x4 ra[A_IT], rb[2];
-    float rv = 0.f;
     auto load_tile = [&](int st) {
         const int p0 = st * BK;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int e = t + 256 * i;
-            const int c4 = e & 15, r = e >> 4;          // r in [0, 3*34)
-            const int kyi = r / SJ, j = r - kyi * SJ;   // strip, position
-            const int q = p0 - 1 + j + (kyi - 1) * W;
-            int n, yq, xq;
-            if (POW2) { xq = q & (W - 1); yq = (q >> lw) & (H - 1); n = q >> (lw + lh); }
-            else { n = q / HW; const int rem = q - n * HW; yq = rem / W; xq = rem - yq * W; }
-            const int yp = yq - (kyi - 1);                  // row of the output pixel this source serves
-            const bool ok = q >= 0 && q < M && yp >= 0 && yp < H;
-            const int pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
-            const int voff = ok ? pix * cs4 + c4 * 16 : (int)0x80000000;
+            const int q = p0 + qoff[i];
+            int pix, yq;
+            if (POW2) {
+                yq = (q >> lw) & (H - 1);
+                pix = ups ? (((q >> (lw + lh)) * Hs + (yq >> 1)) * Ws + ((q & (W - 1)) >> 1)) : q;
+            } else {
+                const int n = q / HW, rem = q - n * HW;
+                yq = rem / W;
+                const int xq = rem - yq * W;
+                pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+            }
+            const int yp = yq - kyv[i];                     // row of the output pixel this source serves
+            const bool ok = (unsigned)q < (unsigned)M && (unsigned)yp < (unsigned)H;
+            const int voff = ok ? pix * cs4 + c16[i] : (int)0x80000000;
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff, cc * 4, 0));
             if (INSCALE) {
                 const float sv = d.in_scale[ok ? pix : 0];
@@ -214,27 +229,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = t + 256 * i;
-            const int prow = e >> 4, c4 = e & 15;
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (p0 + prow) * Cout * 4 + c4 * 16, n0 * 4, 0));
-        }
-        if (t < 2 * BK) {
-            const int k = t & (BK - 1), p = p0 + k;
-            const int ox = POW2 ? (p & (W - 1)) : (p % W);
-            rv = (t < BK) ? (ox >= 1 ? 1.f : 0.f) : (ox <= W - 2 ? 1.f : 0.f);
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (p0 + (e >> 4)) * Cout * 4 + (e & 15) * 16, n0 * 4, 0));
         }
     };
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * STAGE;
-        float* Bs = As + 3 * SJ * BM;
-        float* vm = Bs + BK * BN;            // kx = -1 / kx = +1 validity of pixel k
+    auto store_tile = [&](int st) {
+        float* As = smem;
+        float* Bs = smem + A_SZ;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int e = t + 256 * i;
             if (e < 3 * SJ * (BM / 4)) *reinterpret_cast<f32x4*>(&As[e * 4]) = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[(t + 256 * i) * 4]) = rb[i];
-        if (t < 2 * BK) vm[t] = rv;
+        for (int i = 0; i < 2; ++i) {
+            const int e = t + 256 * i;
+            const int p = st * BK + (e >> 4);
+            const int ox = POW2 ? (p & (W - 1)) : (p % W);
+            *reinterpret_cast<f32x4*>(&Bs[e * 4]) = rb[i] * (ox >= 1 ? 1.f : 0.f);               // kx = -1
+            *reinterpret_cast<f32x4*>(&Bs[B_SZ + e * 4]) = rb[i];                                 // kx =  0
+            *reinterpret_cast<f32x4*>(&Bs[2 * B_SZ + e * 4]) = rb[i] * (ox <= W - 2 ? 1.f : 0.f);  // kx = +1
+        }
     };
 
     f32x16 acc[9];
@@ -243,41 +257,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(const rpnet_conv_de
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    auto mma_range = [&](const float* As, int kp0, int kp1) {
-        const float* Bs = As + 3 * SJ * BM;
-        const float* vm = Bs + BK * BN;
-        const float* ap = As + wm * 32 + li;
-        const float* bp = Bs + wn * 32 + li;
-#pragma unroll
-        for (int kp = kp0; kp < kp1; ++kp) {
-            const int k = kp * 2 + h;
-            const float b = bp[k * BN];
-            const float mm = vm[k], mp = vm[BK + k];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float am = ap[(ky * SJ + k) * BM] * mm;
-                const float a0 = ap[(ky * SJ + k + 1) * BM];
-                const float a1 = ap[(ky * SJ + k + 2) * BM] * mp;
-                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[ky * 3 + 2], 0, 0, 0);
-            }
-        }
-    };
     if (s_begin < s_end) {
         load_tile(s_begin);
-        store_tile(0);
+        store_tile(s_begin);
         __syncthreads();
-        int cur = 0;
+        const float* ap = smem + wm * 32 + li + h * BM;          // row k = 2*kp + h
+        const float* bp = smem + A_SZ + wn * 32 + li + h * BN;
         for (int st = s_begin; st < s_end; ++st) {
             const bool more = st + 1 < s_end;
             if (more) load_tile(st + 1);
-            const float* As = smem + cur * STAGE;
-            mma_range(As, 0, 12);
-            if (more) store_tile(cur ^ 1);     // the other stage was last read one barrier ago
-            mma_range(As, 12, 16);
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                const float bm = bp[kp * 2 * BN], b0 = bp[B_SZ + kp * 2 * BN], b1 = bp[2 * B_SZ + kp * 2 * BN];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float am = ap[(ky * SJ + kp * 2) * BM];
+                    const float a0 = ap[(ky * SJ + kp * 2 + 1) * BM];
+                    const float a1 = ap[(ky * SJ + kp * 2 + 2) * BM];
+                    acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, acc[ky * 3 + 0], 0, 0, 0);
+                    acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[ky * 3 + 1], 0, 0, 0);
+                    acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[ky * 3 + 2], 0, 0, 0);
+                }
+            }
             __syncthreads();
-            cur ^= 1;
+            if (more) store_tile(st + 1);
+            __syncthreads();
         }
     }
     if (z >= ksplit) return;
@@ -299,13 +303,14 @@ static int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// split-K plan of the nine-tap kernel: ~1024 blocks, >= 8 K-steps each, <= 64 MiB of partials
+// split-K plan of the nine-tap kernel: tiles * ksplit = 512 blocks (two resident blocks on each of
+// the 256 CUs, one full wave of the machine) whenever the K extent allows >= 8 steps per block;
+// the partial buffer is then 512 * 9 * 64 * 64 * 4 B = 75 MB whatever the layer.
 static void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
     const int tiles = (Cin / 64) * (Cout / 64);
     const int total_steps = (M + 31) / 32;
-    long ks = (1024 + tiles - 1) / tiles;
+    long ks = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
     ks = std::min<long>(ks, std::max(1, total_steps / 8));
-    ks = std::min<long>(ks, std::max<long>(1, (64L << 20) / ((long)9 * Cin * Cout * 4)));
     if (ks >= 8) ks = (ks / 8) * 8;
     *steps_per_split = (int)((total_steps + ks - 1) / ks);
     int k2 = (total_steps + *steps_per_split - 1) / *steps_per_split;
