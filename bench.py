@@ -81,14 +81,16 @@ def profile_step(net, bucket, inp, scaler):
 
     def timed(name, *args):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        flops = 0.0
+        flops = nbytes = 0.0
         if name in ("rpnet_conv_fwd", "rpnet_conv_wgrad"):
             d = args[0]._obj
-            flops = 2.0 * d.N * d.H * d.W * (d.C0 + d.C1) * (d.Co0 + d.Co1) * d.taps
+            m, ci, co = d.N * d.H * d.W, d.C0 + d.C1, d.Co0 + d.Co1
+            flops = 2.0 * m * ci * co * d.taps
+            nbytes = 4.0 * ((m >> (2 * d.upsample)) * ci + m * co + d.taps * ci * co)  # read x, w; write y
         a.record()
         orig(name, *args)
         b.record()
-        records.append((name, flops, a, b))
+        records.append((name, flops, nbytes, a, b))
 
     hip.call = timed
     import rpnet_amd.functional as RF
@@ -100,12 +102,30 @@ def profile_step(net, bucket, inp, scaler):
         hip.call = orig
         RF.call = orig
     agg = {}
-    for name, flops, a, b in records:
-        e = agg.setdefault(name, [0, 0.0, 0.0])
+    for name, flops, nbytes, a, b in records:
+        e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         e[0] += 1
         e[1] += a.elapsed_time(b) * 1e-3
         e[2] += flops
+        e[3] += nbytes
     return agg
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    command, KiB units, read side doubled per the gfx950 note of MI355X_MICROARCH.md).  A PMC
+    pass cannot run inside the timed process, so this is the offline figure or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    n = b = 0.0
+    for k, v in d.items():
+        if "conv_igemm_kernel" in k:
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return round(b / n) if n else None
 
 
 def cpu_baseline(cfg, size, T, seconds_budget=25.0):
@@ -198,8 +218,8 @@ def main():
     result = None
     if rank == 0:
         agg = profile_step(net, bucket, inp, scaler)
-        conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0])
-        wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0])
+        conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
+        wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
         achieved = conv[2] / conv[1] / 1e12
         kern_total = sum(v[1] for v in agg.values())
         result = {
@@ -214,7 +234,9 @@ def main():
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (rpnet_conv_fwd: conv forward + dgrad launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline pass)",
+                         "algorithmic_bytes_per_launch": round(conv[3] / max(conv[0], 1)),
                          "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
                          "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
                          "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
