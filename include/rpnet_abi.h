@@ -85,10 +85,16 @@ typedef struct rpnet_conv_desc {
     int N, H, W;                       /* output (= conv input after up-sampling) size */
     int taps;                          /* 9 or 1 */
     int upsample;                      /* sources are [N][H/2][W/2][C] */
-    int groups;                        /* for ep_scale/ep_shift rows */
+    int groups;                        /* for ep_scale/ep_shift rows and the statistics below */
+    double* stats_partial;             /* optional: per (M-tile half, channel) sum / sum-of-squares of the
+                                          output, [groups * rpnet_conv_stats_blocks()][Cout][2] — the
+                                          train-mode BatchNorm batch statistics fused into the epilogue */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
+/* partial-statistic rows per group rpnet_conv_fwd writes for this descriptor (0: this shape cannot
+ * fuse them — a group does not split into whole tiles — use rpnet_bn_stats on the output instead) */
+int rpnet_conv_stats_blocks(const rpnet_conv_desc* d);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dW[cout][cin][kh][kw] = sum_pixels A[pixel+tap][cin] * dy[pixel][cout], A gathered
@@ -124,6 +130,11 @@ int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float
                    float* running_mean, float* running_var, float momentum, float eps,
                    float* scale, float* shift, float* mean, float* invstd,
                    void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+/* finalize half of rpnet_bn_stats on partial sums produced by rpnet_conv_fwd (stats_partial) */
+int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, int C, int groups,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                rpnet_stream_t stream);
 int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, int C,
                          rpnet_stream_t stream);

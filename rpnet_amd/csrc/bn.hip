@@ -240,6 +240,20 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     return check_launch("bn_stats");
 }
 
+extern "C" int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, int C, int groups,
+                                           const float* gamma, const float* beta, float* running_mean,
+                                           float* running_var, float momentum, float eps, float* scale, float* shift,
+                                           float* mean, float* invstd, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && nblk > 0, RPNET_ERR_ARG,
+                  "bn_stats_from_partial: null pointer");
+    RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "bn_stats_from_partial: N=%d groups=%d", N, groups);
+    const long R = (long)(N / groups) * HW;
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
+                       beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    return check_launch("bn_stats_from_partial");
+}
+
 extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, float* scale, float* shift, int C,
                                     rpnet_stream_t stream) {

@@ -193,6 +193,33 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
+    if (d.stats_partial) {
+        // train-mode BatchNorm statistics of y = acc + bias, fused: this wave's 32*WM rows of each of
+        // its columns -> one (sum, sum of squares) pair per column; the two lane halves hold the same
+        // columns.  Row blocks never straddle a statistic group (host-checked).
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * WN * 32 + j * 32 + li;
+            const float bv = d.bias ? d.bias[col] : 0.f;
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = row < M ? acc[i][j][r] + bv : 0.f;
+                    sm += v;
+                    sq += v * v;
+                }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (h == 0) {
+                double* o = d.stats_partial + ((size_t)(tm * 2 + wm) * Cout + col) * 2;
+                o[0] = (double)sm;
+                o[1] = (double)sq;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn * WN * 32 + j * 32 + li;
@@ -242,6 +269,36 @@ static int launch_igemm(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipS
 
 }  // namespace rpnet
 
+
+// Tile choice = fewest idle block slots.  Resident blocks per CU follow from the VGPR budget of each
+// variant (128x128: 3, 128x64 / 64x128: 4, 64x64: 6); a grid that is not close to a whole number
+// of machine waves leaves CUs idle for the whole tail (measured 100 -> 131 TF on the wgrad grid),
+// so the variant with the best fill wins, ties go to the larger tile.
+static int choose_tile(const rpnet_conv_desc* d, int M, int Cout) {
+    const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
+    struct Cand { int wm, wn, slots; } cands[4] = {{2, 2, 768}, {2, 1, 1024}, {1, 2, 1024}, {1, 1, 1536}};
+    int best = -1;
+    double best_fill = -1.0;
+    for (int c = 0; c < 4; ++c) {
+        if (cands[c].wn == 2 && !n128) continue;
+        const long tiles = (long)rpnet::cdiv(M, 64 * cands[c].wm) * (Cout / (64 * cands[c].wn));
+        const long waves = (tiles + cands[c].slots - 1) / cands[c].slots;
+        const double fill = (double)tiles / (double)(waves * cands[c].slots);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = c; }
+    }
+    return best;
+}
+
+extern "C" int rpnet_conv_stats_blocks(const rpnet_conv_desc* d) {
+    if (!d || d->groups < 1 || d->N % d->groups) return 0;
+    const int M = d->N * d->H * d->W, Cout = d->Co0 + d->Co1;
+    const int best = choose_tile(d, M, Cout);
+    const int bm = (best == 0 || best == 1) ? 128 : 64;
+    const long per_group = (long)(d->N / d->groups) * d->H * d->W;
+    if (per_group % bm) return 0;
+    return (int)(per_group / bm) * 2;
+}
+
 extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(d && d->x0 && d->w && d->y0, RPNET_ERR_ARG, "conv_fwd: null pointer");
@@ -251,6 +308,8 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
                   "conv_fwd: Cin (%d+%d) must be a multiple of 32 per source", d->C0, d->C1);
     RPNET_REQUIRE(Cout % 64 == 0 && (d->Co1 == 0 || (d->y1 && d->Co0 % 64 == 0)), RPNET_ERR_SHAPE,
                   "conv_fwd: Cout (%d+%d) must be a multiple of 64 per destination", d->Co0, d->Co1);
+    RPNET_REQUIRE(!d->stats_partial || rpnet_conv_stats_blocks(d) > 0, RPNET_ERR_SHAPE,
+                  "conv_fwd: statistic groups do not split into whole tiles; use rpnet_bn_stats");
     RPNET_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), RPNET_ERR_SHAPE, "conv_fwd: odd size with upsample");
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
     RPNET_REQUIRE((size_t)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) &&
@@ -266,21 +325,7 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
         if (!strcmp(ov, "24")) return launch_igemm<2, 4>(d, M, Cin, Cout, s);
         if (!strcmp(ov, "42")) return launch_igemm<4, 2>(d, M, Cin, Cout, s);
     }
-    // Tile choice = fewest idle block slots.  Resident blocks per CU follow from the VGPR budget of each
-    // variant (128x128: 3, 128x64 / 64x128: 4, 64x64: 6); a grid that is not close to a whole number
-    // of machine waves leaves CUs idle for the whole tail (measured 100 -> 131 TF on the wgrad grid),
-    // so the variant with the best fill wins, ties go to the larger tile.
-    const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
-    struct Cand { int wm, wn, slots; } cands[4] = {{2, 2, 768}, {2, 1, 1024}, {1, 2, 1024}, {1, 1, 1536}};
-    int best = -1;
-    double best_fill = -1.0;
-    for (int c = 0; c < 4; ++c) {
-        if (cands[c].wn == 2 && !n128) continue;
-        const long tiles = (long)cdiv(M, 64 * cands[c].wm) * (Cout / (64 * cands[c].wn));
-        const long waves = (tiles + cands[c].slots - 1) / cands[c].slots;
-        const double fill = (double)tiles / (double)(waves * cands[c].slots);
-        if (fill > best_fill + 0.02) { best_fill = fill; best = c; }
-    }
+    const int best = choose_tile(d, M, Cout);
     switch (best) {
         case 0: return launch_igemm<2, 2>(d, M, Cin, Cout, s);
         case 1: return launch_igemm<2, 1>(d, M, Cin, Cout, s);

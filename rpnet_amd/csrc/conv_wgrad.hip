@@ -366,12 +366,11 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int ncin = min(32, cin_w - ci0);
     const int nel = ncin * taps;
-    for (int col = 0; col < 32; ++col) {
-        const float* src = w + ((size_t)(co0 + col) * cin_w + ci0) * taps;
-        for (int e = t; e < nel; e += 256) {
-            const int c = e / taps, tap = e - c * taps;
-            tile[tap][c][col] = src[e];
-        }
+    // 32 cout rows of `nel` contiguous floats each: one flat, fully independent load loop
+    for (int e = t; e < 32 * nel; e += 256) {
+        const int col = e / nel, r = e - col * nel;
+        const int c = r / taps, tap = r - c * taps;
+        tile[tap][c][col] = w[((size_t)(co0 + col) * cin_w + ci0) * taps + r];
     }
     __syncthreads();
     // wp: for (tap, cin_l): 32 consecutive cout, element [row/4][cout][row%4]

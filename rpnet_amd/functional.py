@@ -112,16 +112,27 @@ class ConvBnRelu(Function):
             ctx.eval_mode = True
             return z
         y = _empty((N, H, W, cout), x0)
+        stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
+        fused = 0
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
-            d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample)
+            d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample, groups)
+            fused = query("rpnet_conv_stats_blocks", C.byref(d))
+            if fused:  # batch statistics come out of the conv epilogue: y is not re-read
+                part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
+                d.stats_partial = ptr(part)
             call("rpnet_conv_fwd", C.byref(d))
-        stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
-        wsb = query("rpnet_bn_workspace_bytes", cout, groups)
-        ws = _ws(wsb, x0)
-        call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-             BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), ptr(ws), wsb)
+        if fused:
+            call("rpnet_bn_stats_from_partial", ptr(part), fused, N, H * W, cout, groups, ptr(gamma), ptr(beta),
+                 ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
+                 ptr(stats[3]))
+        else:
+            wsb = query("rpnet_bn_workspace_bytes", cout, groups)
+            ws = _ws(wsb, x0)
+            call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
+                 ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+                 ptr(ws), wsb)
         if nbt is not None:
             nbt += groups
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), N, H * W, cout, groups)
