@@ -204,6 +204,15 @@ int rpnet_bilinear_up_bwd(const float* dout, float* din, int planes, int h, int 
 int rpnet_softmax_thresh_pool(const float* logits, float* mask, int B, int K, int H, int W, int scale, int soft,
                               rpnet_stream_t stream);
 
+/* soft_mask: True (yaml) — the fed-back mask stays differentiable (net/rp_net.py:309 skips the threshold):
+ *   rpnet_rowdot_scale     autograd of x*s / x*(1-s) wrt BOTH factors given g = d/d(x*f(s)):
+ *                          dx = g*f(s), dscale[p] = +-<g[p,:], x[p,:]> (mode 1: s, mode 2: 1-s)
+ *   rpnet_softmax_pool_bwd autograd of avg_pool2d(softmax(logits,1)[:,1], scale) wrt logits */
+int rpnet_rowdot_scale(const float* g, const float* x, const float* scale, float* dx, float* dscale, size_t P, int C,
+                       int mode, int accumulate_dscale, rpnet_stream_t stream);
+int rpnet_softmax_pool_bwd(const float* logits, const float* dmask, float* dlogits, int B, int K, int H, int W,
+                           int scale, rpnet_stream_t stream);
+
 /* -------------------------------------------------------------------------- losses
  * dice_ce (net/rp_net.py:87-127) for K-class logits [B][K][H][W], int64 labels [B][H][W]:
  *   loss = [with_dice] (1 - mean_k 2*I_k/(C_k + 1e-7)) + cross-entropy,

@@ -281,7 +281,72 @@ __global__ void softmax_thresh_pool_kernel(const float* __restrict__ logits, flo
     mask[i] = acc / (float)(s * s);
 }
 
+// soft-mask gradient pieces (net/rp_net.py:283,308-311 with soft_mask: True)
+// dx = g * f(s), ds = sign * <g, x> per pixel, f(s) = s (mode 1) or 1 - s (mode 2)
+__global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ sc, float* __restrict__ dx,
+                                                            float* __restrict__ ds, size_t P, int C, int mode, int accumulate_ds) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int C4 = C / 4;
+    for (size_t p = (size_t)blockIdx.x * 4 + wv; p < P; p += (size_t)gridDim.x * 4) {
+        const float sv = sc[p];
+        const float f = mode == 2 ? 1.f - sv : sv;
+        float dot = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const f32x4 gv = reinterpret_cast<const f32x4*>(g + p * C)[c4];
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x + p * C)[c4];
+            dot += gv[0] * xv[0] + gv[1] * xv[1] + gv[2] * xv[2] + gv[3] * xv[3];
+            reinterpret_cast<f32x4*>(dx + p * C)[c4] = gv * f;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            const float v = mode == 2 ? -dot : dot;
+            ds[p] = accumulate_ds ? ds[p] + v : v;
+        }
+    }
+}
+
+// d logits of mask = avg_pool(softmax(logits)[:,1], s):  dl_k = p1 * ([k == 1] - p_k) * dmask / s^2
+__global__ void softmax_pool_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dmask,
+                                        float* __restrict__ dlogits, int B, int K, int H, int W, int s) {
+    const size_t plane = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * plane) return;
+    const int X = (int)(i % W), Y = (int)((i / W) % H), b = (int)(i / plane);
+    const float* base = logits + (size_t)b * K * plane + (size_t)Y * W + X;
+    float mx = base[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, base[k * plane]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += expf(base[k * plane] - mx);
+    const float p1 = expf(base[plane] - mx) / den;
+    const float gp = dmask[((size_t)b * (H / s) + Y / s) * (W / s) + X / s] / (float)(s * s);
+    float* o = dlogits + (size_t)b * K * plane + (size_t)Y * W + X;
+    for (int k = 0; k < K; ++k) {
+        const float pk = expf(base[k * plane] - mx) / den;
+        o[k * plane] = p1 * ((k == 1 ? 1.f : 0.f) - pk) * gp;
+    }
+}
+
 }  // namespace rpnet
+
+extern "C" int rpnet_rowdot_scale(const float* g, const float* x, const float* scale, float* dx, float* dscale, size_t P,
+                                  int C, int mode, int accumulate_dscale, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(g && x && scale && dx && dscale, RPNET_ERR_ARG, "rowdot_scale: null pointer");
+    RPNET_REQUIRE(C % 4 == 0 && (mode == 1 || mode == 2), RPNET_ERR_SHAPE, "rowdot_scale: C=%d mode=%d", C, mode);
+    size_t nb = (P + 3) / 4; if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(rowdot_scale_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, x, scale, dx, dscale, P, C, mode, accumulate_dscale);
+    return check_launch("rowdot_scale");
+}
+
+extern "C" int rpnet_softmax_pool_bwd(const float* logits, const float* dmask, float* dlogits, int B, int K, int H, int W,
+                                      int scale, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(logits && dmask && dlogits, RPNET_ERR_ARG, "softmax_pool_bwd: null pointer");
+    RPNET_REQUIRE(K >= 2 && H % scale == 0 && W % scale == 0, RPNET_ERR_SHAPE, "softmax_pool_bwd: K=%d H=%d W=%d scale=%d", K, H, W, scale);
+    hipLaunchKernelGGL(softmax_pool_bwd_kernel, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, logits, dmask, dlogits, B, K, H, W, scale);
+    return check_launch("softmax_pool_bwd");
+}
 
 extern "C" int rpnet_mask_adjoint(const float* masks, float* am, float* msum, int B, int nmask, int H, int W, int h, int w,
                                   rpnet_stream_t stream) {

@@ -158,7 +158,7 @@ class ConvBnRelu(Function):
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dgamma), ptr(dbeta), N, H * W, cout, groups, ptr(ws), wsb)
         dw = torch.empty_like(weight)
-        dx0 = dx1 = None
+        dx0 = dx1 = dscale = None
         if first:
             wb = query("rpnet_conv1_wgrad_workspace_bytes", N, H, W, cout)
             ws2 = _ws(wb, y)
@@ -178,9 +178,15 @@ class ConvBnRelu(Function):
                 g0 = _empty((N, H, W, c0), y)
                 g1 = _empty((N, H, W, c1), y) if x1 is not None else None
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
+                need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
                 dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
-                           out_scale=in_scale, out_mode=in_mode)
+                           out_scale=None if need_s else in_scale, out_mode=in_mode)
                 call("rpnet_conv_fwd", C.byref(dd))
+                if need_s:   # d(x*f(s)) -> dx = g*f(s), ds = +-<g, x>
+                    gx, dscale = torch.empty_like(g0), torch.empty_like(in_scale)
+                    call("rpnet_rowdot_scale", ptr(g0), ptr(x0), ptr(in_scale), ptr(gx), ptr(dscale), N * H * W, c0,
+                         in_mode, 0)
+                    g0 = gx
                 if upsample:
                     h0 = _empty(x0.shape, y)
                     call("rpnet_upsample2_bwd", ptr(g0), ptr(h0), N, H, W, c0)
@@ -189,7 +195,7 @@ class ConvBnRelu(Function):
                 dx1 = g1 if need1 else None
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = torch.zeros_like(gamma)
-        return dx0, dx1, None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None):
@@ -326,6 +332,28 @@ class CosineMatchUp(Function):
         call("rpnet_cosine_match_bwd", ptr(f), ptr(proto), ptr(dpred), ptr(df), ptr(dproto), B, K, h * w, Cc, scaler, 0,
              ptr(ws), wb)
         return df, dproto, None, None, None
+
+
+class SoftmaxPool(Function):
+    """soft_mask: True — avg_pool2d(softmax(logits, 1)[:, 1], scale) kept differentiable (net/rp_net.py:308-311)."""
+
+    @staticmethod
+    def forward(ctx, logits, scale):
+        B, K, H, W = logits.shape
+        out = _empty((B, H // scale, W // scale), logits)
+        call("rpnet_softmax_thresh_pool", ptr(logits), ptr(out), B, K, H, W, scale, 1)
+        ctx.save_for_backward(logits)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmask):
+        (logits,) = ctx.saved_tensors
+        B, K, H, W = logits.shape
+        dl = torch.empty_like(logits)
+        call("rpnet_softmax_pool_bwd", ptr(logits), ptr(dmask.contiguous()), ptr(dl), B, K, H, W, ctx.scale)
+        return dl, None
 
 
 def softmax_thresh_pool(logits, scale, soft):

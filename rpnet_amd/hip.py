@@ -58,6 +58,8 @@ _SIGS = {
     "rpnet_bilinear_up_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_bilinear_up_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_softmax_thresh_pool": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_rowdot_scale": (ci, [vp, vp, vp, vp, vp, cs, ci, ci, ci, vp]),
+    "rpnet_softmax_pool_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_loss_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_dice_ce_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
     "rpnet_dice_ce_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),

@@ -250,15 +250,16 @@ class RP_Net(nn.Module):
 
         # ---- refinement loop (:281-312)
         soft = self.backbone_cfg["soft_mask"] != False  # noqa: E712 (the reference compares with ==)
-        if soft and torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("soft_mask=True: the gradient through the fed-back mask is not implemented")
         qry_mask = RF.mask_avgpool(appr_query_labels.float(), self.scale)
         refinement = {}
         inter = pred = None
         for i in range(self.num_iter):
             inter = self.cre.forward_masked(qry_d4, qry_mask, cache)
             logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
-            qry_mask = RF.softmax_thresh_pool(logits, self.scale, soft)
+            if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask
+                qry_mask = RF.SoftmaxPool.apply(logits, self.scale)
+            else:
+                qry_mask = RF.softmax_thresh_pool(logits, self.scale, soft)
             refinement[i] = logits
         # final pass (:314-337) recomputes refinement[T-1] bit for bit: alias it
         output = refinement[self.num_iter - 1]

@@ -198,3 +198,36 @@ def test_five_shot_extension_vs_composed_oracle():
                   [mv(qi[0])], appr_query_labels=mv(appr))
     for i in range(2):
         assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL
+
+
+def test_soft_mask_training_vs_oracle():
+    """soft_mask: True — the fed-back mask stays differentiable (net/rp_net.py:309): forward and
+    gradients against the CPU oracle (autograd through softmax -> avg_pool -> x*mask)."""
+    from oracle import rpnet_oracle as O
+    cfg = load_cfg(3)
+    cfg["soft_mask"] = True
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(91, 2, 64, "cpu")
+    P = O.seeded_params(requires_grad=True)
+    ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True)
+    ref_loss = O.total_loss(ref, ql)
+    ref_loss.backward()
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    out = net([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], appr_query_labels=mv(appr))
+    loss = total_loss(out, mv(ql), 1.0)
+    loss.backward()
+    for i in range(3):
+        assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL
+    assert rel_err(loss, ref_loss) < TOL
+    for n, p in net.named_parameters():
+        if p.grad is None or P[n].grad.norm() < 1e-4:
+            continue
+        a, b = p.grad.double().cpu().norm().item(), P[n].grad.double().norm().item()
+        tol = 1e-2 if n.startswith("encoder.") else 2e-3
+        assert abs(a - b) < tol * b, f"{n}: {a} vs {b}"
+    # the mask gradient really flows: hard-mask gradients differ
+    cfg_h = load_cfg(3)
+    net_h = build(cfg_h, True)
+    out_h = net_h([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], appr_query_labels=mv(appr))
+    total_loss(out_h, mv(ql), 1.0).backward()
+    assert rel_err(net_h.cre.q[0].weight.grad, net.cre.q[0].weight.grad) > 1e-3
