@@ -86,6 +86,7 @@ typedef struct rpnet_conv_desc {
     int taps;                          /* 9 or 1 */
     int upsample;                      /* sources are [N][H/2][W/2][C] */
     int groups;                        /* for ep_scale/ep_shift rows and the statistics below */
+    int dilation;                      /* 3x3 tap spacing: 0/1 = dense, 2 = the dilated last VGG block (net/vgg.py:31) */
     double* stats_partial;             /* optional: per (M-tile half, channel) sum / sum-of-squares of the
                                           output, [groups * rpnet_conv_stats_blocks()][Cout][2] — the
                                           train-mode BatchNorm batch statistics fused into the epilogue */
@@ -144,6 +145,17 @@ int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const floa
                  const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
                  int N, int HW, int C, int groups, void* workspace, size_t workspace_bytes,
                  rpnet_stream_t stream);
+
+/* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:
+ * dy = dz * [z > 0] (z may be NULL: no ReLU behind the conv) and db[c] = sum_pixels dy[p][c] */
+size_t rpnet_bias_relu_bwd_workspace_bytes(int C);
+int rpnet_bias_relu_bwd(const float* dz, const float* z, float* dy, float* db, size_t P, int C,
+                        void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+/* nn.MaxPool2d(kernel_size=3, stride=s, padding=1), s in {1,2} (net/vgg.py:23-29), NHWC; backward
+ * routes each window's gradient to its first maximum (gather form, no atomics) */
+int rpnet_maxpool3_fwd(const float* z, float* out, int N, int H, int W, int C, int stride, rpnet_stream_t stream);
+int rpnet_maxpool3_bwd(const float* z, const float* dpool, float* dz, int N, int H, int W, int C, int stride,
+                       rpnet_stream_t stream);
 
 /* ------------------------------------------------------------ pooling / up-sampling
  * nn.MaxPool2d(2,2) (net/unet.py:397) forward; backward routes the gradient to the

@@ -80,6 +80,23 @@ def unet_d4(P, x, training, prefix="encoder"):
     return d4
 
 
+def vgg_encoder(P, x, prefix="vgg"):
+    """vgg.Encoder.forward (net/vgg.py:8-58): (conv3x3, ReLU) blocks 2-2-3-3-3, MaxPool2d(3, 2, 1) x3,
+    MaxPool2d(3, 1, 1), last block dilation 2 without its final ReLU.  Keys `features.<b>.<i>.*`."""
+    plan = [(0, 2, 1, True), (2, 2, 1, True), (4, 3, 1, True), (6, 3, 1, True), (8, 3, 2, False)]
+    for bi, (blk, n, dil, last_relu) in enumerate(plan):
+        for i in range(n):
+            k = f"{prefix}.features.{blk}.{2 * i}"
+            x = F.conv2d(x, P[k + ".weight"], P[k + ".bias"], padding=dil, dilation=dil)
+            if i != n - 1 or last_relu:
+                x = F.relu(x)
+        if bi < 3:
+            x = F.max_pool2d(x, 3, 2, 1)
+        elif bi == 3:
+            x = F.max_pool2d(x, 3, 1, 1)
+    return x
+
+
 # --------------------------------------------------------------------- correlation
 def correlation_as_written(fmap1, fmap2, r):
     """Correlation + coords_grid + bilinear_sampler, operator for operator

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
     const int H = d.H, W = d.W, HW = H * W;
     const int ups = d.upsample;
     const int Hs = H >> ups, Ws = W >> ups;
+    const int dil = d.dilation > 1 ? d.dilation : 1;
 
     // the A rows this thread stages: r = (t >> 3) + 32 * j
     int rn[A_F4], ry[A_F4], rx[A_F4];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
     float rsc[A_F4];     // x*mask factor of that pixel (INSCALE only)
     auto tap_setup = [&](int tap) {
         int ky = 0, kx = 0;
-        if (d.taps == 9) { ky = tap / 3 - 1; kx = tap - (tap / 3) * 3 - 1; }
+        if (d.taps == 9) { ky = (tap / 3 - 1) * dil; kx = (tap - (tap / 3) * 3 - 1) * dil; }
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             const int iy = ry[j] + ky, ix = rx[j] + kx;

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const rpnet_conv_desc d
     const int cm0 = tm * BM, n0 = tn * BN;
     const int tap = blockIdx.y;
     int ky = 0, kx = 0;
-    if (d.taps == 9) { ky = tap / 3 - 1; kx = tap - (tap / 3) * 3 - 1; }
+    const int dil = d.dilation > 1 ? d.dilation : 1;
+    if (d.taps == 9) { ky = (tap / 3 - 1) * dil; kx = (tap - (tap / 3) * 3 - 1) * dil; }
 
     const int H = d.H, W = d.W, HW = H * W;
     const int ups = d.upsample;
@@ -412,14 +413,15 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
 }  // namespace rpnet
 
 extern "C" size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps) {
-    if (taps == 9 && cin_gathered % 64 == 0 && cout % 64 == 0) {
-        int ks9, sps9;
-        rpnet::wgrad9_plan(N * H * W, cin_gathered, cout, &ks9, &sps9);
-        return (size_t)ks9 * 9 * cin_gathered * cout * sizeof(float);
-    }
     int bm, bn, ks, sps;
     rpnet::wgrad_plan(N * H * W, cin_gathered, cout, taps, &bm, &bn, &ks, &sps);
-    return (size_t)ks * taps * cin_gathered * cout * sizeof(float);
+    size_t need = (size_t)ks * taps * cin_gathered * cout * sizeof(float);
+    if (taps == 9 && cin_gathered % 64 == 0 && cout % 64 == 0) {   // nine-tap kernel (dense) or single-tap (dilated): max
+        int ks9, sps9;
+        rpnet::wgrad9_plan(N * H * W, cin_gathered, cout, &ks9, &sps9);
+        need = std::max(need, (size_t)ks9 * 9 * cin_gathered * cout * sizeof(float));
+    }
+    return need;
 }
 
 extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int cin_w, int cin_off0,
@@ -432,7 +434,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
-    if (d->taps == 9) {
+    if (d->taps == 9 && d->dilation <= 1) {
         RPNET_REQUIRE(d->C1 == 0 || d->C0 % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to 64", d->C0);
         int ks9, sps9;
         wgrad9_plan(M, Cin, Cout, &ks9, &sps9);

@@ -87,12 +87,161 @@ __global__ void mask_avgpool_kernel(const float* __restrict__ m, float* __restri
     out[i] = acc / (float)(s * s);
 }
 
+// MaxPool2d(3, stride, padding=1): -inf padding, first maximum in (ky, kx) scan order
+__global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H,
+                                                            int W, int Ho, int Wo, int C4, int stride) {
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(z)[(((size_t)n * H + iy) * W + ix) * C4 + c4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = m;
+    }
+}
+
+// gather form: input pixel (iy, ix) receives dpool of every window whose FIRST maximum it is
+__global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool,
+                                                            float* __restrict__ dz, int N, int H, int W, int Ho, int Wo,
+                                                            int C4, int stride) {
+    const size_t total = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H);
+        const int n = (int)(p / H);
+        const f32x4 me = reinterpret_cast<const f32x4*>(z)[i];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int oy_hi = min(Ho - 1, (iy + 1) / stride), ox_hi = min(Wo - 1, (ix + 1) / stride);
+        for (int oy = max(0, oy_hi - 2); oy <= oy_hi; ++oy) {       // candidate windows; coverage checked below
+            for (int ox = max(0, ox_hi - 2); ox <= ox_hi; ++ox) {
+                const int y0 = oy * stride - 1, x0 = ox * stride - 1;
+                if (iy < y0 || iy > y0 + 2 || ix < x0 || ix > x0 + 2) continue;
+                const int myrank = (iy - y0) * 3 + (ix - x0);
+                bool first[4] = {true, true, true, true};
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y0 + ky;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = x0 + kx;
+                        if (xx < 0 || xx >= W) continue;
+                        const int rank = ky * 3 + kx;
+                        if (rank == myrank) continue;
+                        const f32x4 v = reinterpret_cast<const f32x4*>(z)[(((size_t)n * H + yy) * W + xx) * C4 + c4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)   // beaten by a larger value, or by an equal one scanned earlier
+                            if (v[k] > me[k] || (v[k] == me[k] && rank < myrank)) first[k] = false;
+                    }
+                }
+                const f32x4 g = reinterpret_cast<const f32x4*>(dpool)[(((size_t)n * Ho + oy) * Wo + ox) * C4 + c4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (first[k]) acc[k] += g[k];
+            }
+        }
+        reinterpret_cast<f32x4*>(dz)[i] = acc;
+    }
+}
+
+// dy = dz * [z > 0]; db partial column sums: partial[blk][C]
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                             float* __restrict__ dy, double* __restrict__ partial, size_t P,
+                                                             int C) {
+    __shared__ double red[256 * 4];
+    const int t = threadIdx.x, C4 = C / 4, rows_it = 256 / C4;
+    const int tc = t % C4, tr = t / C4;
+    double s[4] = {0, 0, 0, 0};
+    if (tr < rows_it)
+        for (size_t r = (size_t)blockIdx.x * rows_it + tr; r < P; r += (size_t)gridDim.x * rows_it) {
+            f32x4 g = reinterpret_cast<const f32x4*>(dz + r * C)[tc];
+            if (z) {
+                const f32x4 zv = reinterpret_cast<const f32x4*>(z + r * C)[tc];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = zv[k] > 0.f ? g[k] : 0.f;
+            }
+            reinterpret_cast<f32x4*>(dy + r * C)[tc] = g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += g[k];
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[t * 4 + k] = s[k];
+    __syncthreads();
+    if (tr == 0) {
+        for (int rr = 1; rr < rows_it; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += red[(rr * C4 + tc) * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) partial[(size_t)blockIdx.x * C + tc * 4 + k] = s[k];
+    }
+}
+
+__global__ __launch_bounds__(64) void bias_grad_final(const double* __restrict__ partial, float* __restrict__ db, int nblk, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0;
+    for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * C + c];
+    s = wave_sum(s);
+    if (lane == 0) db[c] = (float)s;
+}
+
+constexpr int kBiasBlocks = 512;
+
 static int pool_grid(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
 }  // namespace rpnet
+
+extern "C" size_t rpnet_bias_relu_bwd_workspace_bytes(int C) { return (size_t)rpnet::kBiasBlocks * C * sizeof(double); }
+
+extern "C" int rpnet_bias_relu_bwd(const float* dz, const float* z, float* dy, float* db, size_t P, int C, void* workspace,
+                                   size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(dz && dy && db && workspace, RPNET_ERR_ARG, "bias_relu_bwd: null pointer");
+    RPNET_REQUIRE(C % 4 == 0 && C / 4 <= 256, RPNET_ERR_SHAPE, "bias_relu_bwd: C=%d", C);
+    RPNET_REQUIRE(workspace_bytes >= rpnet_bias_relu_bwd_workspace_bytes(C), RPNET_ERR_WORKSPACE, "bias_relu_bwd: workspace");
+    const int rows_it = 256 / (C / 4);
+    int nb = (int)((P + rows_it - 1) / rows_it);
+    if (nb > kBiasBlocks) nb = kBiasBlocks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(nb), dim3(256), 0, s, dz, z, dy, (double*)workspace, P, C);
+    hipLaunchKernelGGL(bias_grad_final, dim3(C), dim3(64), 0, s, (const double*)workspace, db, nb, C);
+    return check_launch("bias_relu_bwd");
+}
+
+extern "C" int rpnet_maxpool3_fwd(const float* z, float* out, int N, int H, int W, int C, int stride, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(z && out, RPNET_ERR_ARG, "maxpool3_fwd: null pointer");
+    RPNET_REQUIRE(C % 4 == 0 && (stride == 1 || stride == 2), RPNET_ERR_SHAPE, "maxpool3_fwd: C=%d stride=%d", C, stride);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, Ho, Wo, C / 4, stride);
+    return check_launch("maxpool3_fwd");
+}
+
+extern "C" int rpnet_maxpool3_bwd(const float* z, const float* dpool, float* dz, int N, int H, int W, int C, int stride,
+                                  rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(z && dpool && dz, RPNET_ERR_ARG, "maxpool3_bwd: null pointer");
+    RPNET_REQUIRE(C % 4 == 0 && (stride == 1 || stride == 2), RPNET_ERR_SHAPE, "maxpool3_bwd: C=%d stride=%d", C, stride);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t total = (size_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, dpool, dz, N, H, W, Ho, Wo, C / 4, stride);
+    return check_launch("maxpool3_bwd");
+}
 
 extern "C" int rpnet_maxpool2_fwd(const float* z, float* out, int N, int H, int W, int C, rpnet_stream_t stream) {
     using namespace rpnet;

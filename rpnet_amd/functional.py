@@ -205,6 +205,72 @@ def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=
                             1 if upsample else 0, in_mode)
 
 
+class ConvRelu(Function):
+    """Conv2d(3x3, padding = dilation, bias) [-> ReLU], no BatchNorm: the (conv, relu) layers of
+    vgg.Encoder (net/vgg.py:39-58).  x [N,H,W,Cg] NHWC with Cg = the packed (zero padded) Cin."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pw, relu, dilation):
+        hip.require_gpu(x, weight)
+        N, H, W, _ = x.shape
+        cout = weight.shape[0]
+        z = _empty((N, H, W, cout), x)
+        d = _desc(x, None, pw.wp, bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
+        d.dilation = dilation
+        call("rpnet_conv_fwd", C.byref(d))
+        ctx.save_for_backward(x, weight, z)
+        ctx.pw, ctx.cfg = pw, (relu, dilation)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, weight, z = ctx.saved_tensors
+        pw = ctx.pw
+        relu, dilation = ctx.cfg
+        N, H, W, cout = z.shape
+        dy, db = torch.empty_like(z), _empty((cout,), z)
+        wb = query("rpnet_bias_relu_bwd_workspace_bytes", cout)
+        ws = _ws(wb, z)
+        call("rpnet_bias_relu_bwd", ptr(dz.contiguous()), ptr(z) if relu else None, ptr(dy), ptr(db), N * H * W, cout,
+             ptr(ws), wb)
+        dw = torch.empty_like(weight)
+        d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+        d.Co0, d.dilation = cout, dilation
+        wb2 = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
+        ws2 = _ws(wb2, z)
+        call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
+        dx = None
+        if ctx.needs_input_grad[0] and pw.wd is not None:
+            dx = _empty(x.shape, z)
+            dd = _desc(dy, None, pw.wd, None, None, 0, dx, None, N, H, W, pw.taps, 0)
+            dd.dilation = dilation
+            call("rpnet_conv_fwd", C.byref(dd))
+        return dx, dw, db, None, None, None
+
+
+class MaxPool3(Function):
+    """nn.MaxPool2d(kernel_size=3, stride=s, padding=1) (net/vgg.py:23-29) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, z, stride):
+        N, H, W, Cc = z.shape
+        out = _empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, Cc), z)
+        call("rpnet_maxpool3_fwd", ptr(z), ptr(out), N, H, W, Cc, stride)
+        ctx.save_for_backward(z)
+        ctx.stride = stride
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpool):
+        (z,) = ctx.saved_tensors
+        N, H, W, Cc = z.shape
+        dz = torch.empty_like(z)
+        call("rpnet_maxpool3_bwd", ptr(z), ptr(dpool.contiguous()), ptr(dz), N, H, W, Cc, ctx.stride)
+        return dz, None
+
+
 # ------------------------------------------------------------------------ pooling
 class MaxPool2(Function):
     """nn.MaxPool2d(2, 2) (net/unet.py:397) on NHWC."""

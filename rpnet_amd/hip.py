@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("C0", ci), ("C1", ci), ("w", vp), ("bias", vp), ("in_scale", vp),
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
-                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("stats_partial", vp)]
+                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp)]
 
 
 _SIGS = {
@@ -41,6 +41,10 @@ _SIGS = {
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
     "rpnet_bn_relu": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
+    "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
+    "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_maxpool3_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_maxpool2_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_maxpool2_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_upsample2_bwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),

@@ -129,6 +129,64 @@ class U_Net(Unet_2D):
         return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache()))}
 
 
+class Encoder(nn.Module):
+    """net/vgg.py:8-74 — VGG16-style (conv3x3, ReLU) stack, stride 8, last block dilated by 2 and
+    without its final ReLU.  Same constructor / forward signature / `features.*` state_dict keys.
+    (RP_Net cannot use it in the reference either: net/rp_net.py:248-249 indexes its tensor
+    output with ['d4'] — kept as a standalone module on the shared conv kernels.)"""
+
+    def __init__(self, in_channels=3, pretrained_path=None):
+        super().__init__()
+        self.pretrained_path = pretrained_path
+        self.features = nn.Sequential(
+            self._make_layer(2, in_channels, 64), nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+            self._make_layer(2, 64, 128), nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+            self._make_layer(3, 128, 256), nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+            self._make_layer(3, 256, 512), nn.MaxPool2d(kernel_size=3, stride=1, padding=1),
+            self._make_layer(3, 512, 512, dilation=2, lastRelu=False))
+        self._init_weights()
+
+    def _make_layer(self, n_convs, in_channels, out_channels, dilation=1, lastRelu=True):
+        layer = []
+        for i in range(n_convs):
+            layer.append(nn.Conv2d(in_channels, out_channels, kernel_size=3, dilation=dilation, padding=dilation))
+            if i != n_convs - 1 or lastRelu:
+                layer.append(nn.ReLU(inplace=True))
+            in_channels = out_channels
+        return nn.Sequential(*layer)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+        if self.pretrained_path is not None:   # net/vgg.py:65-74: first 26 tensors of a VGG16 checkpoint
+            dic = torch.load(self.pretrained_path, map_location="cpu")
+            keys, new_dic = list(dic.keys()), self.state_dict()
+            new_keys = list(new_dic.keys())
+            for i in range(26):
+                new_dic[new_keys[i]] = dic[keys[i]]
+            self.load_state_dict(new_dic)
+
+    def forward(self, x, mask=None):
+        cache = RF.WeightCache()
+        n, c, h, w = x.shape
+        cg = 64                                     # packed Cin of the first conv: 3 real + zero channels
+        a = torch.zeros(n, h, w, cg, device=x.device, dtype=torch.float32)
+        a[..., :c] = x.permute(0, 2, 3, 1)
+        for block in self.features:
+            if isinstance(block, nn.MaxPool2d):
+                a = RF.MaxPool3.apply(a, block.stride)
+                continue
+            mods = list(block)
+            for i, m in enumerate(mods):
+                if not isinstance(m, nn.Conv2d):
+                    continue
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                split = (m.in_channels, cg) if m.in_channels < 32 else None
+                a = RF.ConvRelu.apply(a, m.weight, m.bias, cache.get(m.weight, split), relu, m.dilation[0])
+        return a.permute(0, 3, 1, 2)
+
+
 class ContextCorrelationEncoder(nn.Module):
     """net/rp_net.py:45-84.  w_context / out are constructed (state_dict parity) and never used."""
 

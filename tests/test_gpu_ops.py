@@ -292,3 +292,42 @@ def test_align_loss(golden):
     assert rel_err(nchw(qf.grad), g["al_gq"]) < 1e-3 and rel_err(nchw(sf.grad)[None], g["al_gs"]) < 1e-3
     pred_bg = pred.clone(); pred_bg[:, 0] = 10; pred_bg[:, 1] = -10
     assert float(RP_Net.alignLoss(net, qf, pred_bg, [[sf]], [[fm[0][None]]], [[1 - fm[0][None]]])) == 0.0
+
+
+def test_vgg_encoder(golden):
+    """vgg.Encoder (net/vgg.py) on the shared conv kernels: forward against the reference's own
+    output, backward against the oracle's autograd.  Dilated last block, MaxPool2d(3, s, 1), Cin = 3."""
+    from oracle import rpnet_oracle as O
+    from rpnet_amd.modules import Encoder
+    from rpnet_amd.utils.seeding import seeded_tensor
+    g = golden("vgg")
+    enc = Encoder(3, None)
+    sd = {k: seeded_tensor(f"vgg.{k}", v) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    enc = enc.to(DEV)
+    x = torch.from_numpy(g["x"])
+    y = enc(x.to(DEV))
+    assert rel_err(y, g["y"]) < TOL
+    P = {f"vgg.{k}": v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.vgg_encoder(P, x)
+    go = rnd(71, *ref.shape)
+    ref.backward(go)
+    y.backward(go.to(DEV))
+    for k, p in enc.named_parameters():
+        r = P[f"vgg.{k}"].grad
+        assert (p.grad.cpu() - r).norm() < 5e-3 * r.norm() + 1e-6, k      # ReLU / max-pool switches: see DESIGN.md Parity
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_maxpool3(RF, stride):
+    x = rnd(72, 2, 8, 9, 11)
+    x[0, :, 0:3, 0:3] = 1.5       # ties: the first maximum in scan order takes the gradient
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, stride, 1)
+    go = rnd(73, *ref.shape)
+    ref.backward(go)
+    xg = nhwc(x).to(DEV).requires_grad_(True)
+    out = RF.MaxPool3.apply(xg, stride)
+    out.backward(nhwc(go).to(DEV))
+    assert torch.equal(nchw(out).cpu(), ref.detach())
+    assert rel_err(nchw(xg.grad), xr.grad) < 1e-6

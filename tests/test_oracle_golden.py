@@ -139,3 +139,15 @@ def test_teacher_forced_iteration(golden):
         out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=False, forced_masks=forced)
     for i in range(T):
         assert rel_err(out["refinement"][i], g[f"refinement_{i}"]) < TOL
+
+
+def test_vgg_encoder_vs_golden(golden):
+    """oracle restatement of vgg.Encoder against the reference's own output (name-seeded weights)."""
+    from rpnet_amd.modules import Encoder
+    from rpnet_amd.utils.seeding import seeded_tensor
+    g = golden("vgg")
+    enc = Encoder(3, None)
+    P = {f"vgg.{k}": seeded_tensor(f"vgg.{k}", v) for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        y = O.vgg_encoder(P, torch.from_numpy(g["x"]))
+    assert y.shape == (1, 512, 8, 8) and rel_err(y, g["y"]) < 1e-5
