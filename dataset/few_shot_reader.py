@@ -1,0 +1,55 @@
+"""`dataset.few_shot_reader.FewshotRegReader` with the item contract test_rpnet.py consumes
+(test_rpnet.py:70,166-184; reference dataset/few_shot_reader.py:592-650).
+
+The reference reader needs the private ABD-110 NRRD volumes plus nrrd / nibabel / SimpleITK
+and a per-slice registration optimiser; none exists offline.  This reader serves SYNTHETIC
+volumes with the same keys, shapes and dtypes (rpnet_amd.utils.synth), so the evaluation
+loop runs end to end on the MI355X path.  Real-data reading is §8(f).4 and raises.
+"""
+import os
+
+import numpy as np
+import torch
+
+from rpnet_amd.utils.synth import make_episode
+
+
+class _VolumeInfo:
+    def __init__(self, classes, n_vol):
+        self.data_info = [[{"pid": f"synthetic_{c}_{i:03d}"} for i in range(n_vol)] for c in range(len(classes))]
+
+
+class _SliceReader:
+    def __init__(self, classes, n_vol):
+        self.fewshot_volume_reader = _VolumeInfo(classes, n_vol)
+
+
+class FewshotRegReader(torch.utils.data.Dataset):
+    def __init__(self, data_dir, set_name, config, mode="train", n_volumes=4, n_slices=6, size=256):
+        if data_dir and os.path.isdir(data_dir) and any(f.endswith(".nrrd") for f in os.listdir(data_dir)):
+            raise NotImplementedError("NRRD volume reading (reference few_shot_reader.py:232-398) is out of scope; "
+                                      "point data_dir at a non-existing path to get synthetic volumes")
+        self.config, self.mode = config, mode
+        self.classes = config.get("eval_classes" if mode == "eval" else "train_classes", ["Liver"])
+        self.n_volumes, self.n_slices, self.size = n_volumes, n_slices, size
+        self.fewshot_reader = _SliceReader(self.classes, n_volumes)
+
+    def __len__(self):
+        return len(self.classes) * self.n_volumes
+
+    def __getitem__(self, idx):
+        if idx >= len(self):
+            raise IndexError(idx)
+        class_id, vol = divmod(idx, self.n_volumes)
+        S, H = self.n_slices, self.size
+        ep = make_episode(7000 + idx, S, H)
+        t = torch.from_numpy
+        supp_img, supp_lab = t(ep["support_images"][0][0]), t(ep["support_fg"][0][0])
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, H), indexing="ij")
+        grid = torch.stack([xs, ys], -1)[None].repeat(S, 1, 1, 1)
+        supp_idx = (vol + 1) % self.n_volumes
+        return {"support_images": [[supp_img]], "support_labels": [[supp_lab]], "warped_supp": supp_img[:, 0],
+                "query_images": t(ep["query_images"]), "query_labels": t(ep["query_labels"]),
+                "appr_query_labels": t(ep["appr_query_labels"]), "grid": grid, "class_id": class_id,
+                "pid": self.fewshot_reader.fewshot_volume_reader.data_info[class_id][vol]["pid"],
+                "supp_pids": [(class_id, supp_idx)], "registration_field": None}

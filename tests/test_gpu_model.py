@@ -231,3 +231,18 @@ def test_soft_mask_training_vs_oracle():
     out_h = net_h([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], appr_query_labels=mv(appr))
     total_loss(out_h, mv(ql), 1.0).backward()
     assert rel_err(net_h.cre.q[0].weight.grad, net.cre.q[0].weight.grad) > 1e-3
+
+
+def test_eval_driver_end_to_end():
+    """The evaluation loop of the reference's driver shape (tools/eval_driver.py) over the synthetic
+    reader, eval mode, T = n_test_iter_refinement: runs through the HIP path and yields Dice values."""
+    from dataset.few_shot_reader import FewshotRegReader
+    from tools.eval_driver import evaluate
+    cfg = load_cfg()
+    cfg["n_iter_refinement"] = cfg["n_test_iter_refinement"]
+    ds = FewshotRegReader("/nonexistent", cfg["eval_set_name"], cfg, mode="eval", n_volumes=2, n_slices=4, size=128)
+    net = build(cfg, False)
+    aff, few, ref = evaluate(net, ds, cfg, n_items=2)
+    assert len(few["Liver"]) == 2 and all(0.0 <= d <= 1.0 for d in few["Liver"])
+    assert sorted(ref["Liver"].keys()) == list(range(10))
+    assert few["Liver"] == [r for r in ref["Liver"][9]]          # output == refinement[T-1]
