@@ -175,11 +175,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    local_rank %= torch.cuda.device_count()   # > 1 rank per device only happens in the gloo plumbing test
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("RPNET_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for 1-GPU plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
     cfg["n_iter_refinement"] = args.iters
@@ -216,8 +221,10 @@ def main():
     gf_pair = algorithmic_gf_per_pair(args.size, args.iters)
 
     result = None
+    # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
+    # issued by rank 0 alone would never complete); only rank 0 reports.
+    agg = profile_step(net, bucket, inp, scaler)
     if rank == 0:
-        agg = profile_step(net, bucket, inp, scaler)
         conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
         wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
         achieved = conv[2] / conv[1] / 1e12
