@@ -16,11 +16,15 @@ constexpr int CT = 8;        // pixel tile edge
 constexpr int CC = 32;       // channels per LDS stage
 constexpr int CSTR = CC + 4; // padded row (floats), keeps float4 alignment
 
+// forward: register-tiled so the kernel is VALU-bound, not LDS-bound.  A thread owns 4 horizontally
+// adjacent pixels and ONE vertical offset (dy): per 4 channels it reads the 4 f1 pixels and the
+// 4 + 2R f2 pixels of the shifted row once (float4 each) and does 4 * K * 4 FMAs (K = 2R+1
+// horizontal offsets) — 0.1 LDS reads per FMA instead of 0.26 with one pixel per thread.
 template <int R>
 __global__ __launch_bounds__(256) void local_corr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                               float* __restrict__ corr, int h, int w, int C, int cstride,
                                                               float inv_sqrt_c) {
-    constexpr int K = 2 * R + 1, KK = K * K, HT = CT + 2 * R, NI = (KK + 3) / 4;
+    constexpr int K = 2 * R + 1, KK = K * K, HT = CT + 2 * R, NX = 4 + 2 * R;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* f2s = sm;                    // [HT*HT][CSTR]
     float* f1s = sm + HT * HT * CSTR;   // [64][CSTR]
@@ -28,57 +32,66 @@ __global__ __launch_bounds__(256) void local_corr_fwd_kernel(const float* __rest
     const int tiles_x = (w + CT - 1) / CT;
     const int b = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles_x) * CT, tx0 = (blockIdx.x % tiles_x) * CT;
-    const int pix = t & 63, og = t >> 6;
-    const int py = pix >> 3, px = pix & 7;
+    // thread -> (quad: row py, pixels px0..px0+3; vertical offset index cdy); 16 quads x K offsets
+    const int quad = t & 15, cdy = t >> 4;
+    const int py = quad >> 1, px0 = (quad & 1) * 4;
+    const bool active = cdy < K;
 
-    int noff[NI];
+    float acc[4][K];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int o = og * NI + i;
-        const int a = o / K, c = o - a * K;  // a -> x offset, c -> y offset
-        noff[i] = (o < KK) ? ((py + c) * HT + (px + a)) * CSTR : 0;
-    }
-    float acc[NI];
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+        for (int a = 0; a < K; ++a) acc[p][a] = 0.f;
 
     const float* f1b = f1 + (size_t)b * h * w * C;
     const float* f2b = f2 + (size_t)b * h * w * C;
+    const int f1row = (py * 8 + px0) * CSTR;
+    const int f2row = ((py + (active ? cdy : 0)) * HT + px0) * CSTR;
     for (int c0 = 0; c0 < C; c0 += CC) {
         __syncthreads();
         for (int e = t; e < HT * HT * (CC / 4); e += 256) {
             const int c4 = e & 7, hp = e >> 3;
             const int hy = hp / HT, hx = hp - hy * HT;
             const int y = ty0 + hy - R, x = tx0 + hx - R;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const f32x4*>(f2b + ((size_t)y * w + x) * C + c0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(&f2s[hp * CSTR + c4 * 4]) = v;
+            const bool ok = y >= 0 && y < h && x >= 0 && x < w;     // clamped, unconditional load (no per-load wait)
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            *reinterpret_cast<f32x4*>(&f2s[hp * CSTR + c4 * 4]) =
+                *reinterpret_cast<const f32x4*>(f2b + ((size_t)yc * w + xc) * C + c0 + c4 * 4) * (ok ? 1.f : 0.f);
         }
         for (int e = t; e < 64 * (CC / 4); e += 256) {
             const int c4 = e & 7, p = e >> 3;
             const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y < h && x < w) v = *reinterpret_cast<const f32x4*>(f1b + ((size_t)y * w + x) * C + c0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(&f1s[p * CSTR + c4 * 4]) = v;
+            const bool ok = y < h && x < w;
+            *reinterpret_cast<f32x4*>(&f1s[p * CSTR + c4 * 4]) =
+                *reinterpret_cast<const f32x4*>(f1b + ((size_t)min(y, h - 1) * w + min(x, w - 1)) * C + c0 + c4 * 4) * (ok ? 1.f : 0.f);
         }
         __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int c4 = 0; c4 < CC / 4; ++c4) {
+                f32x4 a1[4], b2[NX];
 #pragma unroll
-        for (int c4 = 0; c4 < CC / 4; ++c4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&f1s[pix * CSTR + c4 * 4]);
+                for (int p = 0; p < 4; ++p) a1[p] = *reinterpret_cast<const f32x4*>(&f1s[f1row + p * CSTR + c4 * 4]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(&f2s[noff[i] + c4 * 4]);
-                acc[i] += a[0] * bv[0] + a[1] * bv[1] + a[2] * bv[2] + a[3] * bv[3];
+                for (int j = 0; j < NX; ++j) b2[j] = *reinterpret_cast<const f32x4*>(&f2s[f2row + j * CSTR + c4 * 4]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int a = 0; a < K; ++a) {
+                        const f32x4 bv = b2[p + a];
+                        acc[p][a] += a1[p][0] * bv[0] + a1[p][1] * bv[1] + a1[p][2] * bv[2] + a1[p][3] * bv[3];
+                    }
             }
         }
     }
     // stage the tile as [64][cstride] rows and write them out contiguously
     __syncthreads();
     float* outs = sm;  // 64 * cstride floats (host checks it fits)
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int o = og * NI + i;
-        if (o < KK) outs[pix * cstride + o] = acc[i] * inv_sqrt_c;
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int a = 0; a < K; ++a) outs[(py * 8 + px0 + p) * cstride + a * K + cdy] = acc[p][a] * inv_sqrt_c;
     }
     for (int e = t; e < 64 * (cstride - KK); e += 256) {
         const int p = e / (cstride - KK), o = KK + e - p * (cstride - KK);
@@ -117,57 +130,69 @@ __global__ void corr_transpose_kernel(const float* __restrict__ dcorr, float* __
 
 // df[b,p,ch] = inv_sqrt_c * sum_o g[b,p,o] * fo[b, p + sign*off(o), ch]
 //   sign=+1, g = dcorr, fo = f2  -> d f1 ;  sign=-1, g = dcT, fo = f1 -> d f2
-template <int R>
+// Register-tiled like the forward: a thread owns 4 adjacent pixels x 4 channels; per vertical offset
+// it reads the 4 x K window gradients (3 float4 per pixel from a [px][dy][dx] LDS image) and the
+// 4 + 2R shifted feature pixels once and does 4 * K * 4 FMAs.  64 channels per LDS stage.
+constexpr int BC = 64;          // channels per stage (backward)
+constexpr int BSTR = BC + 4;    // padded feature row
+template <int R, int SIGN>
 __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __restrict__ g, const float* __restrict__ fo,
                                                               float* __restrict__ df, int h, int w, int C, int cstride,
-                                                              int sign, float inv_sqrt_c) {
-    constexpr int K = 2 * R + 1, KK = K * K, HT = CT + 2 * R;
-    constexpr int GSTR = KK + 1;
+                                                              float inv_sqrt_c) {
+    constexpr int K = 2 * R + 1, HT = CT + 2 * R, NX = 4 + 2 * R, KA = (K + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* fs = sm;                   // [HT*HT][CSTR]
-    float* gs = sm + HT * HT * CSTR;  // [64][GSTR]
+    float* fs = sm;                   // [HT*HT][BSTR]
+    float* gs = sm + HT * HT * BSTR;  // [64][K][KA]
     const int t = threadIdx.x;
     const int tiles_x = (w + CT - 1) / CT;
     const int b = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles_x) * CT, tx0 = (blockIdx.x % tiles_x) * CT;
-    const int pix = t & 63, cg = t >> 6;  // 8 channels per thread inside the 32-channel stage
-    const int py = pix >> 3, px = pix & 7;
+    const int quad = t & 15, cg = t >> 4;       // 16 quads x 16 channel groups of 4
+    const int py = quad >> 1, px0 = (quad & 1) * 4;
     const float* gb = g + (size_t)b * h * w * cstride;
     const float* fb = fo + (size_t)b * h * w * C;
     float* dfb = df + (size_t)b * h * w * C;
 
-    for (int e = t; e < 64 * KK; e += 256) {
-        const int p = e / KK, o = e - p * KK;
+    for (int e = t; e < 64 * K * KA; e += 256) {
+        const int a = e % KA, c = (e / KA) % K, p = e / (KA * K);
         const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
-        gs[p * GSTR + o] = (y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] : 0.f;
+        const bool ok = a < K && y < h && x < w;
+        gs[e] = gb[((size_t)min(y, h - 1) * w + min(x, w - 1)) * cstride + min(a, K - 1) * K + c] * (ok ? 1.f : 0.f);
     }
-    for (int c0 = 0; c0 < C; c0 += CC) {
+    for (int c0 = 0; c0 < C; c0 += BC) {
         __syncthreads();
-        for (int e = t; e < HT * HT * (CC / 4); e += 256) {
-            const int c4 = e & 7, hp = e >> 3;
+        for (int e = t; e < HT * HT * (BC / 4); e += 256) {
+            const int c4 = e & 15, hp = e >> 4;
             const int hy = hp / HT, hx = hp - hy * HT;
             const int y = ty0 + hy - R, x = tx0 + hx - R;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < h && x >= 0 && x < w) v = *reinterpret_cast<const f32x4*>(fb + ((size_t)y * w + x) * C + c0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(&fs[hp * CSTR + c4 * 4]) = v;
+            const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            *reinterpret_cast<f32x4*>(&fs[hp * BSTR + c4 * 4]) =
+                *reinterpret_cast<const f32x4*>(fb + ((size_t)yc * w + xc) * C + c0 + c4 * 4) * (ok ? 1.f : 0.f);
         }
         __syncthreads();
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < K; ++a) {
+        f32x4 acc[4];
 #pragma unroll
-            for (int c = 0; c < K; ++c) {
-                const float gv = gs[pix * GSTR + a * K + c];
-                const int ny = py + R + sign * (c - R), nx = px + R + sign * (a - R);
-                const float* src = &fs[(ny * HT + nx) * CSTR + cg * 8];
-                a0 += gv * *reinterpret_cast<const f32x4*>(src);
-                a1 += gv * *reinterpret_cast<const f32x4*>(src + 4);
+        for (int p = 0; p < 4; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < K; ++c) {
+            const int ny = py + R + SIGN * (c - R);
+            f32x4 fv[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) fv[j] = *reinterpret_cast<const f32x4*>(&fs[(ny * HT + px0 + j) * BSTR + cg * 4]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float gv[KA];
+#pragma unroll
+                for (int q = 0; q < KA / 4; ++q)
+                    *reinterpret_cast<f32x4*>(&gv[q * 4]) = *reinterpret_cast<const f32x4*>(&gs[((py * 8 + px0 + p) * K + c) * KA + q * 4]);
+#pragma unroll
+                for (int a = 0; a < K; ++a) acc[p] += gv[a] * fv[SIGN > 0 ? p + a : p + (K - 1 - a)];
             }
         }
-        const int y = ty0 + py, x = tx0 + px;
-        if (y < h && x < w) {
-            float* dst = dfb + ((size_t)y * w + x) * C + c0 + cg * 8;
-            *reinterpret_cast<f32x4*>(dst) = a0 * inv_sqrt_c;
-            *reinterpret_cast<f32x4*>(dst + 4) = a1 * inv_sqrt_c;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty0 + py, x = tx0 + px0 + p;
+            if (y < h && x < w) *reinterpret_cast<f32x4*>(dfb + ((size_t)y * w + x) * C + c0 + cg * 4) = acc[p] * inv_sqrt_c;
         }
     }
 }
@@ -217,6 +242,7 @@ extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const floa
     using namespace rpnet;
     RPNET_REQUIRE(f1 && f2 && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_bwd: null pointer");
     RPNET_REQUIRE(C % CC == 0 && cstride >= (2 * r + 1) * (2 * r + 1), RPNET_ERR_SHAPE, "local_corr_bwd: C=%d cstride=%d", C, cstride);
+    RPNET_REQUIRE(C % BC == 0, RPNET_ERR_SHAPE, "local_corr_bwd: C=%d must be a multiple of 64", C);
     RPNET_REQUIRE(workspace_bytes >= rpnet_local_corr_bwd_workspace_bytes(B, h, w, cstride), RPNET_ERR_WORKSPACE,
                   "local_corr_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -227,13 +253,14 @@ extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const floa
     int nb = (int)((total + 255) / 256);
     if (nb > 16384) nb = 16384;
     RPNET_CORR_DISPATCH(r, {
-        constexpr int K = 2 * RR + 1, HT = CT + 2 * RR;
-        const size_t lds = (size_t)(HT * HT * CSTR + 64 * (K * K + 1)) * sizeof(float);
+        constexpr int K = 2 * RR + 1, HT = CT + 2 * RR, KA = (K + 3) & ~3;
+        const size_t lds = (size_t)(HT * HT * BSTR + 64 * K * KA) * sizeof(float);
         // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, +1, isc);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc);
         hipLaunchKernelGGL((corr_transpose_kernel<RR>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, -1, isc);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc);
     });
     return check_launch("local_corr_bwd");
 }

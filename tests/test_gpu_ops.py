@@ -186,7 +186,7 @@ def test_mask_avgpool_and_threshold(RF):
         assert (got - ref).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("dims", [(2, 32, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5)])
+@pytest.mark.parametrize("dims", [(2, 64, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5)])
 def test_local_correlation(RF, dims):
     from oracle import rpnet_oracle as O
     b, c, h, w, r = dims
