@@ -18,40 +18,67 @@ class FlatGradBucket:
     """Gradients of `module` as views into one contiguous buffer.
 
     p.grad is pre-set to a view of the flat buffer, so autograd accumulates straight into it
-    (no gather copy); `zero()` is one memset, `allreduce()` is one collective + one scale.
+    (no gather copy); `zero()` is one memset.  The exchange is split in two so that most of it
+    hides under the backward pass: backward reaches the parameters in reverse module order
+    (cre.* and the decoder half Up_conv4..Up5 first, Conv5..Conv1 last), so the TAIL of the buffer
+    (everything from `split_at` on, ~46 % of the bytes) is final as soon as the first gradient of
+    the HEAD has been accumulated — a post-accumulate hook on that parameter launches the tail's
+    all-reduce asynchronously (RCCL stream) while the rest of backward still runs; `allreduce()`
+    then only exposes the head's all-reduce.  Both are plain sums over identical buffers on every
+    rank, so results do not depend on the overlap.
     """
 
-    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES):
+    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES, split_at="encoder.Up5."):
         self.params = [(n, p) for n, p in module.named_parameters()
                        if p.requires_grad and not n.startswith(tuple(skip_prefixes))]
         total = sum(p.numel() for _, p in self.params)
         p0 = self.params[0][1]
         self.flat = torch.zeros(total, device=p0.device, dtype=torch.float32)
-        off = 0
-        for _, p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        off, self.split = 0, None
+        for n, p in self.params:
+            if self.split is None and split_at and n.startswith(split_at):
+                self.split = off
+            k = p.numel()
+            p.grad = self.flat[off:off + k].view_as(p)
+            off += k
         self.numel = total
+        self._tail_work = None
+        self._hook = None
+        if self.split:   # the last head parameter in module order is the FIRST head gradient backward produces
+            trigger = [p for n, p in self.params if not n.startswith(split_at)]
+            head_last = None
+            o = 0
+            for n, p in self.params:
+                if o + p.numel() <= self.split:
+                    head_last = p
+                o += p.numel()
+            if head_last is not None and hasattr(head_last, "register_post_accumulate_grad_hook"):
+                self._hook = head_last.register_post_accumulate_grad_hook(self._launch_tail)
+            del trigger
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _launch_tail(self, _param=None):
+        if self._active() and self._tail_work is None and self.split:
+            self._tail_work = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def zero(self):
+        self._tail_work = None
         self.flat.zero_()
 
     def allreduce(self, async_op=False):
         """sum over ranks, then 1/world (mean gradient).  No-op without a process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._active():
             return None
-        world = dist.get_world_size()
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-        if async_op:
-            return work
-        self.flat.mul_(1.0 / world)
+        if self.split and self._tail_work is not None:     # tail already in flight (or done): only the head remains
+            dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM)
+            self._tail_work.wait()
+            self._tail_work = None
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / dist.get_world_size())
         return None
-
-    def finish(self, work):
-        if work is not None:
-            work.wait()
-            self.flat.mul_(1.0 / dist.get_world_size())
 
 
 def shard_episodes(n_global, rank, world):

@@ -68,12 +68,14 @@ def _ddp_worker(rank, world, port, q):
     torch.manual_seed(rank)                                  # different init per rank ...
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
     broadcast_parameters(net)                                # ... replicated from rank 0
-    bucket = FlatGradBucket(net, skip_prefixes=("1.bias",))  # one tensor left out, like cre.w_context/out
+    bucket = FlatGradBucket(net, skip_prefixes=("1.bias",), split_at="1.")  # one tensor left out; tail = layer 1 (overlapped)
+    assert bucket.split == 6 * 5 + 5 and bucket._hook is not None
     xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
     lo, hi = shard_episodes(8, rank, world)
     bucket.zero()
     net(xs[lo:hi]).square().sum().backward()
     skipped = net[1].bias.grad.clone()
+    assert bucket._tail_work is not None                     # the hook fired during backward: tail all-reduce in flight
     bucket.allreduce()
     q.put((rank, lo, hi, bucket.flat.clone(), net[0].weight.detach().clone(), skipped, bucket.numel))
     dist.barrier()
