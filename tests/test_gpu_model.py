@@ -246,3 +246,44 @@ def test_eval_driver_end_to_end():
     assert len(few["Liver"]) == 2 and all(0.0 <= d <= 1.0 for d in few["Liver"])
     assert sorted(ref["Liver"].keys()) == list(range(10))
     assert few["Liver"] == [r for r in ref["Liver"][9]]          # output == refinement[T-1]
+
+
+def test_two_way_extension_vs_composed_oracle():
+    """BASELINE config 5 shape class (2-way, fp32 here): no reference behaviour; oracle composed from the
+    reference's own pieces, incl. gradients of the well-conditioned CRE block and the align loss."""
+    from oracle import rpnet_oracle as O
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(66, 2, 64, "cpu", n_shots=1, n_ways=2)
+    P = O.seeded_params(requires_grad=True)
+    ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True)
+    ref_loss = ref["refinement"][1].square().mean() + ref["align_loss"]
+    ref_loss.backward()
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    out = net([[mv(s) for s in w] for w in si], [[mv(s) for s in w] for w in fg], [[mv(s) for s in w] for w in bg],
+              [mv(qi[0])], appr_query_labels=mv(appr))
+    assert out["output"].shape == (2, 3, 64, 64)
+    for i in range(2):
+        assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL
+    assert rel_err(out["align_loss"], ref["align_loss"]) < TOL
+    (out["refinement"][1].square().mean() + out["align_loss"]).backward()
+    for n in ("cre.q.0.weight", "cre.w_k.0.weight", "cre.q.1.bias"):
+        a, b = dict(net.named_parameters())[n].grad.double().cpu(), P[n].grad.double()
+        assert (a - b).norm() < 5e-3 * b.norm(), n
+
+
+def test_config3_full_size_properties():
+    """BASELINE configs[2]: 1-way 5-shot, 256x256, T=5, batch 16 — full-size forward + backward through
+    the multi-shot path: shapes, finiteness, BatchNorm update counts, prototype = mean over shots."""
+    cfg = load_cfg(5)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(4321, 16, 256, DEV, n_shots=5)
+    net = build(cfg, True)
+    out = net(si, fg, bg, qi, appr_query_labels=appr)
+    loss = total_loss(out, ql, 1.0)
+    loss.backward()
+    assert out["output"].shape == (16, 2, 256, 256) and torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    sd = net.state_dict()
+    assert int(sd["encoder.Conv1.conv.1.num_batches_tracked"]) == 2       # one support call (80 images) + one query call
+    assert int(sd["cre.w_k.1.num_batches_tracked"]) == 5 + 5               # one CRE call per shot + T query calls
+    torch.cuda.synchronize()
