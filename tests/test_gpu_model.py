@@ -287,3 +287,30 @@ def test_config3_full_size_properties():
     assert int(sd["encoder.Conv1.conv.1.num_batches_tracked"]) == 2       # one support call (80 images) + one query call
     assert int(sd["cre.w_k.1.num_batches_tracked"]) == 5 + 5               # one CRE call per shot + T query calls
     torch.cuda.synchronize()
+
+
+def test_odd_shapes_vs_oracle():
+    """Ragged everything: 96x96 images (24x24 feature maps: not powers of two -> the division paths of
+    the wgrad strips), batch 3 (statistic groups of 3 images, M tails in every tile variant), T=2."""
+    from oracle import rpnet_oracle as O
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(123, 3, 96, "cpu")
+    P = O.seeded_params(requires_grad=True)
+    ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True)
+    ref_loss = O.total_loss(ref, ql)
+    ref_loss.backward()
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    out = net([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], appr_query_labels=mv(appr))
+    loss = total_loss(out, mv(ql), 1.0)
+    loss.backward()
+    for i in range(2):
+        assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL
+    assert rel_err(loss, ref_loss) < TOL
+    for n, p in net.named_parameters():
+        if p.grad is None or P[n].grad.norm() < 1e-4:
+            continue
+        a, b = p.grad.double().cpu().norm().item(), P[n].grad.double().norm().item()
+        assert abs(a - b) < (1e-2 if n.startswith("encoder.") else 2e-3) * b, f"{n}: {a} vs {b}"
+    for k in ("encoder.Conv2.conv.4.running_var", "cre.w_q.1.running_mean"):
+        assert rel_err(net.state_dict()[k], P[k]) < 1e-4
