@@ -16,9 +16,6 @@
 // B as [8][BN][4].  Register-prefetch pipeline: global loads for step s+1 are issued before
 // the 16*WM*WN MFMAs of step s and written to LDS after them; >= 2 blocks per CU overlap one
 // block's staging with the other's matrix work.
-#include <stdlib.h>
-#include <string.h>
-
 #include "common.h"
 
 namespace rpnet {
@@ -318,14 +315,6 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
                   RPNET_ERR_SHAPE, "conv_fwd: a source tensor exceeds the 2 GiB buffer-descriptor range");
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
-    if (const char* ov = getenv("RPNET_IGEMM_TILE")) {  // tuning aid only
-        if (!strcmp(ov, "22")) return launch_igemm<2, 2>(d, M, Cin, Cout, s);
-        if (!strcmp(ov, "12")) return launch_igemm<1, 2>(d, M, Cin, Cout, s);
-        if (!strcmp(ov, "21")) return launch_igemm<2, 1>(d, M, Cin, Cout, s);
-        if (!strcmp(ov, "11")) return launch_igemm<1, 1>(d, M, Cin, Cout, s);
-        if (!strcmp(ov, "24")) return launch_igemm<2, 4>(d, M, Cin, Cout, s);
-        if (!strcmp(ov, "42")) return launch_igemm<4, 2>(d, M, Cin, Cout, s);
-    }
     const int best = choose_tile(d, M, Cout);
     switch (best) {
         case 0: return launch_igemm<2, 2>(d, M, Cin, Cout, s);

@@ -164,12 +164,10 @@ class ConvBnRelu(Function):
             ws2 = _ws(wb, y)
             call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
         else:
+            # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
-            d.y0 = None
-            d.Co0, d.Co1 = cout, 0
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             ws2 = _ws(wb, y)
-            d.y0 = ptr(dy)  # unused by wgrad; keeps the descriptor self-consistent
             call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
             need0 = ctx.needs_input_grad[0]
             need1 = x1 is not None and ctx.needs_input_grad[1]

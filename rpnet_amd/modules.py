@@ -294,12 +294,10 @@ class RP_Net(nn.Module):
 
         # ---- prototypes: constant across iterations, computed once (:288-300)
         fg_protos, bg_sum = [], 0
-        adj = {}
         for wa in range(n_ways):
             fg_w, bg_w = 0, 0
             for s in range(n_shots):
                 am, msum = RF.mask_adjoint(torch.stack([back[wa][s], fore[wa][s]], 0), h, w)
-                adj[wa, s] = (am, msum)
                 p = RF.MaskedPool.apply(supp_fts[wa][s], am, msum)          # [B,2,C]: bg, fg
                 bg_w, fg_w = bg_w + p[:, 0], fg_w + p[:, 1]
             fg_protos.append(fg_w / n_shots)

@@ -45,7 +45,6 @@ class FlatGradBucket:
         self._tail_work = None
         self._hook = None
         if self.split:   # the last head parameter in module order is the FIRST head gradient backward produces
-            trigger = [p for n, p in self.params if not n.startswith(split_at)]
             head_last = None
             o = 0
             for n, p in self.params:
@@ -54,7 +53,6 @@ class FlatGradBucket:
                 o += p.numel()
             if head_last is not None and hasattr(head_last, "register_post_accumulate_grad_hook"):
                 self._hook = head_last.register_post_accumulate_grad_hook(self._launch_tail)
-            del trigger
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
