@@ -191,6 +191,8 @@ def main():
     scaler = cfg["align_loss_scaler"]
 
     from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
+    import rpnet_amd.functional as RF
+    RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
     net = build_model(cfg, dev)
     broadcast_parameters(net)
     bucket = FlatGradBucket(net)

@@ -324,7 +324,7 @@ static void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_sp
 // (8 row groups x 32 lanes read 128-byte rows of every split) and writes it transposed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                             int ksplit, int taps, int Cin_g, int Cout, int cin_w,
-                                                            int off0, int split, int off1) {
+                                                            int off0, int split, int off1, int accumulate) {
     __shared__ float tile[32][33];
     const int t = threadIdx.x;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const int col = t >> 3, c = (t & 7) * 4 + jj;
-        if (ci0 + c < cin_w) dw[((size_t)(co0 + col) * cin_w + ci0 + c) * taps + tap] = tile[c][col];
+        if (ci0 + c < cin_w) {
+            float* o = dw + ((size_t)(co0 + col) * cin_w + ci0 + c) * taps + tap;
+            *o = accumulate ? *o + tile[c][col] : tile[c][col];
+        }
     }
 }
 
@@ -455,7 +458,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         int rc9 = check_launch("conv_wgrad9");
         if (rc9) return rc9;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
-                           Cout, cin_w, cin_off0, cin_split, cin_off1);
+                           Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
         return check_launch("wgrad_reduce");
     }
     int bm, bn, ks, sps;
@@ -477,7 +480,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, d->taps), dim3(256), 0, s, part, dw, ks, d->taps,
-                       Cin, Cout, cin_w, cin_off0, cin_split, cin_off1);
+                       Cin, Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
     return check_launch("wgrad_reduce");
 }
 

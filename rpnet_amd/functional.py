@@ -16,6 +16,32 @@ from .hip import ConvDesc, call, ptr, query
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# ---------------------------------------------------------------- async weight gradients
+# Opt-in (bench.py / train_rpnet.py): the weight gradient of a conv only needs dy and the saved
+# input, not the dgrad chain, so it is launched on a second HIP stream and accumulated straight
+# into the parameter's existing .grad buffer (the flat bucket) instead of being returned to
+# autograd; the backward pass's HBM-bound kernels then run beside MFMA work.  The two streams are
+# joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
+_ASYNC = {"on": False, "side": {}, "pending": set()}
+
+
+def set_async_wgrad(on=True):
+    _ASYNC["on"] = bool(on)
+
+
+def _side_stream(device):
+    s = _ASYNC["side"].get(device)
+    if s is None:
+        s = _ASYNC["side"][device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_streams():
+    """Make the current stream wait for every async weight-gradient launch issued so far."""
+    for dev in list(_ASYNC["pending"]):
+        torch.cuda.current_stream(dev).wait_stream(_ASYNC["side"][dev])
+    _ASYNC["pending"].clear()
+
 
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
@@ -167,8 +193,25 @@ class ConvBnRelu(Function):
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
-            ws2 = _ws(wb, y)
-            call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+            if _ASYNC["on"] and weight.grad is not None and weight.grad.is_contiguous():
+                dev = y.device
+                side, main = _side_stream(dev), torch.cuda.current_stream(dev)
+                side.wait_stream(main)                       # dy, x are ready on the main stream
+                d.accumulate = 1
+                with torch.cuda.stream(side):
+                    ws2 = _ws(wb, y)
+                    call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                         ptr(ws2), wb)
+                for tns in (x0, x1, in_scale, dy):           # keep their blocks alive until the side stream is done
+                    if tns is not None:
+                        tns.record_stream(side)
+                if not _ASYNC["pending"]:
+                    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+                _ASYNC["pending"].add(dev)
+                dw = None
+            else:
+                ws2 = _ws(wb, y)
+                call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
             need0 = ctx.needs_input_grad[0]
             need1 = x1 is not None and ctx.needs_input_grad[1]
             if need0 or need1:

@@ -59,6 +59,8 @@ class FlatGradBucket:
 
     def _launch_tail(self, _param=None):
         if self._active() and self._tail_work is None and self.split:
+            from .functional import join_side_streams
+            join_side_streams()      # async weight gradients of the tail must have landed in the bucket
             self._tail_work = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def zero(self):
@@ -69,6 +71,8 @@ class FlatGradBucket:
         """sum over ranks, then 1/world (mean gradient).  No-op without a process group."""
         if not self._active():
             return None
+        from .functional import join_side_streams
+        join_side_streams()
         if self.split and self._tail_work is not None:     # tail already in flight (or done): only the head remains
             dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM)
             self._tail_work.wait()

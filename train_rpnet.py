@@ -51,6 +51,8 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
     broadcast_parameters(net)
     net.train()
     bucket = FlatGradBucket(net)
+    import rpnet_amd.functional as RF
+    RF.set_async_wgrad(True)             # weight gradients on a second stream, straight into the bucket
     params = [p for _, p in bucket.params]
     opt = torch.optim.Adam(params, lr=lr if lr is not None else config["init_lr"], weight_decay=config["weight_decay"])
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=config["scheduler_step"])
