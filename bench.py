@@ -15,7 +15,10 @@ name-seeded random init (no dataset / checkpoint exists offline).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live: every C-ABI call of one extra
 step is bracketed by HIP events on the launch stream; the dominant kernel is the fp32-MFMA
-implicit-GEMM convolution (rpnet_conv_fwd: forward + dgrad launches).  `cpu_baseline` is
+implicit-GEMM convolution (rpnet_conv_fwd: forward + dgrad launches).  The timed steps run with
+the weight gradients on a second HIP stream (overlap on); the extra profiled step serialises the
+streams so that every launch owns the GPU and its duration is the kernel's own
+(RPNET_ASYNC_WGRAD=0 makes the timed steps serial too; profiles/ holds rocprofv3 stats of both).  `cpu_baseline` is
 the CPU oracle in as-written mode (= the reference's operator sequence) on the host cores.
 """
 import argparse
@@ -95,12 +98,15 @@ def profile_step(net, bucket, inp, scaler):
     hip.call = timed
     import rpnet_amd.functional as RF
     RF.call = timed
+    was_async = RF._ASYNC["on"]
+    RF.set_async_wgrad(False)   # per-kernel durations need each launch to own the GPU: streams serialised here
     try:
         step(net, bucket, inp, scaler)
         torch.cuda.synchronize()
     finally:
         hip.call = orig
         RF.call = orig
+        RF.set_async_wgrad(was_async)
     agg = {}
     for name, flops, nbytes, a, b in records:
         e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -253,7 +259,9 @@ def main():
                          "gflop_per_pair": round(gf_pair, 1),
                          "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
                                                sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
-                         "sum_kernel_ms_per_step": round(1e3 * kern_total, 2)},
+                         "sum_kernel_ms_per_step": round(1e3 * kern_total, 2),
+                         "note": "per-kernel figures from one extra step with the two HIP streams serialised; "
+                                 "value/ms_per_step measured with async weight gradients on"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters)
