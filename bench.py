@@ -54,12 +54,13 @@ def build_model(cfg, dev):
     return net
 
 
-def make_inputs(seed, B, size, dev):
+def make_inputs(seed, B, size, dev, n_shots=1):
     from rpnet_amd.utils.synth import make_episode
-    ep = make_episode(seed, B, size)
+    ep = make_episode(seed, B, size, n_shots=n_shots)
     t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
-    return ([[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], [[t(ep["support_bg"][0][0])]],
-            [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"]))
+    return ([[t(s) for s in ep["support_images"][0]]], [[t(s) for s in ep["support_fg"][0]]],
+            [[t(s) for s in ep["support_bg"][0]]], [t(ep["query_images"])], t(ep["query_labels"]),
+            t(ep["appr_query_labels"]))
 
 
 def step(net, bucket, inp, scaler):
@@ -173,6 +174,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="episodes (support/query pairs) per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5, help="T refinement iterations")
+    ap.add_argument("--shots", type=int, default=1, help="support shots (5 with --batch 16 = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -202,7 +204,7 @@ def main():
     net = build_model(cfg, dev)
     broadcast_parameters(net)
     bucket = FlatGradBucket(net)
-    inp = make_inputs(1234 + rank, args.batch, args.size, dev)   # resident in HBM before timing
+    inp = make_inputs(1234 + rank, args.batch, args.size, dev, args.shots)   # resident in HBM before timing
 
     def fence():
         torch.cuda.synchronize()
@@ -226,7 +228,7 @@ def main():
 
     pairs = world * args.batch * args.steps
     value = pairs / el
-    gf_pair = algorithmic_gf_per_pair(args.size, args.iters)
+    gf_pair = algorithmic_gf_per_pair(args.size, args.iters, args.shots)
 
     result = None
     # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
@@ -238,12 +240,12 @@ def main():
         achieved = conv[2] / conv[1] / 1e12
         kern_total = sum(v[1] for v in agg.values())
         result = {
-            "metric": "support/query pairs/sec (fwd+bwd, 1-shot 256x256, T=5)",
+            "metric": f"support/query pairs/sec (fwd+bwd, {args.shots}-shot {args.size}x{args.size}, T={args.iters})",
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"1-way 1-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
-                                   f"(BASELINE configs[{1 if world == 1 else 3}]), train mode, align loss on, "
+            "config": {"workload": f"1-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
+                                   f"(BASELINE configs[{(1 if world == 1 else 3) if args.shots == 1 else 2}]), train mode, align loss on, "
                                    "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
@@ -263,7 +265,7 @@ def main():
                          "note": "per-kernel figures from one extra step with the two HIP streams serialised; "
                                  "value/ms_per_step measured with async weight gradients on"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.shots == 1:
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     if world > 1:
