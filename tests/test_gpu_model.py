@@ -357,3 +357,20 @@ def test_async_weight_gradients_match():
     assert rel_err(grads[1], grads[0]) < 1e-5
     # second step on the same bucket: zero() really clears what the side stream accumulated
     assert float((grads[1] - grads[0]).abs().max()) < 1e-5 * float(grads[0].abs().max())
+
+
+def test_graphed_eval_matches_eager():
+    """hipGraph replay of the evaluation forward (batch 2, T = 10 like test_rpnet.py) is bit-identical to the
+    eager call, also after the static input buffers are refilled with a different batch."""
+    from rpnet_amd.graph import GraphedEval
+    cfg = load_cfg(10)
+    net = build(cfg, False)
+    graphed = GraphedEval(net)
+    for seed in (31, 32):
+        (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, 2, 128, DEV)
+        with torch.no_grad():
+            ref = net(si, fg, bg, qi, appr_query_labels=appr)["output"].clone()
+        out = graphed(si, fg, bg, qi, appr_query_labels=appr)
+        assert len(out["refinement"]) == 10
+        assert torch.equal(out["output"], ref)
+    assert len(graphed._graphs) == 1
