@@ -435,7 +435,10 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     const int Cin = d->C0 + d->C1, Cout = d->Co0 + d->Co1;
     RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
     RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
+    RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_wgrad: too many pixels");
     const int M = d->N * d->H * d->W;
+    RPNET_REQUIRE((size_t)M * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) && (size_t)M * Cout * 4 < (1UL << 31),
+                  RPNET_ERR_SHAPE, "conv_wgrad: an operand exceeds the 2 GiB buffer-descriptor range (split the batch)");
     hipStream_t s = (hipStream_t)stream;
     if (d->taps == 9 && d->dilation <= 1) {
         RPNET_REQUIRE(d->C1 == 0 || d->C0 % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to 64", d->C0);
