@@ -122,19 +122,21 @@ int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  *   rpnet_bn_stats   per (group, channel) batch mean / biased variance (fp64
  *                    accumulation) -> scale = gamma*invstd, shift = beta - mean*scale,
  *                    save mean & invstd; running_mean/var momentum update with the
- *                    unbiased variance, one update per group in group order.
+ *                    unbiased variance, one update per group in group order;
+ *                    num_batches_tracked (int64, may be NULL) += groups.
  *   rpnet_bn_relu    z = relu(y*scale + shift)
- *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups) and
+ *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups; accumulate != 0: added to what the
+ *                    pointers hold, i.e. straight into the parameters' gradient buffers) and
  *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)). */
 size_t rpnet_bn_workspace_bytes(int C, int groups);
 int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float momentum, float eps,
-                   float* scale, float* shift, float* mean, float* invstd,
+                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                   float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                    void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 /* finalize half of rpnet_bn_stats on partial sums produced by rpnet_conv_fwd (stats_partial) */
 int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, int C, int groups,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                 rpnet_stream_t stream);
 int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, int C,
@@ -143,7 +145,7 @@ int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float*
                   int groups, rpnet_stream_t stream);
 int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
                  const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
-                 int N, int HW, int C, int groups, void* workspace, size_t workspace_bytes,
+                 int N, int HW, int C, int groups, int accumulate, void* workspace, size_t workspace_bytes,
                  rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:

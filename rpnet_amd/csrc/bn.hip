@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 // one 64-lane wave per channel: lanes stride over the per-block partials, xor-shuffle sum
 __global__ __launch_bounds__(64) void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                  float* running_mean, float* running_var, float momentum, float eps,
-                                  float* scale, float* shift, float* mean, float* invstd) {
+                                  float* running_mean, float* running_var, long long* num_batches_tracked,
+                                  float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    if (num_batches_tracked && c == 0 && lane == 0) *num_batches_tracked += G;  // one "forward call" per group
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {  // sequential: one running-stat update per group, in call order
         double s = 0, q = 0;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 
 // coef[g][C][2] floats = (s1/R, s2/R); dgamma/dbeta summed over groups
 __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
-                                float* coef, float* dgamma, float* dbeta) {
+                                float* coef, float* dgamma, float* dbeta, int accumulate) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     for (int g = 0; g < G; ++g) {
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* __restrict__
         }
         tb += s1; tg += s2;
     }
-    if (lane == 0) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
+    if (lane == 0) {
+        if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
+        else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz, const float* __restrict__ y,
@@ -224,9 +228,9 @@ static int bn_check(const char* who, int N, int HW, int C, int groups) {
 }
 
 extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                              float* shift, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
-                              rpnet_stream_t stream) {
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                              void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && gamma && beta && scale && shift && mean && invstd && workspace, RPNET_ERR_ARG, "bn_stats: null pointer");
     if (int rc = bn_check("bn_stats", N, HW, C, groups)) return rc;
@@ -236,13 +240,14 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
     hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, s, (const double*)workspace, gm.nblk, R, C,
-                       groups, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+                       groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
+                       mean, invstd);
     return check_launch("bn_stats");
 }
 
 extern "C" int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, int C, int groups,
                                            const float* gamma, const float* beta, float* running_mean,
-                                           float* running_var, float momentum, float eps, float* scale, float* shift,
+                                           float* running_var, long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
                                            float* mean, float* invstd, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && nblk > 0, RPNET_ERR_ARG,
@@ -250,7 +255,7 @@ extern "C" int rpnet_bn_stats_from_partial(const double* partial, int nblk, int 
     RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "bn_stats_from_partial: N=%d groups=%d", N, groups);
     const long R = (long)(N / groups) * HW;
     hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
-                       beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+                       beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
     return check_launch("bn_stats_from_partial");
 }
 
@@ -277,7 +282,8 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
 
 extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
                             const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, int N, int HW,
-                            int C, int groups, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
+                            int C, int groups, int accumulate, void* workspace, size_t workspace_bytes,
+                            rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
     RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && dy && dgamma && dbeta && workspace, RPNET_ERR_ARG,
@@ -292,7 +298,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
                        R, C, gm);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(64), 0, s, (const double*)partial, gm.nblk, R, C, groups,
-                       coef, dgamma, dbeta);
+                       coef, dgamma, dbeta, accumulate);
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
                        (const float*)coef, dy, total4, C, group4);

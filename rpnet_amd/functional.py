@@ -26,7 +26,17 @@ _ASYNC = {"on": False, "side": {}, "pending": set()}
 
 
 def set_async_wgrad(on=True):
+    """Opt-in "bucket mode" of the backward pass: weight gradients are launched on a second HIP stream and
+    every parameter gradient of a conv+BN layer is accumulated by the producing kernel straight into the
+    existing `param.grad` (the flat bucket of rpnet_amd.parallel) instead of being handed to autograd's
+    AccumulateGrad (one torch add per parameter).  Parameter hooks then do not fire for those parameters;
+    a parameter that must keep its hook is tagged `_rpnet_autograd_grad = True`."""
     _ASYNC["on"] = bool(on)
+
+
+def _direct(p):
+    return (_ASYNC["on"] and p is not None and p.grad is not None and p.grad.is_contiguous()
+            and not getattr(p, "_rpnet_autograd_grad", False))
 
 
 def _side_stream(device):
@@ -151,19 +161,18 @@ class ConvBnRelu(Function):
             call("rpnet_conv_fwd", C.byref(d))
         if fused:
             call("rpnet_bn_stats_from_partial", ptr(part), fused, N, H * W, cout, groups, ptr(gamma), ptr(beta),
-                 ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
-                 ptr(stats[3]))
+                 ptr(running_mean), ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]),
+                 ptr(stats[2]), ptr(stats[3]))
         else:
             wsb = query("rpnet_bn_workspace_bytes", cout, groups)
             ws = _ws(wsb, x0)
             call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
-                 ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+                 ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
                  ptr(ws), wsb)
-        if nbt is not None:
-            nbt += groups
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), N, H * W, cout, groups)
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
+        ctx.bias, ctx.beta = bias, beta
         return z
 
     @staticmethod
@@ -180,9 +189,15 @@ class ConvBnRelu(Function):
         wsb = query("rpnet_bn_workspace_bytes", cout, groups)
         ws = _ws(wsb, y)
         dy = torch.empty_like(y)
-        dgamma, dbeta = _empty((cout,), y), _empty((cout,), y)
-        call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-             ptr(dy), ptr(dgamma), ptr(dbeta), N, H * W, cout, groups, ptr(ws), wsb)
+        beta, bias = ctx.beta, ctx.bias
+        if _direct(gamma) and _direct(beta):     # straight into the gradient bucket, no AccumulateGrad add
+            call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
+                 ptr(stats[3]), ptr(dy), ptr(gamma.grad), ptr(beta.grad), N, H * W, cout, groups, 1, ptr(ws), wsb)
+            dgamma = dbeta = None
+        else:
+            dgamma, dbeta = _empty((cout,), y), _empty((cout,), y)
+            call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
+                 ptr(stats[3]), ptr(dy), ptr(dgamma), ptr(dbeta), N, H * W, cout, groups, 0, ptr(ws), wsb)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:
@@ -193,7 +208,7 @@ class ConvBnRelu(Function):
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
-            if _ASYNC["on"] and weight.grad is not None and weight.grad.is_contiguous():
+            if _direct(weight):
                 dev = y.device
                 side, main = _side_stream(dev), torch.cuda.current_stream(dev)
                 side.wait_stream(main)                       # dy, x are ready on the main stream
@@ -235,7 +250,7 @@ class ConvBnRelu(Function):
                 dx0 = g0 if need0 else None
                 dx1 = g1 if need1 else None
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
-        db = torch.zeros_like(gamma)
+        db = None if _direct(bias) else torch.zeros_like(gamma)
         return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -30,17 +30,17 @@ _SIGS = {
     "rpnet_pack_conv_weight": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
-    "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
+    "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
     "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
-    "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
+    "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
     "rpnet_bn_relu": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
-    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
     "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
     "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

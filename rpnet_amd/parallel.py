@@ -52,6 +52,7 @@ class FlatGradBucket:
                     head_last = p
                 o += p.numel()
             if head_last is not None and hasattr(head_last, "register_post_accumulate_grad_hook"):
+                head_last._rpnet_autograd_grad = True    # keep this one on AccumulateGrad so that the hook fires
                 self._hook = head_last.register_post_accumulate_grad_hook(self._launch_tail)
 
     def _active(self):
