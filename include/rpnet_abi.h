@@ -54,6 +54,24 @@ const char* rpnet_last_error_string(void);
 int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int cin, int taps,
                            int cin_off0, int cin_split, int cin_off1, int cin_pad, rpnet_stream_t stream);
 
+/* ------------------------------------------------------- split-bf16 operands (fp32-accurate)
+ * The bf16 matrix pipe of gfx950 is 16x the fp32 one.  An fp32 value x is carried as NP bf16 planes
+ * x = h + m (+ l), h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (exact: 3 x 8 significand bits),
+ * and a product x*y as the partial products of the planes, accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16:
+ *   NP = 3: hh + hm + mh + hl + lh + mm   (dropped terms <= 2^-23 |x*y|: fp32 round-off level), 6 MFMAs
+ *   NP = 2: hh + hm + mh                  (dropped terms <= 2^-16 |x*y|), 3 MFMAs
+ * rpnet_split_bf16: x [rows][C] fp32 (optionally times a per-row factor s or 1-s: x*mask of
+ * net/rp_net.py:275,283) -> out [planes][rows][C] bf16.  C % 8 == 0.
+ * rpnet_pack_conv_weight_split: as rpnet_pack_conv_weight, into
+ *   wp [planes][taps][Cin_pad/32][Cout][32]   (k = input channel, contiguous per output channel)
+ *   wd [planes][taps][Cout/32][Cin_pad][32]   (dgrad: k = output channel, taps flipped); wd may be NULL.
+ * cin, cin_off0, cin_split, cin_off1 multiples of 8; cin_pad, cout multiples of 32. */
+int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
+                     rpnet_stream_t stream);
+int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
+                                 int cin_split, int cin_off1, int cin_pad, int planes, rpnet_stream_t stream);
+
 /* ------------------------------------------------------------- conv (implicit GEMM)
  * Replaces nn.Conv2d(k=3,s=1,p=1,bias=True) / nn.Conv2d(k=1) forward and its
  * autograd input-gradient (net/modules.py:47,50,67; net/rp_net.py:51,56,66), fp32 MFMA
@@ -90,6 +108,10 @@ typedef struct rpnet_conv_desc {
     double* stats_partial;             /* optional: per (M-tile half, channel) sum / sum-of-squares of the
                                           output, [groups * rpnet_conv_stats_blocks()][Cout][2] — the
                                           train-mode BatchNorm batch statistics fused into the epilogue */
+    int split_planes;                  /* 0: x0/x1/w are fp32 (v_mfma_f32_32x32x2_f32).  2 or 3: x0/x1/w point at
+                                          split-bf16 operands (rpnet_split_bf16 / rpnet_pack_conv_weight_split),
+                                          plane p of a source at +p*N*Hin*Win*C elements, of w at
+                                          +p*taps*Cin*Cout; in_scale must already be folded into the split */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);

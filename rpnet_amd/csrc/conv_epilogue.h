@@ -1,0 +1,74 @@
+// Epilogue shared by the implicit-GEMM convolution kernels (fp32-MFMA and split-bf16 variants):
+// the accumulators of a (32*WGM*WM) x (64*WN) block tile held by WGM x 2 waves, each wave WM x WN
+// MFMA tiles of 32x32 in the C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma once
+#include "common.h"
+
+namespace rpnet {
+
+template <int WM, int WN, int WGM = 2>
+__device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const int M, const int Cout,
+                                              const int HW, const int m0, const int n0, const int tm, const int wm,
+                                              const int wn, const int li, const int h) {
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
+    if (d.stats_partial) {
+        // train-mode BatchNorm statistics of y = acc + bias, fused: this wave's 32*WM rows of each of
+        // its columns -> one (sum, sum of squares) pair per column; the two lane halves hold the same
+        // columns.  Row blocks never straddle a statistic group (host-checked).
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * WN * 32 + j * 32 + li;
+            const float bv = d.bias ? d.bias[col] : 0.f;
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = row < M ? acc[i][j][r] + bv : 0.f;
+                    sm += v;
+                    sq += v * v;
+                }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (h == 0) {
+                double* o = d.stats_partial + ((size_t)(tm * WGM + wm) * Cout + col) * 2;
+                o[0] = (double)sm;
+                o[1] = (double)sq;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn * WN * 32 + j * 32 + li;
+        const float bv = d.bias ? d.bias[col] : 0.f;
+        float* dst; int Cd, cd;
+        if (col < d.Co0) { dst = d.y0; Cd = d.Co0; cd = col; } else { dst = d.y1; Cd = d.Co1; cd = col - d.Co0; }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (d.ep_scale) {
+                        const int g = row / per_group;
+                        v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];
+                    }
+                    if (d.ep_relu) v = fmaxf(v, 0.f);
+                    if (d.out_scale_mode) {
+                        float s = d.out_scale[row];
+                        if (d.out_scale_mode == 2) s = 1.f - s;
+                        v *= s;
+                    }
+                    float* p = dst + (size_t)row * Cd + cd;
+                    if (d.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rpnet

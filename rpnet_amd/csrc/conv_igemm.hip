@@ -16,7 +16,7 @@
 // B as [8][BN][4].  Register-prefetch pipeline: global loads for step s+1 are issued before
 // the 16*WM*WN MFMAs of step s and written to LDS after them; >= 2 blocks per CU overlap one
 // block's staging with the other's matrix work.
-#include "common.h"
+#include "conv_epilogue.h"
 
 namespace rpnet {
 
@@ -189,65 +189,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
-    if (d.stats_partial) {
-        // train-mode BatchNorm statistics of y = acc + bias, fused: this wave's 32*WM rows of each of
-        // its columns -> one (sum, sum of squares) pair per column; the two lane halves hold the same
-        // columns.  Row blocks never straddle a statistic group (host-checked).
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wn * WN * 32 + j * 32 + li;
-            const float bv = d.bias ? d.bias[col] : 0.f;
-            float sm = 0.f, sq = 0.f;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = row < M ? acc[i][j][r] + bv : 0.f;
-                    sm += v;
-                    sq += v * v;
-                }
-            sm += __shfl_xor(sm, 32, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            if (h == 0) {
-                double* o = d.stats_partial + ((size_t)(tm * 2 + wm) * Cout + col) * 2;
-                o[0] = (double)sm;
-                o[1] = (double)sq;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn * WN * 32 + j * 32 + li;
-        const float bv = d.bias ? d.bias[col] : 0.f;
-        float* dst; int Cd, cd;
-        if (col < d.Co0) { dst = d.y0; Cd = d.Co0; cd = col; } else { dst = d.y1; Cd = d.Co1; cd = col - d.Co0; }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (d.ep_scale) {
-                        const int g = row / per_group;
-                        v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];
-                    }
-                    if (d.ep_relu) v = fmaxf(v, 0.f);
-                    if (d.out_scale_mode) {
-                        float s = d.out_scale[row];
-                        if (d.out_scale_mode == 2) s = 1.f - s;
-                        v *= s;
-                    }
-                    float* p = dst + (size_t)row * Cd + cd;
-                    if (d.accumulate) v += *p;
-                    *p = v;
-                }
-            }
-        }
-    }
+    conv_epilogue<WM, WN>(d, acc, M, Cout, HW, m0, n0, tm, wm, wn, li, h);
 }
 
 template <int WM, int WN, bool INSCALE>
@@ -264,6 +206,11 @@ static int launch_igemm(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipS
     if (d->in_scale_mode) return launch_igemm_t<WM, WN, true>(d, M, Cin, Cout, s);
     return launch_igemm_t<WM, WN, false>(d, M, Cin, Cout, s);
 }
+
+// split-bf16 operand variant (conv_split.hip)
+int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout);
+int split_tile_rows(int variant, int* wave_rows);
+int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s);
 
 }  // namespace rpnet
 
@@ -290,11 +237,16 @@ static int choose_tile(const rpnet_conv_desc* d, int M, int Cout) {
 extern "C" int rpnet_conv_stats_blocks(const rpnet_conv_desc* d) {
     if (!d || d->groups < 1 || d->N % d->groups) return 0;
     const int M = d->N * d->H * d->W, Cout = d->Co0 + d->Co1;
-    const int best = choose_tile(d, M, Cout);
-    const int bm = (best == 0 || best == 1) ? 128 : 64;
+    int bm, wave_rows = 2;
+    if (d->split_planes) {
+        bm = rpnet::split_tile_rows(rpnet::choose_tile_split(d, M, Cout), &wave_rows);
+    } else {
+        const int best = choose_tile(d, M, Cout);
+        bm = (best == 0 || best == 1) ? 128 : 64;
+    }
     const long per_group = (long)(d->N / d->groups) * d->H * d->W;
     if (per_group % bm) return 0;
-    return (int)(per_group / bm) * 2;
+    return (int)(per_group / bm) * wave_rows;
 }
 
 extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
@@ -315,6 +267,11 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
                   RPNET_ERR_SHAPE, "conv_fwd: a source tensor exceeds the 2 GiB buffer-descriptor range");
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
+    if (d->split_planes) {
+        RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
+                      "conv_fwd: split operands take 2 or 3 planes and no in_scale (fold it into rpnet_split_bf16)");
+        return conv_fwd_split(d, M, Cin, Cout, s);
+    }
     const int best = choose_tile(d, M, Cout);
     switch (best) {
         case 0: return launch_igemm<2, 2>(d, M, Cin, Cout, s);

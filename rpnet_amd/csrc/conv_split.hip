@@ -1,0 +1,422 @@
+// fp32-accurate 3x3 convolution on the bf16 matrix pipe of gfx950 (v_mfma_f32_32x32x16_bf16,
+// 16x the rate of v_mfma_f32_32x32x2_f32).  Every fp32 operand is carried as NP bf16 planes
+//   x = h + m (+ l),   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (exact for NP = 3)
+// and x*y is the sum of the partial products of the planes that matter, accumulated in fp32:
+//   NP = 3:  hh + hm + mh + hl + lh + mm      6 MFMAs, dropped terms <= 2^-23 |x*y|  (fp32 round-off level)
+//   NP = 2:  hh + hm + mh                     3 MFMAs, dropped terms <= 2^-16 |x*y|
+// i.e. 16/6 = 2.7x (NP = 3) the fp32 matrix rate for the same algorithmic FLOPs.
+//
+// The split is done ONCE by whoever produces a tensor (rpnet_split_bf16; weights by
+// rpnet_pack_conv_weight_split), never inside the GEMM: the implicit-GEMM kernel below only moves
+// 16-byte groups of 8 bf16 from HBM/L2 to LDS to the MFMA operand registers.
+//
+// GEMM view as conv_igemm.hip (M = pixels, N = Cout, K = taps*Cin, 32 channels per K-step).
+// LDS image of a plane of a tile: [row][64 B = 4 k-groups of 8 bf16], the position of k-group g inside
+// the row XOR-swizzled with (row >> 2) & 3: both the 16-byte stores (4 lanes per row, rows consecutive)
+// and the b128 fragment reads (16-lane groups = 16 rows, one k-group) are bank-conflict free.
+// A fragment of the 32x32x16 MFMA = rows li, k-group 2*s + h (lane = li + 32 h): ONE ds_read_b128.
+#include "conv_epilogue.h"
+
+namespace rpnet {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+__device__ __forceinline__ unsigned bf16_bits(float x) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);   // v_cvt_pk_bf16_f32: round to nearest even
+}
+__device__ __forceinline__ float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
+
+// v[8] -> NP planes of 8 bf16 (16 bytes each)
+template <int NP>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
+    unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        hb[q] = bf16_bits(v[q]);
+        const float r1 = v[q] - bf16_val(hb[q]);
+        mb[q] = bf16_bits(r1);
+        if (NP > 2) lb[q] = bf16_bits(r1 - bf16_val(mb[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[0][q] = hb[2 * q] | (hb[2 * q + 1] << 16);
+        out[1][q] = mb[2 * q] | (mb[2 * q + 1] << 16);
+        if (NP > 2) out[NP - 1][q] = lb[2 * q] | (lb[2 * q + 1] << 16);
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const int mode, unsigned short* __restrict__ out,
+                                                          const size_t n8, const int C8, const size_t plane_elems) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (mode) {
+            float s = scale[i / C8];
+            if (mode == 2) s = 1.f - s;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= s;
+        }
+        u32x4 o[NP];
+        split8<NP>(v, o);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(out + p * plane_elems + i * 8) = o[p];
+    }
+}
+
+// w [Cout][cin_w][taps] -> wp [plane][tap][Cin_g/32][Cout][32] (+ wd [plane][tapflip][Cout/32][Cin_g][32])
+template <int NP>
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                                                 unsigned short* __restrict__ wd, int taps, int Cin_g,
+                                                                 int Cout, int cin_w, int off0, int split, int off1) {
+    __shared__ float tile[9][32][33];  // [tap][cin_l][cout_l]
+    const int t = threadIdx.x;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ncin = min(32, cin_w - ci0);
+    const int nel = ncin * taps;
+    for (int e = t; e < 32 * nel; e += 256) {
+        const int col = e / nel, r = e - col * nel;
+        const int c = r / taps, tap = r - c * taps;
+        tile[tap][c][col] = w[((size_t)(co0 + col) * cin_w + ci0) * taps + r];
+    }
+    __syncthreads();
+    const size_t plane = (size_t)taps * Cin_g * Cout;
+    // wp: item (tap, cout_l, g): 8 consecutive input channels of one output channel
+    for (int e = t; e < taps * 32 * 4; e += 256) {
+        const int g = e & 3, cl = (e >> 2) & 31, tap = e >> 7;
+        if (g * 8 < ncin) {
+            const int cin = ci0 + g * 8;
+            const int row = cin < split ? off0 + cin : off1 + (cin - split);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = tile[tap][g * 8 + q][cl];
+            u32x4 o[NP];
+            split8<NP>(v, o);
+            const size_t dst = (((size_t)tap * (Cin_g >> 5) + (row >> 5)) * Cout + co0 + cl) * 32 + (row & 31);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(wp + p * plane + dst) = o[p];
+        }
+    }
+    if (wd) {
+        // wd: GEMM K = cout, N = gathered cin: item (tap, cin_l, g): 8 consecutive output channels
+        for (int e = t; e < taps * 32 * 4; e += 256) {
+            const int g = e & 3, c = (e >> 2) & 31, tap = e >> 7;
+            if (c < ncin) {
+                const int cin = ci0 + c;
+                const int row = cin < split ? off0 + cin : off1 + (cin - split);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = tile[tap][c][g * 8 + q];
+                u32x4 o[NP];
+                split8<NP>(v, o);
+                const int tf = taps - 1 - tap;
+                const size_t dst = (((size_t)tf * (Cout >> 5) + (co0 >> 5)) * Cin_g + row) * 32 + g * 8;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(wd + p * plane + dst) = o[p];
+            }
+        }
+    }
+}
+
+// WGM x 2 waves; wave tile (32 WM) x (32 WN); block tile BM = 32 WGM WM, BN = 64 WN.
+// DB: two LDS stages and ONE barrier per K-step (tile s+1 is written into the other stage while tile s is
+// being multiplied, tile s+2 is in flight in registers); otherwise one stage and two barriers, relying on
+// co-resident blocks to cover the staging.
+template <int WGM, int WM, int WN, int NP, bool DB>
+__global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv_igemm_split_kernel(
+    const rpnet_conv_desc d, const int M, const int Cin, const int Cout, const int tiles_n, const int ntiles) {
+    constexpr int NT = WGM * 128;                 // threads
+    constexpr int BM = 32 * WGM * WM, BN = 64 * WN;
+    constexpr int RP = NT / 4;                    // tile rows staged per pass (4 lanes per 64-byte row)
+    constexpr int AJ = BM / RP, BJ = (BN + RP - 1) / RP;
+    constexpr bool B_PART = BN < RP;              // fewer B rows than one pass: only the first threads stage B
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;       // one plane of a tile
+    constexpr int STAGE = NP * (A_BYTES + B_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    const int tile = xcd_swizzle(blockIdx.x, ntiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int H = d.H, W = d.W, HW = H * W;
+    const int ups = d.upsample;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const int dil = d.dilation > 1 ? d.dilation : 1;
+
+    // staging: thread t moves k-group (t & 3) of tile rows (t >> 2) + RP j — four lanes cover the 64
+    // contiguous bytes of one row of one plane
+    const int srow = t >> 2, skg = t & 3;
+    int rn[AJ], ry[AJ], rx[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + srow + RP * j;
+        if (m < M) {
+            const int n = m / HW, rem = m - n * HW;
+            rn[j] = n;
+            ry[j] = rem / W;
+            rx[j] = rem - ry[j] * W;
+        } else {
+            rn[j] = -1; ry[j] = 0; rx[j] = 0;
+        }
+    }
+    const int kchunks = Cin >> 5;
+    const int nsteps = d.taps * kchunks;
+    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    int l_tap = 0, l_c0 = rot << 5, l_kc = 0;
+
+    const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
+    const size_t planew = (size_t)d.taps * Cin * Cout;
+    const unsigned short* x0 = reinterpret_cast<const unsigned short*>(d.x0);
+    const unsigned short* x1 = reinterpret_cast<const unsigned short*>(d.x1 ? d.x1 : d.x0);
+    const unsigned short* wq = reinterpret_cast<const unsigned short*>(d.w);
+    __amdgpu_buffer_rsrc_t rs0[NP], rs1[NP], rsw[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        rs0[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0 + p * plane0), (short)0,
+                                                   (int)(plane0 * 2), 0x00020000);
+        rs1[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x1 + p * (d.x1 ? plane1 : plane0)), (short)0,
+                                                   (int)((d.x1 ? plane1 : plane0) * 2), 0x00020000);
+        rsw[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq + p * planew), (short)0,
+                                                   (int)(planew * 2), 0x00020000);
+    }
+    int roff[AJ];
+    auto tap_setup = [&](int tap) {
+        int ky = 0, kx = 0;
+        if (d.taps == 9) { ky = (tap / 3 - 1) * dil; kx = (tap - (tap / 3) * 3 - 1) * dil; }
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int iy = ry[j] + ky, ix = rx[j] + kx;
+            const bool inb = rn[j] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            roff[j] = inb ? (rn[j] * Hs + (iy >> ups)) * Ws + (ix >> ups) : -1;
+        }
+    };
+    tap_setup(0);
+    const bool stage_b = !B_PART || srow < BN;
+    int wvoff[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) wvoff[j] = stage_b ? (srow + RP * j) * 64 + skg * 16 : -1;   // -1: out of range, zeros
+
+    u32x4 ra[NP][AJ], rb[NP][BJ];
+    auto load_tile = [&]() {
+        const bool first = l_c0 < d.C0;
+        const int Cs = first ? d.C0 : d.C1;
+        const int cc = first ? l_c0 : l_c0 - d.C0;
+        const int soff = cc * 2;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int voff = roff[j] * (Cs * 2) + skg * 16;   // roff == -1 -> beyond num_records -> zeros
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                ra[p][j] = first ? __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0[p], voff, soff, 0))
+                                 : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1[p], voff, soff, 0));
+        }
+        const int wsoff = ((l_tap * kchunks + (l_c0 >> 5)) * Cout + n0) * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                rb[p][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw[p], wvoff[j], wsoff, 0));
+        l_c0 += 32;
+        if (l_c0 == Cin) l_c0 = 0;
+        if (++l_kc == kchunks) {
+            l_kc = 0;
+            if (++l_tap < d.taps) tap_setup(l_tap);
+        }
+    };
+    // RP j rows further: same swizzle, (RP j >> 2) & 3 == 0
+    const int sdst = srow * 64 + 16 * (skg ^ ((srow >> 2) & 3));
+    auto store_tile = [&](unsigned char* st) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+                *reinterpret_cast<u32x4*>(st + p * A_BYTES + j * (RP * 64) + sdst) = ra[p][j];
+            if (stage_b) {
+#pragma unroll
+                for (int j = 0; j < BJ; ++j)
+                    *reinterpret_cast<u32x4*>(st + NP * A_BYTES + p * B_BYTES + j * (RP * 64) + sdst) = rb[p][j];
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int a_row = (wm * WM * 32 + li) * 64, b_row = (wn * WN * 32 + li) * 64;
+    auto mma_slice = [&](const unsigned char* st, int s) {
+        const int koff = 16 * ((2 * s + h) ^ sw);
+        bf16x8 af[NP][WM], bfr[NP][WN];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                af[p][i] = *reinterpret_cast<const bf16x8*>(st + p * A_BYTES + a_row + i * 2048 + koff);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bfr[p][j] = *reinterpret_cast<const bf16x8*>(st + NP * A_BYTES + p * B_BYTES + b_row + j * 2048 + koff);
+        }
+        // smallest partial products first
+        constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+        for (int q = 0; q < NPROD; ++q) {
+            const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (DB) {
+        load_tile();
+        store_tile(smem);
+        if (nsteps > 1) load_tile();
+        __syncthreads();
+        for (int ks = 0; ks < nsteps; ++ks) {
+            unsigned char* cur = smem + (ks & 1) * STAGE;
+            unsigned char* nxt = smem + ((ks + 1) & 1) * STAGE;
+            if (ks + 1 < nsteps) {
+                store_tile(nxt);                       // tile ks+1 (fetched during step ks-1)
+                if (ks + 2 < nsteps) load_tile();      // tile ks+2: a whole K-step to land
+            }
+            mma_slice(cur, 0);
+            mma_slice(cur, 1);
+            __syncthreads();
+        }
+    } else {
+        load_tile();
+        store_tile(smem);
+        __syncthreads();
+        for (int ks = 0; ks < nsteps; ++ks) {
+            const bool more = ks + 1 < nsteps;
+            if (more) load_tile();
+            mma_slice(smem, 0);
+            mma_slice(smem, 1);
+            __syncthreads();
+            if (more) store_tile(smem);
+            __syncthreads();
+        }
+    }
+    conv_epilogue<WM, WN, WGM>(d, acc, M, Cout, HW, m0, n0, tm, wm, wn, li, h);
+}
+
+// tile variants: {WGM, WM, WN, double-buffered}
+struct SplitVariant { int wgm, wm, wn, db, slots; };
+static const SplitVariant kSplitVariants[] = {
+    {2, 2, 2, 0, 768},    // 0: 128 x 128, 4 waves, 3 blocks per CU
+    {2, 2, 1, 0, 1024},   // 1: 128 x 64
+    {2, 1, 2, 0, 1024},   // 2:  64 x 128
+    {2, 1, 1, 0, 1536},   // 3:  64 x 64
+    {4, 2, 2, 1, 256},    // 4: 256 x 128, 8 waves, two LDS stages, 1 block per CU
+    {4, 2, 2, 0, 256},    // 5: 256 x 128, 8 waves, one stage
+    {2, 2, 2, 1, 256},    // 6: 128 x 128 two stages
+};
+constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
+
+template <int WGM, int WM, int WN, bool DB>
+static int launch_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+    constexpr int BM = 32 * WGM * WM, BN = 64 * WN;
+    const int tiles_m = cdiv(M, BM), tiles_n = Cout / BN;
+    const int ntiles = tiles_m * tiles_n;
+    if (d->split_planes == 3)
+        hipLaunchKernelGGL((conv_igemm_split_kernel<WGM, WM, WN, 3, DB>), dim3(ntiles), dim3(WGM * 128), 0, s, *d, M, Cin,
+                           Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_kernel<WGM, WM, WN, 2, DB>), dim3(ntiles), dim3(WGM * 128), 0, s, *d, M, Cin,
+                           Cout, tiles_n, ntiles);
+    return check_launch("conv_igemm_split");
+}
+
+// same rule as conv_igemm.hip: fewest idle block slots
+int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
+    const char* e = getenv("RPNET_SPLIT_TILE");   // tuning override (tools/bench_conv_split.py)
+    const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
+    if (e) {
+        const int v = atoi(e);
+        if (v >= 0 && v < kNumSplitVariants && (kSplitVariants[v].wn == 1 || n128)) return v;
+    }
+    int best = -1;
+    double best_fill = -1.0;
+    for (int c = 0; c < 4; ++c) {
+        const SplitVariant& v = kSplitVariants[c];
+        if (v.wn == 2 && !n128) continue;
+        const long tiles = (long)cdiv(M, 32 * v.wgm * v.wm) * (Cout / (64 * v.wn));
+        const long waves = (tiles + v.slots - 1) / v.slots;
+        const double fill = (double)tiles / (double)(waves * v.slots);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = c; }
+    }
+    return best;
+}
+
+int split_tile_rows(int variant, int* wave_rows) {
+    const SplitVariant& v = kSplitVariants[variant];
+    *wave_rows = v.wgm;
+    return 32 * v.wgm * v.wm;
+}
+
+int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+    switch (choose_tile_split(d, M, Cout)) {
+        case 0: return launch_split<2, 2, 2, false>(d, M, Cin, Cout, s);
+        case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);
+        case 2: return launch_split<2, 1, 2, false>(d, M, Cin, Cout, s);
+        case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
+        case 4: return launch_split<4, 2, 2, true>(d, M, Cin, Cout, s);
+        case 5: return launch_split<4, 2, 2, false>(d, M, Cin, Cout, s);
+        default: return launch_split<2, 2, 2, true>(d, M, Cin, Cout, s);
+    }
+}
+
+}  // namespace rpnet
+
+extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C,
+                                int planes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && out && (scale_mode == 0 || scale), RPNET_ERR_ARG, "split_bf16: null pointer");
+    RPNET_REQUIRE(C > 0 && C % 8 == 0 && (planes == 2 || planes == 3) && scale_mode >= 0 && scale_mode <= 2, RPNET_ERR_SHAPE,
+                  "split_bf16: C=%d planes=%d mode=%d", C, planes, scale_mode);
+    if (rows == 0) return RPNET_OK;
+    const size_t n8 = rows * (size_t)(C / 8);
+    const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
+    if (planes == 3)
+        hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    else
+        hipLaunchKernelGGL(split_bf16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    return check_launch("split_bf16");
+}
+
+extern "C" int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
+                                            int cin_split, int cin_off1, int cin_pad, int planes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(w && wp, RPNET_ERR_ARG, "pack_conv_weight_split: null pointer");
+    RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 32 == 0 && (taps == 9 || taps == 1) && (planes == 2 || planes == 3),
+                  RPNET_ERR_SHAPE, "pack_conv_weight_split: cout %d cin_pad %d taps %d planes %d", cout, cin_pad, taps, planes);
+    RPNET_REQUIRE(cin % 8 == 0 && cin_off0 % 8 == 0 && cin_split % 8 == 0 && cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
+                  "pack_conv_weight_split: channel counts / offsets must be multiples of 8");
+    if (planes == 3)
+        hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
+                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1);
+    else
+        hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
+                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1);
+    return check_launch("pack_conv_weight_split");
+}

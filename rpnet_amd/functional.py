@@ -5,6 +5,7 @@ reference (images, masks, logits) keep their NCHW layout.  Every Function calls
 librpnet_hip.so through rpnet_amd.hip — there is no torch-operator fallback.
 """
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -23,6 +24,20 @@ BN_MOMENTUM = 0.1
 # autograd; the backward pass's HBM-bound kernels then run beside MFMA work.  The two streams are
 # joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
 _ASYNC = {"on": False, "side": {}, "pending": set()}
+
+# Arithmetic of the 3x3 convolutions (forward, dgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
+# "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
+# v_mfma_f32_32x32x16_bf16 partial products into fp32 accumulators (dropped terms <= 2^-23 |x*y|: fp32
+# round-off level, 16/6 of the fp32 matrix rate); "bf16x2" = two planes, three products (2^-16).
+_MATH = {"planes": {"f32": 0, "bf16x3": 3, "bf16x2": 2}[os.environ.get("RPNET_CONV_MATH", "f32")]}
+
+
+def set_conv_math(mode):
+    _MATH["planes"] = {"f32": 0, "bf16x3": 3, "bf16x2": 2}[mode]
+
+
+def conv_math():
+    return {0: "f32", 3: "bf16x3", 2: "bf16x2"}[_MATH["planes"]]
 
 
 def set_async_wgrad(on=True):
@@ -61,6 +76,36 @@ def _ws(nbytes, like):
     return torch.empty((max(int(nbytes), 16) + 7) // 8, device=like.device, dtype=torch.float64)
 
 
+def split_bf16(x, planes, scale=None, mode=0):
+    """x [..., C] fp32 (optionally * scale or * (1 - scale) per row) -> [planes, ..., C] bf16 planes with
+    x = sum of the planes (rpnet_split_bf16)."""
+    hip.require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty((planes,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16)
+    c = x.shape[-1]
+    call("rpnet_split_bf16", ptr(x), ptr(scale), mode if scale is not None else 0, ptr(out), x.numel() // c, c, planes)
+    return out
+
+
+def _split_operand(x, planes, scale=None, mode=0):
+    """Split planes of a conv operand; an unscaled tensor remembers its split (skip connections and the
+    backward pass ask for it again)."""
+    if scale is not None and mode:
+        return split_bf16(x, planes, scale, mode)
+    cached = getattr(x, "_rp_split", None)
+    if cached is not None and cached.shape[0] == planes and cached.shape[1:] == x.shape:
+        return cached
+    xs = split_bf16(x, planes)
+    x._rp_split = xs
+    return xs
+
+
+def _use_split(pw, x0, x1):
+    """3x3 convolutions whose channel counts fit the split pack run on the bf16 pipe when enabled."""
+    return (_MATH["planes"] and pw is not None and pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0
+            and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0))
+
+
 # ------------------------------------------------------------------ weight packing
 class PackedWeight:
     """Packed copies of one nn.Conv2d weight (see rpnet_pack_conv_weight)."""
@@ -80,6 +125,20 @@ class PackedWeight:
         self.wd = mk(self.taps * self.cin_pad * cout, device=weight.device, dtype=torch.float32) if cin >= 32 else None
         call("rpnet_pack_conv_weight", ptr(weight), ptr(self.wp), ptr(self.wd), cout, cin, self.taps, self.off0,
              self.split, self.off1, self.cin_pad)
+        self.wps = self.wds = None
+        self._weight = weight
+
+    def split_packs(self, planes):
+        """bf16 split packs of the same weight (rpnet_pack_conv_weight_split), made on first use."""
+        if self.wps is None or self.wps.shape[0] != planes:
+            n = self.taps * self.cin_pad * self.cout
+            mk = torch.zeros if self.cin_pad != self.cin else torch.empty
+            w = self._weight
+            self.wps = mk((planes, n), device=w.device, dtype=torch.bfloat16)
+            self.wds = mk((planes, n), device=w.device, dtype=torch.bfloat16)
+            call("rpnet_pack_conv_weight_split", ptr(w), ptr(self.wps), ptr(self.wds), self.cout, self.cin, self.taps,
+                 self.off0, self.split, self.off1, self.cin_pad, planes)
+        return self.wps, self.wds
 
 
 class WeightCache:
@@ -142,6 +201,12 @@ class ConvBnRelu(Function):
                  ptr(shift), cout)
             if first:
                 call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout)
+            elif _use_split(pw, x0, x1):
+                np_ = _MATH["planes"]
+                d = _desc(_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_),
+                          pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
+                d.split_planes = np_
+                call("rpnet_conv_fwd", C.byref(d))
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                 call("rpnet_conv_fwd", C.byref(d))
@@ -153,7 +218,13 @@ class ConvBnRelu(Function):
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
-            d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample, groups)
+            if _use_split(pw, x0, x1):
+                np_ = _MATH["planes"]
+                d = _desc(_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_),
+                          pw.split_packs(np_)[0], bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
+                d.split_planes = np_
+            else:
+                d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample, groups)
             fused = query("rpnet_conv_stats_blocks", C.byref(d))
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
@@ -235,8 +306,14 @@ class ConvBnRelu(Function):
                 g1 = _empty((N, H, W, c1), y) if x1 is not None else None
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
                 need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
-                dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
-                           out_scale=None if need_s else in_scale, out_mode=in_mode)
+                if _use_split(pw, x0, x1) and cout % 32 == 0:
+                    np_ = _MATH["planes"]
+                    dd = _desc(_split_operand(dy, np_), None, pw.split_packs(np_)[1], None, None, 0, g0, g1, N, H, W,
+                               pw.taps, 0, out_scale=None if need_s else in_scale, out_mode=in_mode)
+                    dd.split_planes = np_
+                else:
+                    dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
+                               out_scale=None if need_s else in_scale, out_mode=in_mode)
                 call("rpnet_conv_fwd", C.byref(dd))
                 if need_s:   # d(x*f(s)) -> dx = g*f(s), ds = +-<g, x>
                     gx, dscale = torch.empty_like(g0), torch.empty_like(in_scale)

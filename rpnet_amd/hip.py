@@ -21,13 +21,15 @@ class ConvDesc(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("C0", ci), ("C1", ci), ("w", vp), ("bias", vp), ("in_scale", vp),
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
-                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp)]
+                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci)]
 
 
 _SIGS = {
     "rpnet_version": (ci, []),
     "rpnet_last_error_string": (C.c_char_p, []),
     "rpnet_pack_conv_weight": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_split_bf16": (ci, [vp, vp, ci, vp, cs, ci, ci, vp]),
+    "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),

@@ -1,0 +1,67 @@
+"""Accuracy and speed of the split-bf16 implicit GEMM (conv_split.hip) against the fp32-MFMA kernel.
+Accuracy: max |err| / max |ref| against an fp64 CPU convolution on a small shape; speed: TFLOP/s
+(algorithmic fp32 FLOPs) on the layer shapes of the 256x256, batch-8 step."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from rpnet_amd.functional import PackedWeight, _desc, split_bf16
+from rpnet_amd.hip import call
+
+dev = "cuda:0"
+
+
+def conv(x, pw, co, planes, xs=None):
+    N, H, W, ci = x.shape
+    y = torch.empty(N, H, W, co, device=dev)
+    if planes:
+        wps, _ = pw.split_packs(planes)
+        xs = split_bf16(x, planes) if xs is None else xs
+        d = _desc(xs[0], None, wps, None, None, 0, y, None, N, H, W, 9, 0)
+        d.split_planes = planes
+    else:
+        d = _desc(x, None, pw.wp, None, None, 0, y, None, N, H, W, 9, 0)
+    call("rpnet_conv_fwd", C.byref(d))
+    return y, d
+
+
+torch.manual_seed(0)
+for (N, H, W, ci, co) in [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]:
+    x = torch.randn(N, H, W, ci, device=dev)
+    w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    pw = PackedWeight(w)
+    for planes in (0, 3, 2):
+        y, _ = conv(x, pw, co, planes)
+        err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"{N}x{H}x{W} {ci}->{co} planes={planes}: max err / max|ref| = {err:.3e}", flush=True)
+    xs = split_bf16(x, 3)
+    print("split exact:", (xs.float().sum(0) - x).abs().max().item())
+
+SHAPES = [(16, 256, 256, 64, 64), (16, 128, 128, 128, 128), (16, 64, 64, 256, 256), (16, 32, 32, 512, 512),
+          (16, 16, 16, 1024, 1024), (16, 32, 32, 1024, 512), (8, 64, 64, 256, 256)]
+for (N, H, W, ci, co) in SHAPES:
+    x = torch.randn(N, H, W, ci, device=dev)
+    w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    pw = PackedWeight(w)
+    fl = 2.0 * N * H * W * ci * co * 9
+    line = f"M={N*H*W:8d} {ci:4d}->{co:4d}"
+    for planes in (0, 3, 2):
+        xs = split_bf16(x, planes) if planes else None
+        _, d = conv(x, pw, co, planes, xs)
+        for _ in range(3):
+            call("rpnet_conv_fwd", C.byref(d))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            call("rpnet_conv_fwd", C.byref(d))
+        b.record(); torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 20
+        line += f"  p{planes} {t:6.3f} ms {fl/t/1e9:6.1f} TF"
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        split_bf16(x, 3)
+    b.record(); torch.cuda.synchronize()
+    line += f"  split3 {a.elapsed_time(b)/10:6.3f} ms"
+    print(line, flush=True)
