@@ -307,7 +307,7 @@ static int ilog2_exact(int v) {
 // split-K plan of the nine-tap kernel: tiles * ksplit = 512 blocks (two resident blocks on each of
 // the 256 CUs, one full wave of the machine) whenever the K extent allows >= 8 steps per block;
 // the partial buffer is then 512 * 9 * 64 * 64 * 4 B = 75 MB whatever the layer.
-static void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
+void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
     const int tiles = (Cin / 64) * (Cout / 64);
     const int total_steps = (M + 31) / 32;
     long ks = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
@@ -413,6 +413,10 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
     *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
 }
 
+// split-bf16 operands (conv_wgrad_split.hip)
+int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
+                      hipStream_t s);
+
 }  // namespace rpnet
 
 extern "C" size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps) {
@@ -434,6 +438,8 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     RPNET_REQUIRE(d && d->x0 && dy && dw && workspace, RPNET_ERR_ARG, "conv_wgrad: null pointer");
     const int Cin = d->C0 + d->C1, Cout = d->Co0 + d->Co1;
     RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
+    RPNET_REQUIRE(!d->split_planes || (d->taps == 9 && d->dilation <= 1), RPNET_ERR_ARG,
+                  "conv_wgrad: split operands are implemented for dense 3x3 taps only");
     RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_wgrad: too many pixels");
     const int M = d->N * d->H * d->W;
@@ -449,6 +455,14 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;
         const int lw = ilog2_exact(d->W), lh = ilog2_exact(d->H);
         float* part9 = (float*)workspace;
+        if (d->split_planes) {   // x0/x1 and dy are split-bf16 planes
+            RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
+                          "conv_wgrad: split operands take 2 or 3 planes and no in_scale");
+            if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
+                               Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
+            return check_launch("wgrad_reduce");
+        }
 #define RPNET_W9(P2, IS, LW, LH)                                                                                   \
     hipLaunchKernelGGL((conv_wgrad9_kernel<P2, IS>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dy, part9, M, Cin, Cout, \
                        tiles9, tiles_n9, ks9, sps9, LW, LH)

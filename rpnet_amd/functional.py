@@ -214,14 +214,14 @@ class ConvBnRelu(Function):
             return z
         y = _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
-        fused = 0
+        fused, xs = 0, None
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
             if _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
-                d = _desc(_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_),
-                          pw.split_packs(np_)[0], bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
+                xs = (_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_))
+                d = _desc(xs[0], xs[1], pw.split_packs(np_)[0], bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
                 d.split_planes = np_
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample, groups)
@@ -243,7 +243,7 @@ class ConvBnRelu(Function):
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), N, H * W, cout, groups)
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
-        ctx.bias, ctx.beta = bias, beta
+        ctx.bias, ctx.beta, ctx.xs = bias, beta, xs
         return z
 
     @staticmethod
@@ -277,7 +277,14 @@ class ConvBnRelu(Function):
             call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
         else:
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
-            d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
+            dyp = dy
+            if ctx.xs is not None and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0:
+                np_ = ctx.xs[0].shape[0]        # both wgrad operands as split planes (the x*mask factor is in xs)
+                dyp = _split_operand(dy, np_)
+                d = _desc(ctx.xs[0], ctx.xs[1], pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, upsample)
+                d.split_planes = np_
+            else:
+                d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             if _direct(weight):
                 dev = y.device
@@ -286,9 +293,9 @@ class ConvBnRelu(Function):
                 d.accumulate = 1
                 with torch.cuda.stream(side):
                     ws2 = _ws(wb, y)
-                    call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                    call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                          ptr(ws2), wb)
-                for tns in (x0, x1, in_scale, dy):           # keep their blocks alive until the side stream is done
+                for tns in (x0, x1, in_scale, dy, dyp) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
                     if tns is not None:
                         tns.record_stream(side)
                 if not _ASYNC["pending"]:
@@ -297,7 +304,7 @@ class ConvBnRelu(Function):
                 dw = None
             else:
                 ws2 = _ws(wb, y)
-                call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
             need0 = ctx.needs_input_grad[0]
             need1 = x1 is not None and ctx.needs_input_grad[1]
             if need0 or need1:

@@ -65,3 +65,59 @@ for (N, H, W, ci, co) in SHAPES:
     b.record(); torch.cuda.synchronize()
     line += f"  split3 {a.elapsed_time(b)/10:6.3f} ms"
     print(line, flush=True)
+
+# ---- weight gradient: accuracy (fp64 CPU reference) and speed
+from rpnet_amd.functional import _ws
+from rpnet_amd.hip import ptr, query
+
+
+def wgrad(x, dy, pw, planes):
+    N, H, W, ci = x.shape
+    co = dy.shape[-1]
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, ci, co, 9)
+    ws = _ws(wb, x)
+    if planes:
+        xs, dys = split_bf16(x, planes), split_bf16(dy, planes)
+        d = _desc(xs[0], None, pw.wp, None, None, 0, dy, None, N, H, W, 9, 0)
+        d.split_planes = planes
+        args = (C.byref(d), ptr(dys), ptr(dw), ci, 0, ci, ci, ptr(ws), wb)
+        keep = (xs, dys)
+    else:
+        d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, 9, 0)
+        args = (C.byref(d), ptr(dy), ptr(dw), ci, 0, ci, ci, ptr(ws), wb)
+        keep = ()
+    call("rpnet_conv_wgrad", *args)
+    return dw, args, (d, ws, keep)
+
+
+for (N, H, W, ci, co) in [(2, 32, 32, 64, 128), (3, 8, 8, 128, 64), (2, 12, 20, 64, 64)]:
+    x = torch.randn(N, H, W, ci, device=dev)
+    dy = torch.randn(N, H, W, co, device=dev)
+    w0 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w0, padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = w0.grad
+    pw = PackedWeight(torch.zeros(co, ci, 3, 3, device=dev))
+    for planes in (0, 3, 2):
+        dw, _, _k = wgrad(x, dy, pw, planes)
+        err = (dw.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"wgrad {N}x{H}x{W} {ci}->{co} planes={planes}: max err / max|ref| = {err:.3e}", flush=True)
+
+for (N, H, W, ci, co) in SHAPES:
+    x = torch.randn(N, H, W, ci, device=dev)
+    dy = torch.randn(N, H, W, co, device=dev)
+    pw = PackedWeight(torch.zeros(co, ci, 3, 3, device=dev))
+    fl = 2.0 * N * H * W * ci * co * 9
+    line = f"wgrad M={N*H*W:8d} {ci:4d}->{co:4d}"
+    for planes in (0, 3, 2):
+        _, args, _k = wgrad(x, dy, pw, planes)
+        for _ in range(3):
+            call("rpnet_conv_wgrad", *args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            call("rpnet_conv_wgrad", *args)
+        b.record(); torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 20
+        line += f"  p{planes} {t:6.3f} ms {fl/t/1e9:6.1f} TF"
+    print(line, flush=True)
