@@ -147,10 +147,12 @@ int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  *                    save mean & invstd; running_mean/var momentum update with the
  *                    unbiased variance, one update per group in group order;
  *                    num_batches_tracked (int64, may be NULL) += groups.
- *   rpnet_bn_relu    z = relu(y*scale + shift)
+ *   rpnet_bn_relu    z = relu(y*scale + shift); z_split (may be NULL): also the split-bf16 planes of z
+ *                    ([planes][N*HW][C], the operand format of the next convolution, see rpnet_split_bf16)
  *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups; accumulate != 0: added to what the
  *                    pointers hold, i.e. straight into the parameters' gradient buffers) and
- *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)). */
+ *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)), in fp32 (dy, may be
+ *                    NULL when dy_split is given) and / or as split-bf16 planes (dy_split, may be NULL). */
 size_t rpnet_bn_workspace_bytes(int C, int groups);
 int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, long long* num_batches_tracked,
@@ -164,10 +166,10 @@ int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, 
 int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, int C,
                          rpnet_stream_t stream);
-int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, int N, int HW, int C,
-                  int groups, rpnet_stream_t stream);
+int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
+                  int N, int HW, int C, int groups, rpnet_stream_t stream);
 int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
-                 const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
+                 const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* dgamma, float* dbeta,
                  int N, int HW, int C, int groups, int accumulate, void* workspace, size_t workspace_bytes,
                  rpnet_stream_t stream);
 

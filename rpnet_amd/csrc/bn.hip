@@ -3,6 +3,7 @@
 // Replaces nn.BatchNorm2d + nn.ReLU(inplace) of net/modules.py:48-49,51-52,68-69 and
 // net/rp_net.py:52-53,57-58,67-68 and their autograd.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace rpnet {
 
@@ -115,6 +116,34 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ 
     }
 }
 
+// same, 8 channels per thread, plus the split-bf16 planes of z (the operand format of the next convolution)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ z,
+                                                             unsigned short* __restrict__ zs, size_t total8, int C8,
+                                                             size_t group8, size_t plane_elems) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const int g = (int)(i / group8);
+        const float* sc = scale + (size_t)(g * C8 + c8) * 8;
+        const float* sh = shift + (size_t)(g * C8 + c8) * 8;
+        float v[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(y)[i * 2 + hh];
+            const f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[k] = fmaxf(a[k] * s4[k] + h4[k], 0.f); v[hh * 4 + k] = o[k]; }
+            reinterpret_cast<f32x4*>(z)[i * 2 + hh] = o;
+        }
+        u32x4 pl[NP];
+        split8<NP>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(zs + p * plane_elems + i * 8) = pl[p];
+    }
+}
+
 // partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const float* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -208,6 +237,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
     }
 }
 
+// same, 8 channels per thread: dy as split-bf16 planes (and, when `dy` is not NULL, also in fp32)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restrict__ dz, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dy,
+                                                           unsigned short* __restrict__ dys, size_t total8, int C,
+                                                           size_t group8, size_t plane_elems) {
+    const int C8 = C / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const int g = (int)(i / group8);
+        float r[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int o = g * C + c8 * 8 + hh * 4;
+            const f32x4 v = reinterpret_cast<const f32x4*>(y)[i * 2 + hh];
+            const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i * 2 + hh];
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+            f32x4 q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
+                const float xh = (v[k] - mu[k]) * is[k];
+                q[k] = sc[k] * (dm - coef[(o + k) * 2] - xh * coef[(o + k) * 2 + 1]);
+                r[hh * 4 + k] = q[k];
+            }
+            if (dy) reinterpret_cast<f32x4*>(dy)[i * 2 + hh] = q;
+        }
+        u32x4 pl[NP];
+        split8<NP>(r, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dys + p * plane_elems + i * 8) = pl[p];
+    }
+}
+
 static int elt_grid(size_t total4) {
     size_t b = (total4 + 255) / 256;
     return (int)(b > 2048 * 4 ? 2048 * 4 : (b < 1 ? 1 : b));
@@ -269,25 +337,38 @@ extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const
     return check_launch("bn_eval_affine");
 }
 
-extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, int N, int HW, int C,
-                             int groups, rpnet_stream_t stream) {
+extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
+                             int N, int HW, int C, int groups, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && scale && shift && z, RPNET_ERR_ARG, "bn_relu: null pointer");
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    if (z_split) {
+        RPNET_REQUIRE((planes == 2 || planes == 3) && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
+        const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
+        if (planes == 3)
+            hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe);
+        else
+            hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe);
+        return check_launch("bn_relu_split");
+    }
     hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z,
                        total4, C / 4, group4);
     return check_launch("bn_relu");
 }
 
 extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
-                            const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta, int N, int HW,
-                            int C, int groups, int accumulate, void* workspace, size_t workspace_bytes,
-                            rpnet_stream_t stream) {
+                            const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* dgamma,
+                            float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
+                            size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
-    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && dy && dgamma && dbeta && workspace, RPNET_ERR_ARG,
-                  "bn_bwd: null pointer");
+    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && (dy || dy_split) && dgamma && dbeta && workspace,
+                  RPNET_ERR_ARG, "bn_bwd: null pointer");
+    RPNET_REQUIRE(!dy_split || ((planes == 2 || planes == 3) && C % 8 == 0), RPNET_ERR_SHAPE, "bn_bwd: split planes=%d C=%d",
+                  planes, C);
     if (int rc = bn_check("bn_bwd", N, HW, C, groups)) return rc;
     RPNET_REQUIRE(workspace_bytes >= rpnet_bn_workspace_bytes(C, groups), RPNET_ERR_WORKSPACE, "bn_bwd: workspace too small");
     const long R = (long)(N / groups) * HW;
@@ -300,6 +381,16 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(64), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                        coef, dgamma, dbeta, accumulate);
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    if (dy_split) {
+        const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
+        if (planes == 3)
+            hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe);
+        return check_launch("bn_bwd");
+    }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
                        (const float*)coef, dy, total4, C, group4);
     return check_launch("bn_bwd");

@@ -29,7 +29,7 @@ _ASYNC = {"on": False, "side": {}, "pending": set()}
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
 # v_mfma_f32_32x32x16_bf16 partial products into fp32 accumulators (dropped terms <= 2^-23 |x*y|: fp32
 # round-off level, 16/6 of the fp32 matrix rate); "bf16x2" = two planes, three products (2^-16).
-_MATH = {"planes": {"f32": 0, "bf16x3": 3, "bf16x2": 2}[os.environ.get("RPNET_CONV_MATH", "f32")]}
+_MATH = {"planes": {"f32": 0, "bf16x3": 3, "bf16x2": 2}[os.environ.get("RPNET_CONV_MATH", "bf16x3")]}
 
 
 def set_conv_math(mode):
@@ -188,7 +188,7 @@ class ConvBnRelu(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, in_scale, weight, bias, gamma, beta, running_mean, running_var, nbt, pw, training,
-                groups, upsample, in_mode):
+                groups, upsample, in_mode, out_split=True):
         hip.require_gpu(x0, weight)
         N, Hs, Ws, _ = x0.shape
         H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
@@ -240,7 +240,11 @@ class ConvBnRelu(Function):
             call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
                  ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
                  ptr(ws), wsb)
-        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), N, H * W, cout, groups)
+        np_out = _MATH["planes"] if (out_split and cout % 32 == 0) else 0
+        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
+        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, N, H * W, cout, groups)
+        if zs is not None:
+            z._rp_split = zs      # the next convolution's operand, produced here instead of by a separate pass
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
         ctx.bias, ctx.beta, ctx.xs = bias, beta, xs
@@ -259,16 +263,19 @@ class ConvBnRelu(Function):
         N, H, W, cout = y.shape
         wsb = query("rpnet_bn_workspace_bytes", cout, groups)
         ws = _ws(wsb, y)
-        dy = torch.empty_like(y)
         beta, bias = ctx.beta, ctx.bias
-        if _direct(gamma) and _direct(beta):     # straight into the gradient bucket, no AccumulateGrad add
-            call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
-                 ptr(stats[3]), ptr(dy), ptr(gamma.grad), ptr(beta.grad), N, H * W, cout, groups, 1, ptr(ws), wsb)
-            dgamma = dbeta = None
-        else:
-            dgamma, dbeta = _empty((cout,), y), _empty((cout,), y)
-            call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
-                 ptr(stats[3]), ptr(dy), ptr(dgamma), ptr(dbeta), N, H * W, cout, groups, 0, ptr(ws), wsb)
+        # which forms of dy the two consumers (wgrad, dgrad) want: split-bf16 planes and / or fp32
+        np_ = ctx.xs[0].shape[0] if ctx.xs is not None else 0
+        need_d = not first and (ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]))
+        wsplit = bool(np_) and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
+        dsplit = bool(np_) and cout % 32 == 0 and need_d
+        dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
+        dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
+        direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
+        dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
+        call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
+             ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(gamma.grad if direct else dgamma),
+             ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(ws), wsb)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:
@@ -277,13 +284,13 @@ class ConvBnRelu(Function):
             call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
         else:
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
-            dyp = dy
-            if ctx.xs is not None and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0:
-                np_ = ctx.xs[0].shape[0]        # both wgrad operands as split planes (the x*mask factor is in xs)
-                dyp = _split_operand(dy, np_)
-                d = _desc(ctx.xs[0], ctx.xs[1], pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, upsample)
+            if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)
+                dyp = dys
+                d = _desc(ctx.xs[0], ctx.xs[1], pw.wp, None, None, 0, None, None, N, H, W, pw.taps, upsample,
+                          co_split=(cout, 0))
                 d.split_planes = np_
             else:
+                dyp = dy
                 d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             if _direct(weight):
@@ -313,9 +320,8 @@ class ConvBnRelu(Function):
                 g1 = _empty((N, H, W, c1), y) if x1 is not None else None
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
                 need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
-                if _use_split(pw, x0, x1) and cout % 32 == 0:
-                    np_ = _MATH["planes"]
-                    dd = _desc(_split_operand(dy, np_), None, pw.split_packs(np_)[1], None, None, 0, g0, g1, N, H, W,
+                if dsplit:
+                    dd = _desc(dys, None, pw.split_packs(np_)[1], None, None, 0, g0, g1, N, H, W,
                                pw.taps, 0, out_scale=None if need_s else in_scale, out_mode=in_mode)
                     dd.split_planes = np_
                 else:
@@ -335,14 +341,17 @@ class ConvBnRelu(Function):
                 dx1 = g1 if need1 else None
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = None if _direct(bias) else torch.zeros_like(gamma)
-        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None):
+def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
+                 out_split=True):
+    """out_split: also write the output as split-bf16 planes (when the split arithmetic is on): pass False
+    when the consumer is not a 3x3 convolution."""
     pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
     return ConvBnRelu.apply(x0, x1, in_scale, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                             bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
-                            1 if upsample else 0, in_mode)
+                            1 if upsample else 0, in_mode, out_split)
 
 
 class ConvRelu(Function):
@@ -355,18 +364,25 @@ class ConvRelu(Function):
         N, H, W, _ = x.shape
         cout = weight.shape[0]
         z = _empty((N, H, W, cout), x)
-        d = _desc(x, None, pw.wp, bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
+        xs = None
+        if _use_split(pw, x, None):
+            np_ = _MATH["planes"]
+            xs = _split_operand(x, np_)
+            d = _desc(xs, None, pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
+            d.split_planes = np_
+        else:
+            d = _desc(x, None, pw.wp, bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
         d.dilation = dilation
         call("rpnet_conv_fwd", C.byref(d))
         ctx.save_for_backward(x, weight, z)
-        ctx.pw, ctx.cfg = pw, (relu, dilation)
+        ctx.pw, ctx.cfg, ctx.xs = pw, (relu, dilation), xs
         return z
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz):
         x, weight, z = ctx.saved_tensors
-        pw = ctx.pw
+        pw, xs = ctx.pw, ctx.xs
         relu, dilation = ctx.cfg
         N, H, W, cout = z.shape
         dy, db = torch.empty_like(z), _empty((cout,), z)
@@ -375,15 +391,25 @@ class ConvRelu(Function):
         call("rpnet_bias_relu_bwd", ptr(dz.contiguous()), ptr(z) if relu else None, ptr(dy), ptr(db), N * H * W, cout,
              ptr(ws), wb)
         dw = torch.empty_like(weight)
-        d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+        dys = _split_operand(dy, xs.shape[0]) if xs is not None and cout % 32 == 0 else None
+        if dys is not None and dilation <= 1 and pw.cin % 64 == 0 and cout % 64 == 0:
+            d = _desc(xs, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            d.split_planes, dyp = xs.shape[0], dys
+        else:
+            d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            dyp = dy
         d.Co0, d.dilation = cout, dilation
         wb2 = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
         ws2 = _ws(wb2, z)
-        call("rpnet_conv_wgrad", C.byref(d), ptr(dy), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
+        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
         dx = None
         if ctx.needs_input_grad[0] and pw.wd is not None:
             dx = _empty(x.shape, z)
-            dd = _desc(dy, None, pw.wd, None, None, 0, dx, None, N, H, W, pw.taps, 0)
+            if dys is not None:
+                dd = _desc(dys, None, pw.split_packs(xs.shape[0])[1], None, None, 0, dx, None, N, H, W, pw.taps, 0)
+                dd.split_planes = xs.shape[0]
+            else:
+                dd = _desc(dy, None, pw.wd, None, None, 0, dx, None, N, H, W, pw.taps, 0)
             dd.dilation = dilation
             call("rpnet_conv_fwd", C.byref(dd))
         return dx, dw, db, None, None, None

@@ -61,8 +61,18 @@ def test_unet_and_cre_vs_oracle():
             assert int(sd["encoder.Conv3.conv.1.num_batches_tracked"]) == 2 and int(sd["cre.w_k.1.num_batches_tracked"]) == 1
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def conv_math(request):
+    """default arithmetic of the 3x3 convolutions (3-plane split-bf16, fp32-equivalent) and the fp32-MFMA kernels"""
+    from rpnet_amd import functional as RF
+    old = RF.conv_math()
+    RF.set_conv_math(request.param)
+    yield request.param
+    RF.set_conv_math(old)
+
+
 @pytest.mark.parametrize("tag", ["m64_train", "m64_eval", "m128_train", "m256_train"])
-def test_model_vs_golden(golden, tag):
+def test_model_vs_golden(golden, tag, conv_math):
     g = golden(tag)
     size, B, T, training, seed = (int(v) for v in g["meta"])
     training = bool(training)
@@ -121,7 +131,7 @@ def test_model_vs_golden(golden, tag):
     print(f"{tag}: threshold flips vs reference {flips}")
 
 
-def test_teacher_forced_iterations(golden):
+def test_teacher_forced_iterations(golden, conv_math):
     """Each refinement iteration reproduced independently from the reference's own mask
     (hard-threshold flips cannot compound)."""
     from rpnet_amd import functional as RF

@@ -19,6 +19,16 @@ def RF():
     return functional
 
 
+@pytest.fixture(params=["f32", "bf16x3", "bf16x2"])
+def conv_math(RF, request):
+    """The 3x3 convolutions under each arithmetic: fp32 MFMA, 3-plane and 2-plane split-bf16 (all must
+    meet the same 1e-3 bar; the 3-plane split sits at fp32 round-off, see test_split_conv_accuracy)."""
+    old = RF.conv_math()
+    RF.set_conv_math(request.param)
+    yield request.param
+    RF.set_conv_math(old)
+
+
 def nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
@@ -62,7 +72,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("N,H,W,cin,cout,k", CONV_CASES)
 @pytest.mark.parametrize("training", [False, True])
-def test_conv_bn_relu(RF, N, H, W, cin, cout, k, training):
+def test_conv_bn_relu(RF, conv_math, N, H, W, cin, cout, k, training):
     conv, bn = _mk_layer(cin, cout, k, 7)
     x = rnd(1, N, cin, H, W)
     go = rnd(2, N, cout, H, W)
@@ -88,7 +98,7 @@ def test_conv_bn_relu(RF, N, H, W, cin, cout, k, training):
         assert int(bn.num_batches_tracked) == 1
 
 
-def test_conv_two_sources_upsample_and_groups(RF):
+def test_conv_two_sources_upsample_and_groups(RF, conv_math):
     """cat((skip, up), 1) as two gathered sources; nearest x2 fused in the gather; two BN
     statistic groups == two separate reference calls (support call, query call)."""
     N, H, W = 4, 8, 8
@@ -125,7 +135,36 @@ def test_conv_two_sources_upsample_and_groups(RF):
     assert rel_err(nchw(xg.grad), xr.grad) < TOL and rel_err(conv2.weight.grad, c2.weight.grad) < TOL
 
 
-def test_conv_masked_inputs(RF):
+def test_split_conv_accuracy(RF):
+    """Error of the split-bf16 convolution against an fp64 reference, next to the fp32-MFMA kernel's:
+    three planes must be as accurate as fp32 arithmetic (<= 1.5x its error + 1e-6), two planes within 2e-5;
+    forward, input gradient and weight gradient."""
+    N, H, W, cin, cout = 2, 16, 16, 256, 128
+    conv, bn = _mk_layer(cin, cout, 3, 21)
+    x, go = rnd(31, N, cin, H, W), rnd(32, N, cout, H, W)
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, conv.bias.detach().double(), padding=1)
+    yd.backward(go.double())
+    conv = conv.to(DEV)
+    errs = {}
+    for math in ("f32", "bf16x3", "bf16x2"):
+        RF.set_conv_math(math)
+        try:
+            xg = nhwc(x).to(DEV).requires_grad_(True)
+            conv.weight.grad = None
+            y = RF.ConvRelu.apply(xg, conv.weight, conv.bias, RF.WeightCache().get(conv.weight), False, 1)
+            y.backward(nhwc(go).to(DEV))
+            errs[math] = (rel_err(nchw(y).double().cpu(), yd.detach()), rel_err(nchw(xg.grad).double().cpu(), xd.grad),
+                          rel_err(conv.weight.grad.double().cpu(), wd.grad))
+        finally:
+            RF.set_conv_math("f32")
+    for k in range(3):
+        assert errs["bf16x3"][k] <= 1.5 * errs["f32"][k] + 1e-6, errs
+        assert errs["bf16x2"][k] <= 2e-5, errs
+
+
+def test_conv_masked_inputs(RF, conv_math):
     """w_k(x*m) and w_q(x*(1-m)) with the mask multiply fused into the gather (net/rp_net.py:275)."""
     N, H, W, Cc = 2, 8, 8, 64
     x, m = rnd(7, N, Cc, H, W), torch.rand(N, H, W, generator=torch.Generator().manual_seed(8))
