@@ -6,10 +6,21 @@
 
 namespace rpnet {
 
-template <int WM, int WN, int WGM = 2>
-__device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const int M, const int Cout,
-                                              const int HW, const int m0, const int n0, const int tm, const int wm,
-                                              const int wn, const int li, const int h) {
+// block-local accumulator row -> output pixel (linear NHW index), or -1 when the row is past the tensor
+struct LinearRows {   // the block's rows are consecutive pixels m0, m0 + 1, ...
+    int m0, M;
+    __device__ __forceinline__ int operator()(int local) const { const int r = m0 + local; return r < M ? r : -1; }
+};
+template <int TW>
+struct PatchRows {    // the block's rows walk a (rows / TW) x TW patch of one image, row-major
+    int base, W;      // linear index of the patch's top-left pixel
+    __device__ __forceinline__ int operator()(int local) const { return base + (local / TW) * W + (local % TW); }
+};
+
+template <int WM, int WN, int WGM = 2, typename RowMap = LinearRows>
+__device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows,
+                                              const int M, const int Cout, const int HW, const int n0, const int tm,
+                                              const int wm, const int wn, const int li, const int h) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
     if (d.stats_partial) {
@@ -25,8 +36,8 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = row < M ? acc[i][j][r] + bv : 0.f;
+                    const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    const float v = row >= 0 ? acc[i][j][r] + bv : 0.f;
                     sm += v;
                     sq += v * v;
                 }
@@ -49,8 +60,8 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) {
+                const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                if (row >= 0) {
                     float v = acc[i][j][r] + bv;
                     if (d.ep_scale) {
                         const int g = row / per_group;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
         __syncthreads();
     }
 
-    conv_epilogue<WM, WN>(d, acc, M, Cout, HW, m0, n0, tm, wm, wn, li, h);
+    conv_epilogue<WM, WN>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h);
 }
 
 template <int WM, int WN, bool INSCALE>

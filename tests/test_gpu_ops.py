@@ -135,6 +135,47 @@ def test_conv_two_sources_upsample_and_groups(RF, conv_math):
     assert rel_err(nchw(xg.grad), xr.grad) < TOL and rel_err(conv2.weight.grad, c2.weight.grad) < TOL
 
 
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [(2, 32, 32, 128, 0, 128, False), (1, 16, 16, 64, 64, 256, False),
+                                                   (2, 32, 64, 64, 0, 128, True), (3, 16, 48, 96, 32, 128, False)])
+def test_split_halo_kernel(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
+    """The halo-resident 256x128 variant (conv_igemm_split_halo_kernel: image patches, input halo staged once per
+    channel chunk) forced on small shapes: two sources, nearest x2, both patch widths (W % 32 == 0 / W % 16 == 0),
+    two BatchNorm groups; forward, dgrad and the fused batch statistics against the torch reference."""
+    monkeypatch.setenv("RPNET_SPLIT_TILE", "7")
+    old = RF.conv_math()
+    RF.set_conv_math("bf16x3")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        conv, bn = _mk_layer(c0 + c1, cout, 3, 41)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(42, N, c0, hs, ws)
+        b = rnd(43, N, c1, hs, ws) if c1 else None
+        go = rnd(44, N, cout, H, W)
+        import copy
+        c_ref, b_ref = copy.deepcopy(conv), copy.deepcopy(bn).train()
+        ar = a.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go)
+        conv, bn = conv.to(DEV), bn.to(DEV).train()
+        ag = nhwc(a).to(DEV).requires_grad_(True)
+        bg = nhwc(b).to(DEV).requires_grad_(True) if c1 else None
+        z = RF.conv_bn_relu(ag, conv, bn, RF.WeightCache(), True, x1=bg, groups=groups, upsample=ups)
+        z.backward(nhwc(go).to(DEV))
+        assert rel_err(nchw(z), ref) < TOL
+        assert rel_err(nchw(ag.grad), ar.grad) < TOL
+        if c1:
+            assert rel_err(nchw(bg.grad), br.grad) < TOL
+        assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+        assert rel_err(bn.running_var, b_ref.running_var) < 1e-5
+    finally:
+        RF.set_conv_math(old)
+
+
 def test_split_conv_accuracy(RF):
     """Error of the split-bf16 convolution against an fp64 reference, next to the fp32-MFMA kernel's:
     three planes must be as accurate as fp32 arithmetic (<= 1.5x its error + 1e-6), two planes within 2e-5;
