@@ -13,9 +13,15 @@ loop) + backward + the flat-bucket gradient all-reduce.  Synthet
 episodes are generated once and are resident in HBM before the timed region; weights are
 name-seeded random init (no dataset / checkpoint exists offline).
 
+Arithmetic of the 3x3 convolutions (`--conv-math`, default bf16x3): every fp32 operand is carried as three
+bf16 planes (an exact split) and multiplied on the bf16 matrix pipe with six partial products into fp32
+accumulators — fp32-level accuracy (dropped terms <= 2^-23 |x*y|; tests/test_gpu_ops.py::test_split_conv_accuracy
+measures it against fp64 next to the fp32-MFMA kernel) at 16/6 of the fp32 matrix rate.  `f32` selects the
+v_mfma_f32_32x32x2_f32 kernels; the JSON line carries that figure too (`alt_math`).
+
 Rank 0 prints ONE JSON line.  `roofline` is measured live: every C-ABI call of one extra
-step is bracketed by HIP events on the launch stream; the dominant kernel is the fp32-MFMA
-implicit-GEMM convolution (rpnet_conv_fwd: forward + dgrad launches).  The timed steps run with
+step is bracketed by HIP events on the launch stream; the dominant kernel is the implicit-GEMM
+convolution (rpnet_conv_fwd: forward + dgrad launches).  The timed steps run with
 the weight gradients on a second HIP stream (overlap on); the extra profiled step serialises the
 streams so that every launch owns the GPU and its duration is the kernel's own
 (RPNET_ASYNC_WGRAD=0 makes the timed steps serial too; profiles/ holds rocprofv3 stats of both).  `cpu_baseline` is
@@ -35,6 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak
+# MFMA partial products issued per algorithmic fp32 multiply-add, and the resulting ceiling in algorithmic FLOPs
+MATH = {"f32": (1, PEAK_F32_MFMA_TFLOPS), "bf16x3": (6, PEAK_BF16_MFMA_TFLOPS / 6), "bf16x2": (3, PEAK_BF16_MFMA_TFLOPS / 3)}
 GF_PER_PAIR = {(256, 5): 675.4, (128, 1): 138.5}  # algorithmic fwd+bwd GFLOP per pair
 
 
@@ -90,7 +99,8 @@ def profile_step(net, bucket, inp, scaler):
             d = args[0]._obj
             m, ci, co = d.N * d.H * d.W, d.C0 + d.C1, d.Co0 + d.Co1
             flops = 2.0 * m * ci * co * d.taps
-            nbytes = 4.0 * ((m >> (2 * d.upsample)) * ci + m * co + d.taps * ci * co)  # read x, w; write y
+            esz = 2.0 * d.split_planes if d.split_planes else 4.0                # operand bytes per element
+            nbytes = esz * ((m >> (2 * d.upsample)) * ci + d.taps * ci * co) + 4.0 * m * co   # read x, w; write y
         a.record()
         orig(name, *args)
         b.record()
@@ -129,7 +139,7 @@ def pmc_traffic():
     d = json.load(open(path))
     n = b = 0.0
     for k, v in d.items():
-        if "conv_igemm_kernel" in k:
+        if "conv_igemm" in k:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
     return round(b / n) if n else None
@@ -176,6 +186,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5, help="T refinement iterations")
     ap.add_argument("--shots", type=int, default=1, help="support shots (5 with --batch 16 = BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-math", choices=sorted(MATH), default=None,
+                    help="arithmetic of the 3x3 convolutions (default: the library's, bf16x3 = fp32-equivalent split)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,6 +213,10 @@ def main():
     from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
     import rpnet_amd.functional as RF
     RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
+    if args.conv_math:
+        RF.set_conv_math(args.conv_math)
+    math = RF.conv_math()
+    products, peak = MATH[math]
     net = build_model(cfg, dev)
     broadcast_parameters(net)
     bucket = FlatGradBucket(net)
@@ -234,6 +250,19 @@ def main():
     # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
     # issued by rank 0 alone would never complete); only rank 0 reports.
     agg = profile_step(net, bucket, inp, scaler)
+    alt = None
+    if world == 1 and math != "f32" and not args.no_cpu_baseline:
+        # the same step on the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), for reference
+        RF.set_conv_math("f32")
+        for _ in range(2):
+            step(net, bucket, inp, scaler)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step(net, bucket, inp, scaler)
+        fence()
+        alt = {"f32": {"value": round(args.batch * 5 / (time.perf_counter() - t1), 3), "unit": "pairs/s", "steps": 5}}
+        RF.set_conv_math(math)
     if rank == 0:
         conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
         wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
@@ -244,20 +273,30 @@ def main():
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "conv_math": {"f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
+                          "bf16x3": "fp32 operands as 3 bf16 planes (exact split), 6 v_mfma_f32_32x32x16_bf16 partial "
+                                    "products, fp32 accumulate: fp32-equivalent (dropped terms <= 2^-23 |x*y|)",
+                          "bf16x2": "2 bf16 planes, 3 partial products (dropped terms <= 2^-16 |x*y|)"}[math],
             "config": {"workload": f"1-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
                                    f"(BASELINE configs[{(1 if world == 1 else 3) if args.shots == 1 else 2}]), train mode, align loss on, "
                                    "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_math": math,
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (rpnet_conv_fwd: conv forward + dgrad launches)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+            "roofline": {"bound": "mfma", "kernel": "rpnet_conv_fwd launches (conv forward + dgrad): conv_igemm"
+                                                    + ("_kernel" if math == "f32" else "_split*_kernel"),
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
+                         "peak_basis": "157.3 TF dense fp32 MFMA" if math == "f32" else
+                                       f"2500 TF dense bf16 MFMA / {products} partial products per fp32 multiply-add "
+                                       "(achieved counts ALGORITHMIC fp32 FLOPs, not issued MFMA FLOPs)",
+                         "issued_mfma_tflops": round(achieved * products, 1),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline pass)",
                          "algorithmic_bytes_per_launch": round(conv[3] / max(conv[0], 1)),
                          "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
                          "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
                          "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
-                         "whole_step_frac": round(value / world * gf_pair * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                         "whole_step_frac": round(value / world * gf_pair * 1e9 / (peak * 1e12), 4),
+                         "whole_step_tflops": round(value / world * gf_pair / 1e3, 1),
                          "gflop_per_pair": round(gf_pair, 1),
                          "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
                                                sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
@@ -265,6 +304,8 @@ def main():
                          "note": "per-kernel figures from one extra step with the two HIP streams serialised; "
                                  "value/ms_per_step measured with async weight gradients on"},
         }
+        if alt:
+            result["alt_math"] = alt
         if world == 1 and not args.no_cpu_baseline and args.shots == 1:
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)

@@ -304,13 +304,14 @@ static int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// split-K plan of the nine-tap kernel: tiles * ksplit = 512 blocks (two resident blocks on each of
-// the 256 CUs, one full wave of the machine) whenever the K extent allows >= 8 steps per block;
+// split-K plan of the nine-tap kernels: tiles * ksplit = target_blocks (512 = two resident blocks on each of
+// the 256 CUs for the fp32 kernel, 256 = one per CU for the split-bf16 kernel: one full wave of the machine
+// either way) whenever the K extent allows >= 8 steps per block;
 // the partial buffer is then 512 * 9 * 64 * 64 * 4 B = 75 MB whatever the layer.
-void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
+void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split, int target_blocks) {
     const int tiles = (Cin / 64) * (Cout / 64);
     const int total_steps = (M + 31) / 32;
-    long ks = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+    long ks = tiles >= target_blocks ? 1 : (target_blocks + tiles - 1) / tiles;
     ks = std::min<long>(ks, std::max(1, total_steps / 8));
     if (ks >= 8) ks = (ks / 8) * 8;
     *steps_per_split = (int)((total_steps + ks - 1) / ks);
@@ -425,7 +426,7 @@ extern "C" size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_
     size_t need = (size_t)ks * taps * cin_gathered * cout * sizeof(float);
     if (taps == 9 && cin_gathered % 64 == 0 && cout % 64 == 0) {   // nine-tap kernel (dense) or single-tap (dilated): max
         int ks9, sps9;
-        rpnet::wgrad9_plan(N * H * W, cin_gathered, cout, &ks9, &sps9);
+        rpnet::wgrad9_plan(N * H * W, cin_gathered, cout, &ks9, &sps9, 512);   // the larger of the two plans
         need = std::max(need, (size_t)ks9 * 9 * cin_gathered * cout * sizeof(float));
     }
     return need;
@@ -449,7 +450,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     if (d->taps == 9 && d->dilation <= 1) {
         RPNET_REQUIRE(d->C1 == 0 || d->C0 % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to 64", d->C0);
         int ks9, sps9;
-        wgrad9_plan(M, Cin, Cout, &ks9, &sps9);
+        wgrad9_plan(M, Cin, Cout, &ks9, &sps9, d->split_planes ? 256 : 512);
         const size_t need9 = (size_t)ks9 * 9 * Cin * Cout * sizeof(float);
         RPNET_REQUIRE(workspace_bytes >= need9, RPNET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", workspace_bytes, need9);
         const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;

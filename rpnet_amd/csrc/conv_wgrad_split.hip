@@ -7,13 +7,14 @@
 // free: the LDS images stay [pixel][channel] (straight 16-byte row copies from HBM) and
 // ds_read_b64_tr_b16 hands lane c of a 16-lane group the 4 pixels x channel c column of a
 // [4 pixel][16 channel] block; every lane passes the address of its own (pixel, 4 channels) piece, so
-//   * the kx = -1 / 0 / +1 taps are the same read one pixel row up or down (an immediate offset), and
-//   * the image-border masks of the kx = -1 / +1 taps (dy rows whose left / right neighbour is outside
-//     the image) are the same read redirected to a row of zeros — no masked copies of dy.
-// LDS: per plane an x strip [3 ky][34 pixel][64 cin] and a dy tile [32 pixel + zero row][64 cout], rows
+//   * the kx = -1 / 0 / +1 taps are the same dy read one pixel row up or down (the sum runs over the x pixel q,
+//     x[q + ky W] * dy[q - kx]: the shift sits on the dy side, so an x fragment serves three taps), and
+//   * the image-border masks of the kx = -1 / +1 taps (q and q - kx in different image rows) are the same read
+//     redirected to a row of zeros — no masked copies of dy.
+// LDS: per plane an x strip [3 ky][32 pixel][64 cin] and a dy tile [34 pixel + zero row][64 cout], rows
 // padded to 192 bytes (four consecutive rows then cover all 64 banks: conflict-free transposing reads).
-// One block per CU (9 x 16 accumulator registers per lane); 108 (NP = 3) MFMAs per wave per 32-pixel
-// K-step keep the matrix pipe busy across the two barriers of the single-stage pipeline.
+// One block per CU (9 x 16 accumulator registers per lane, two LDS stages): 108 (NP = 3) MFMAs per wave per
+// 32-pixel K-step, one barrier per step, the next tile's LDS writes interleaved with the MFMAs.
 #include <algorithm>
 
 #include "common.h"
@@ -26,7 +27,6 @@ using s16x8 = __attribute__((ext_vector_type(8))) short;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split);   // conv_wgrad.hip
 
 template <int NP, bool POW2>
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
@@ -34,10 +34,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
                                                                      const int Cout, const int tiles, const int tiles_n,
                                                                      const int ksplit, const int steps_per_split,
                                                                      const int lw, const int lh) {
-    constexpr int BM = 64, BK = 32, SJ = BK + 2, RS = 192;
-    constexpr int A_PLANE = 3 * SJ * RS, B_PLANE = (BK + 1) * RS;
-    constexpr int A_ITEMS = 3 * SJ * 8, A_IT = (A_ITEMS + 255) / 256;   // 16-byte pieces of one plane of the strip
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (A_PLANE + B_PLANE)];
+    constexpr int BM = 64, BK = 32, RS = 192;
+    constexpr int A_PLANE = 3 * BK * RS, B_ROWS = BK + 2, B_PLANE = (B_ROWS + 1) * RS;
+    constexpr int A_IT = 3 * BK * 8 / 256;                    // 16-byte pieces of one plane of the x strip per thread (3)
+    constexpr int STAGE = NP * (A_PLANE + B_PLANE);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];   // two stages: 147 KB of the CU's 160 KB
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -72,19 +73,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
         rsx[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src + p * planex), (short)0, (int)(planex * 2), 0x00020000);
         rsy[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dy + p * planey), (short)0, (int)(planey * 2), 0x00020000);
     }
-    // strip pieces this thread stages: row r = e >> 3 of [3 ky][34], 16-byte column e & 7; source q = p0 + qoff
+    // x strip pieces this thread stages: row r = e >> 3 of [3 ky][32], 16-byte column e & 7; source q = p0 + qoff
     int qoff[A_IT], kyv[A_IT], adst[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int e = min(t + 256 * i, A_ITEMS - 1);
+        const int e = t + 256 * i;
         const int r = e >> 3;
-        const int kyi = r / SJ, j = r - kyi * SJ;
+        const int kyi = r / BK, j = r - kyi * BK;
         kyv[i] = kyi - 1;
-        qoff[i] = j - 1 + (kyi - 1) * W;
+        qoff[i] = j + (kyi - 1) * W;
         adst[i] = r * RS + (e & 7) * 16;
     }
-    const int brow = t >> 3, bdst = NP * A_PLANE + brow * RS + (t & 7) * 16;
-    u32x4 ra[NP][A_IT], rb[NP];
+    // dy pieces: rows p0 - 1 .. p0 + 32 (34 rows x 8 pieces = 272: a second, partial pass for t < 16)
+    const int c16 = (t & 7) * 16;
+    const int brow0 = t >> 3, brow1 = 32 + (t >> 3);
+    const bool b2 = t < (B_ROWS - 32) * 8;
+    u32x4 ra[NP][A_IT], rb[NP][2];
     auto load_tile = [&](int st) {
         const int p0 = st * BK;
 #pragma unroll
@@ -100,30 +104,36 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
                 const int xq = rem - yq * W;
                 pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
             }
-            const int yp = yq - kyv[i];                     // row of the output pixel this source serves
+            const int yp = yq - kyv[i];                     // image row of the x pixel this source row pairs with
             const bool ok = (unsigned)q < (unsigned)M && (unsigned)yp < (unsigned)H;
-            const int voff = ok ? pix * (Cs * 2) + (adst[i] % RS) : (int)0x80000000;
+            const int voff = ok ? pix * (Cs * 2) + c16 : (int)0x80000000;
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 ra[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx[p], voff, cc * 2, 0));
         }
-        const int yoff = (p0 + brow) * (Cout * 2) + (t & 7) * 16;   // past M*Cout: beyond num_records, zeros
+        // pixels before 0 (negative offset) or past M (beyond num_records) read as zeros
+        const int y0 = (p0 - 1 + brow0) * (Cout * 2) + c16, y1 = b2 ? (p0 - 1 + brow1) * (Cout * 2) + c16 : (int)0x80000000;
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-            rb[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], yoff, n0 * 2, 0));
+        for (int p = 0; p < NP; ++p) {
+            rb[p][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], y0, n0 * 2, 0));
+            rb[p][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], y1, n0 * 2, 0));
+        }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                if (t + 256 * i < A_ITEMS) *reinterpret_cast<u32x4*>(smem + p * A_PLANE + adst[i]) = ra[p][i];
-            *reinterpret_cast<u32x4*>(smem + p * B_PLANE + bdst) = rb[p];
+                *reinterpret_cast<u32x4*>(smem + stage + p * A_PLANE + adst[i]) = ra[p][i];
+            unsigned char* bpl = smem + stage + NP * A_PLANE + p * B_PLANE;
+            *reinterpret_cast<u32x4*>(bpl + brow0 * RS + c16) = rb[p][0];
+            if (b2) *reinterpret_cast<u32x4*>(bpl + brow1 * RS + c16) = rb[p][1];
         }
     };
-    if (t < 8 * NP) {   // the zero row (row 32) of every dy plane
+    if (t < 16 * NP) {   // the zero row (row 34) of every dy plane of both stages
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(smem + NP * A_PLANE + (t >> 3) * B_PLANE + BK * RS + (t & 7) * 16) = zero;
+        const int pl = t >> 3;
+        *reinterpret_cast<u32x4*>(smem + (pl / NP) * STAGE + NP * A_PLANE + (pl % NP) * B_PLANE + B_ROWS * RS + c16) = zero;
     }
 
     f32x16 acc[9];
@@ -136,61 +146,75 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
     // lane L of the group addresses row (L >> 2), channels 4 (L & 3)..
     const int g = lane >> 4, L = lane & 15;
     const int krow = 8 * (g >> 1) + (L >> 2);
-    const int a_base = krow * RS + (wm * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
-    const int b_col = NP * A_PLANE + (wn * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
+    const int a_base0 = krow * RS + (wm * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
+    const int b_col0 = NP * A_PLANE + (wn * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
     auto tr = [&](int byte_off) -> s16x4 {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + byte_off));
     };
 
+    // Two LDS stages, one barrier per K-step: tile st + 1 (fetched during step st - 1) is written into the other stage
+    // between the MFMA groups of step st, tile st + 2 is then put in flight.
     if (s_begin < s_end) {
         load_tile(s_begin);
-        store_tile();
+        store_tile(0);
+        if (s_begin + 1 < s_end) load_tile(s_begin + 1);
         __syncthreads();
         for (int st = s_begin; st < s_end; ++st) {
             const bool more = st + 1 < s_end;
-            if (more) load_tile(st + 1);
-            // dy rows this lane addresses in the 4 (slice, half) reads, and their kx = -1 / +1 border redirects
-            int b0[4], bm_[4], bp_[4];
+            const int cur = ((st - s_begin) & 1) * STAGE;
+            const int a_base = a_base0 + cur, b_col = b_col0 + cur;
+            // x pixel rows this lane addresses in the 4 (slice, half) reads; the dy row paired with x pixel q for tap
+            // kx is q - (kx - 1) = tile row (q - p0) + 2 - kx, redirected to the zero row when q and it are not in
+            // the same image row
+            int bk0[4], bk1[4], bk2[4];
 #pragma unroll
             for (int se = 0; se < 4; ++se) {
                 const int row = 16 * (se >> 1) + 4 * (se & 1) + krow;
-                const int p = st * BK + row;
-                const int ox = POW2 ? (p & (W - 1)) : (p % W);
-                b0[se] = b_col + row * RS;
-                bm_[se] = ox >= 1 ? b0[se] : b_col + BK * RS;
-                bp_[se] = ox <= W - 2 ? b0[se] : b_col + BK * RS;
+                const int q = st * BK + row;
+                const int ox = POW2 ? (q & (W - 1)) : (q % W);
+                const int zr = b_col + B_ROWS * RS;
+                bk0[se] = ox <= W - 2 ? b_col + (row + 2) * RS : zr;     // kx = -1: dy[q + 1]
+                bk1[se] = b_col + (row + 1) * RS;                        // kx =  0: dy[q]
+                bk2[se] = ox >= 1 ? b_col + row * RS : zr;               // kx = +1: dy[q - 1]
             }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 bf[3][NP];
+            // All fragments of a 16-pixel slice (3 ky strips of x, 3 kx variants of dy, NP planes each) feed its
+            // 9 x NPROD MFMAs; the two slices are double-buffered in registers and the taps advance together so
+            // that consecutive MFMAs never share an accumulator.
+            auto load_frags = [&](int s, bf16x8 (&af)[3][NP], bf16x8 (&bf)[3][NP]) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    bf[0][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bm_[2 * s] + p * B_PLANE), tr(bm_[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
-                    bf[1][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(b0[2 * s] + p * B_PLANE), tr(b0[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
-                    bf[2][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bp_[2 * s] + p * B_PLANE), tr(bp_[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+                    bf[0][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk0[2 * s] + p * B_PLANE), tr(bk0[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
+                    bf[1][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk1[2 * s] + p * B_PLANE), tr(bk1[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
+                    bf[2][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk2[2 * s] + p * B_PLANE), tr(bk2[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        bf16x8 af[NP];
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) {
-                            const int o = a_base + p * A_PLANE + (ky * SJ + 16 * s + kx) * RS;   // strip row = pixel + kx (kx - 1 + 1)
-                            af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(o), tr(o + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
-                        }
-                        constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-                        constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-                        constexpr int NPROD = NP == 3 ? 6 : 3;
-#pragma unroll
-                        for (int q = 0; q < NPROD; ++q) {
-                            const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[kx][pb], acc[ky * 3 + kx], 0, 0, 0);
-                        }
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int o = a_base + p * A_PLANE + (ky * BK + 16 * s) * RS;
+                        af[ky][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(o), tr(o + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
                     }
+                }
+            };
+            auto mma_slice = [&](const bf16x8 (&af)[3][NP], const bf16x8 (&bf)[3][NP]) {
+                constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+                constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+                for (int q = 0; q < NPROD; ++q) {
+                    const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap)
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap / 3][pa], bf[tap % 3][pb], acc[tap], 0, 0, 0);
+                }
+            };
+            bf16x8 afA[3][NP], bfA[3][NP], afB[3][NP], bfB[3][NP];
+            load_frags(0, afA, bfA);
+            load_frags(1, afB, bfB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slice(afA, bfA);
+            if (more) {
+                store_tile(STAGE - cur);
+                if (st + 2 < s_end) load_tile(st + 2);
             }
-            __syncthreads();
-            if (more) store_tile();
+            mma_slice(afB, bfB);
             __syncthreads();
         }
     }
