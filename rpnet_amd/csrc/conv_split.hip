@@ -298,13 +298,13 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
 // Weights are double-buffered (one barrier per K-step); the next chunk's halo waits in registers during the nine
 // taps of the current one.  A 32-pixel MFMA tile row is TW = 32 consecutive pixels of a patch row (or two
 // 16-pixel rows), so the (row >> 2) & 3 k-group swizzle keeps the fragment reads conflict-free.
-template <int TW, int NP>
+template <int TW, int NP, int WN>
 __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
                                                                         const int tiles_n, const int ntiles) {
-    constexpr int NT = 512, BM = 256, BN = 128, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int NT = 512, BM = 256, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
     constexpr int A_BYTES = HALO * 64, B_BYTES = BN * 64;
     constexpr int HJ = (HALO * 4 + NT - 1) / NT;
-    constexpr int WM = 2, WN = 2;
+    constexpr int WM = 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NP * A_BYTES + 2 * NP * B_BYTES];
     unsigned char* const bsm = smem + NP * A_BYTES;
 
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                 if (hdst[j] >= 0) *reinterpret_cast<u32x4*>(smem + p * A_BYTES + hdst[j]) = ha[p][j];
     };
     const int brow = t >> 2;
-    const int wvoff = brow * 64 + skg16;
+    const bool stage_b = brow < BN;              // BN = 64: the first four waves stage the weights
+    const int wvoff = stage_b ? brow * 64 + skg16 : -1;
     const int bdst = brow * 64 + 16 * ((t & 3) ^ ((brow >> 2) & 3));
     auto load_b = [&](int tap, int c0) {
         const int wsoff = ((tap * kchunks + (c0 >> 5)) * Cout + n0) * 64;
@@ -387,8 +388,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
             rb[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw[p], wvoff, wsoff, 0));
     };
     auto store_b = [&](int stage) {
+        if (stage_b) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(bsm + (stage * NP + p) * B_BYTES + bdst) = rb[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(bsm + (stage * NP + p) * B_BYTES + bdst) = rb[p];
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -478,21 +481,25 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                                             li, h);
 }
 
-template <int TW>
+template <int TW, int WN>
 static int launch_split_halo(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
-    const int tiles_m = M / 256, tiles_n = Cout / 128;
+    const int tiles_m = M / 256, tiles_n = Cout / (64 * WN);
     const int ntiles = tiles_m * tiles_n;
     if (d->split_planes == 3)
-        hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 3>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 3, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     else
-        hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 2>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 2, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split_halo");
 }
 
-// halo variant usable: dense 3x3, 128-aligned output channels, image made of whole (256 / TW) x TW patches
+// tile width of the halo variant: 128 output channels per block when they split that way, else 64
+static int halo_bn(const rpnet_conv_desc* d, int Cout) {
+    return ((Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0)) ? 128 : 64;
+}
+
+// halo variant usable: dense 3x3, image made of whole (256 / TW) x TW patches
 static int halo_tw(const rpnet_conv_desc* d, int Cout) {
-    const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
-    if (d->taps != 9 || d->dilation > 1 || !n128) return 0;
+    if (d->taps != 9 || d->dilation > 1) return 0;
     if (d->W % 32 == 0 && d->H % 8 == 0) return 32;
     if (d->W % 16 == 0 && d->H % 16 == 0) return 16;
     return 0;
@@ -532,10 +539,11 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (e) {
         const int v = atoi(e);
-        if (v >= 0 && v < kNumSplitVariants && (kSplitVariants[v].wn == 1 || n128) && (v != 7 || halo_tw(d, Cout))) return v;
+        if (v == 7 && halo_tw(d, Cout)) return v;
+        if (v >= 0 && v < 7 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
-    if (halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224) return 7;
+    if (halo_tw(d, Cout) && (long)(M / 256) * (Cout / halo_bn(d, Cout)) >= 224) return 7;
     int best = -1;
     double best_fill = -1.0;
     for (int c = 0; c < 4; ++c) {
@@ -564,7 +572,10 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 4: return launch_split<4, 2, 2, true>(d, M, Cin, Cout, s);
         case 5: return launch_split<4, 2, 2, false>(d, M, Cin, Cout, s);
         case 6: return launch_split<2, 2, 2, true>(d, M, Cin, Cout, s);
-        default: return halo_tw(d, Cout) == 32 ? launch_split_halo<32>(d, M, Cin, Cout, s) : launch_split_halo<16>(d, M, Cin, Cout, s);
+        default:
+            if (halo_bn(d, Cout) == 128)
+                return halo_tw(d, Cout) == 32 ? launch_split_halo<32, 2>(d, M, Cin, Cout, s) : launch_split_halo<16, 2>(d, M, Cin, Cout, s);
+            return halo_tw(d, Cout) == 32 ? launch_split_halo<32, 1>(d, M, Cin, Cout, s) : launch_split_halo<16, 1>(d, M, Cin, Cout, s);
     }
 }
 

@@ -119,14 +119,29 @@ class PackedWeight:
             n0, n0_pad = split
             self.off0, self.split, self.off1, self.cin_pad = 0, n0, n0_pad, n0_pad + (cin - n0)
         self.cout, self.cin = cout, cin
-        padded = self.cin_pad != cin
-        mk = torch.zeros if padded else torch.empty
-        self.wp = mk(self.taps * self.cin_pad * cout, device=weight.device, dtype=torch.float32)
-        self.wd = mk(self.taps * self.cin_pad * cout, device=weight.device, dtype=torch.float32) if cin >= 32 else None
-        call("rpnet_pack_conv_weight", ptr(weight), ptr(self.wp), ptr(self.wd), cout, cin, self.taps, self.off0,
-             self.split, self.off1, self.cin_pad)
-        self.wps = self.wds = None
+        self.has_wd = cin >= 32
         self._weight = weight
+        self._wp = self._wd = self.wps = self.wds = None    # packed on first use (fp32 and split packs are exclusive per layer)
+
+    def _pack_f32(self):
+        w, n = self._weight, self.taps * self.cin_pad * self.cout
+        mk = torch.zeros if self.cin_pad != self.cin else torch.empty
+        self._wp = mk(n, device=w.device, dtype=torch.float32)
+        self._wd = mk(n, device=w.device, dtype=torch.float32) if self.has_wd else None
+        call("rpnet_pack_conv_weight", ptr(w), ptr(self._wp), ptr(self._wd), self.cout, self.cin, self.taps, self.off0,
+             self.split, self.off1, self.cin_pad)
+
+    @property
+    def wp(self):
+        if self._wp is None:
+            self._pack_f32()
+        return self._wp
+
+    @property
+    def wd(self):
+        if self._wp is None:
+            self._pack_f32()
+        return self._wd
 
     def split_packs(self, planes):
         """bf16 split packs of the same weight (rpnet_pack_conv_weight_split), made on first use."""
@@ -286,12 +301,12 @@ class ConvBnRelu(Function):
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)
                 dyp = dys
-                d = _desc(ctx.xs[0], ctx.xs[1], pw.wp, None, None, 0, None, None, N, H, W, pw.taps, upsample,
+                d = _desc(ctx.xs[0], ctx.xs[1], None, None, None, 0, None, None, N, H, W, pw.taps, upsample,
                           co_split=(cout, 0))
                 d.split_planes = np_
             else:
                 dyp = dy
-                d = _desc(x0, x1, pw.wp, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
+                d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             if _direct(weight):
                 dev = y.device
@@ -393,17 +408,17 @@ class ConvRelu(Function):
         dw = torch.empty_like(weight)
         dys = _split_operand(dy, xs.shape[0]) if xs is not None and cout % 32 == 0 else None
         if dys is not None and dilation <= 1 and pw.cin % 64 == 0 and cout % 64 == 0:
-            d = _desc(xs, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            d = _desc(xs, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0)
             d.split_planes, dyp = xs.shape[0], dys
         else:
-            d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            d = _desc(x, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0)
             dyp = dy
         d.Co0, d.dilation = cout, dilation
         wb2 = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
         ws2 = _ws(wb2, z)
         call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
         dx = None
-        if ctx.needs_input_grad[0] and pw.wd is not None:
+        if ctx.needs_input_grad[0] and pw.has_wd:
             dx = _empty(x.shape, z)
             if dys is not None:
                 dd = _desc(dys, None, pw.split_packs(xs.shape[0])[1], None, None, 0, dx, None, N, H, W, pw.taps, 0)

@@ -40,6 +40,8 @@ for (N, H, W, ci, co) in [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]:
 
 SHAPES = [(16, 256, 256, 64, 64), (16, 128, 128, 128, 128), (16, 64, 64, 256, 256), (16, 32, 32, 512, 512),
           (16, 16, 16, 1024, 1024), (16, 32, 32, 1024, 512), (8, 64, 64, 256, 256)]
+if os.environ.get("SHAPES"):
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for (N, H, W, ci, co) in SHAPES:
     x = torch.randn(N, H, W, ci, device=dev)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
