@@ -16,6 +16,7 @@
 // One block per CU (9 x 16 accumulator registers per lane, two LDS stages): 108 (NP = 3) MFMAs per wave per
 // 32-pixel K-step, one barrier per step, the next tile's LDS writes interleaved with the MFMAs.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -28,21 +29,27 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 
-template <int NP, bool POW2>
-__global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
+// KYW = false: 4 waves, each a 32x32 quadrant of the tile for all nine taps (9 x 16 accumulators, one wave per SIMD).
+// KYW = true: 12 waves = 4 quadrants x 3 tap rows (ky): 3 x 16 accumulators per wave, three waves per SIMD, so one
+//             wave's LDS reads / staging issue under the other waves' MFMAs; the dy fragments are read by three
+//             waves instead of one (LDS reads 0.67 -> 1.33 per MFMA, still a third of the LDS bandwidth).
+template <int NP, bool POW2, bool KYW>
+__global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                      float* __restrict__ partial, const int M, const int Cin,
                                                                      const int Cout, const int tiles, const int tiles_n,
                                                                      const int ksplit, const int steps_per_split,
                                                                      const int lw, const int lh) {
     constexpr int BM = 64, BK = 32, RS = 192;
     constexpr int A_PLANE = 3 * BK * RS, B_ROWS = BK + 2, B_PLANE = (B_ROWS + 1) * RS;
-    constexpr int A_IT = 3 * BK * 8 / 256;                    // 16-byte pieces of one plane of the x strip per thread (3)
+    constexpr int NT = KYW ? 768 : 256;
+    constexpr int A_IT = 3 * BK * 8 / NT;                     // 16-byte pieces of one plane of the x strip per thread
+    constexpr int NACC = KYW ? 3 : 9;
     constexpr int STAGE = NP * (A_PLANE + B_PLANE);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];   // two stages: 147 KB of the CU's 160 KB
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = (wv & 3) >> 1, wn = wv & 1, wky = wv >> 2;
     int tile, z;
     if ((ksplit & 7) == 0) {       // the blocks of one pixel chunk share an XCD (and its L2)
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
     int qoff[A_IT], kyv[A_IT], adst[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int e = t + 256 * i;
+        const int e = t + NT * i;
         const int r = e >> 3;
         const int kyi = r / BK, j = r - kyi * BK;
         kyv[i] = kyi - 1;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
     // dy pieces: rows p0 - 1 .. p0 + 32 (34 rows x 8 pieces = 272: a second, partial pass for t < 16)
     const int c16 = (t & 7) * 16;
     const int brow0 = t >> 3, brow1 = 32 + (t >> 3);
-    const bool b2 = t < (B_ROWS - 32) * 8;
+    const bool b1 = brow0 < B_ROWS, b2 = !KYW && t < (B_ROWS - 32) * 8;   // 34 rows: a second partial pass with 256 threads
     u32x4 ra[NP][A_IT], rb[NP][2];
     auto load_tile = [&](int st) {
         const int p0 = st * BK;
@@ -112,11 +119,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
                 ra[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx[p], voff, cc * 2, 0));
         }
         // pixels before 0 (negative offset) or past M (beyond num_records) read as zeros
-        const int y0 = (p0 - 1 + brow0) * (Cout * 2) + c16, y1 = b2 ? (p0 - 1 + brow1) * (Cout * 2) + c16 : (int)0x80000000;
+        const int y0 = b1 ? (p0 - 1 + brow0) * (Cout * 2) + c16 : (int)0x80000000;
+        const int y1 = b2 ? (p0 - 1 + brow1) * (Cout * 2) + c16 : (int)0x80000000;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             rb[p][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], y0, n0 * 2, 0));
-            rb[p][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], y1, n0 * 2, 0));
+            if (!KYW) rb[p][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], y1, n0 * 2, 0));
         }
     };
     auto store_tile = [&](int stage) {
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
             for (int i = 0; i < A_IT; ++i)
                 *reinterpret_cast<u32x4*>(smem + stage + p * A_PLANE + adst[i]) = ra[p][i];
             unsigned char* bpl = smem + stage + NP * A_PLANE + p * B_PLANE;
-            *reinterpret_cast<u32x4*>(bpl + brow0 * RS + c16) = rb[p][0];
+            if (b1) *reinterpret_cast<u32x4*>(bpl + brow0 * RS + c16) = rb[p][0];
             if (b2) *reinterpret_cast<u32x4*>(bpl + brow1 * RS + c16) = rb[p][1];
         }
     };
@@ -136,9 +144,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
         *reinterpret_cast<u32x4*>(smem + (pl / NP) * STAGE + NP * A_PLANE + (pl % NP) * B_PLANE + B_ROWS * RS + c16) = zero;
     }
 
-    f32x16 acc[9];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
@@ -177,44 +185,71 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
                 bk1[se] = b_col + (row + 1) * RS;                        // kx =  0: dy[q]
                 bk2[se] = ox >= 1 ? b_col + row * RS : zr;               // kx = +1: dy[q - 1]
             }
-            // All fragments of a 16-pixel slice (3 ky strips of x, 3 kx variants of dy, NP planes each) feed its
-            // 9 x NPROD MFMAs; the two slices are double-buffered in registers and the taps advance together so
-            // that consecutive MFMAs never share an accumulator.
-            auto load_frags = [&](int s, bf16x8 (&af)[3][NP], bf16x8 (&bf)[3][NP]) {
+            auto load_bf = [&](int s, bf16x8 (&bf)[3][NP]) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     bf[0][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk0[2 * s] + p * B_PLANE), tr(bk0[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
                     bf[1][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk1[2 * s] + p * B_PLANE), tr(bk1[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
                     bf[2][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(bk2[2 * s] + p * B_PLANE), tr(bk2[2 * s + 1] + p * B_PLANE), 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            };
+            auto load_af = [&](int s, int ky, bf16x8 (&af)[NP]) {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int o = a_base + p * A_PLANE + (ky * BK + 16 * s) * RS;
-                        af[ky][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(o), tr(o + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
+                for (int p = 0; p < NP; ++p) {
+                    const int o = a_base + p * A_PLANE + (ky * BK + 16 * s) * RS;
+                    af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(o), tr(o + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            };
+            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+            if constexpr (KYW) {
+                // this wave: one tap row (ky = wky), three kx taps of its 32x32 quadrant
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 af[NP], bf[3][NP];
+                    load_af(s, wky, af);
+                    load_bf(s, bf);
+                    if (s == 1 && more) {
+                        store_tile(STAGE - cur);
+                        if (st + 2 < s_end) load_tile(st + 2);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPROD; ++q) {
+                        const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[kx][pb], acc[kx], 0, 0, 0);
                     }
                 }
-            };
-            auto mma_slice = [&](const bf16x8 (&af)[3][NP], const bf16x8 (&bf)[3][NP]) {
-                constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-                constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-                constexpr int NPROD = NP == 3 ? 6 : 3;
+            } else {
+                // All fragments of a 16-pixel slice (3 ky strips of x, 3 kx variants of dy, NP planes each) feed its
+                // 9 x NPROD MFMAs; the two slices are double-buffered in registers and the taps advance together so
+                // that consecutive MFMAs never share an accumulator.
+                auto mma_slice = [&](const bf16x8 (&af)[3][NP], const bf16x8 (&bf)[3][NP]) {
 #pragma unroll
-                for (int q = 0; q < NPROD; ++q) {
-                    const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                    for (int q = 0; q < NPROD; ++q) {
+                        const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap)
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap / 3][pa], bf[tap % 3][pb], acc[tap], 0, 0, 0);
+                        for (int tap = 0; tap < 9; ++tap)
+                            acc[tap % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap / 3][pa], bf[tap % 3][pb], acc[tap % NACC], 0, 0, 0);
+                    }
+                };
+                bf16x8 afA[3][NP], bfA[3][NP], afB[3][NP], bfB[3][NP];
+                load_bf(0, bfA);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) load_af(0, ky, afA[ky]);
+                load_bf(1, bfB);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) load_af(1, ky, afB[ky]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_slice(afA, bfA);
+                if (more) {
+                    store_tile(STAGE - cur);
+                    if (st + 2 < s_end) load_tile(st + 2);
                 }
-            };
-            bf16x8 afA[3][NP], bfA[3][NP], afB[3][NP], bfB[3][NP];
-            load_frags(0, afA, bfA);
-            load_frags(1, afB, bfB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_slice(afA, bfA);
-            if (more) {
-                store_tile(STAGE - cur);
-                if (st + 2 < s_end) load_tile(st + 2);
+                mma_slice(afB, bfB);
             }
-            mma_slice(afB, bfB);
             __syncthreads();
         }
     }
@@ -222,12 +257,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_split_kernel(const rpnet_c
     const int li = lane & 31, h = lane >> 5;
     const int col = n0 + wn * 32 + li;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int a = 0; a < NACC; ++a) {
+        const int tap = KYW ? wky * 3 + a : a;
         float* out = partial + ((size_t)(z * 9 + tap) * Cin) * Cout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = cm0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(size_t)row * Cout + col] = acc[tap][r];
+            out[(size_t)row * Cout + col] = acc[a][r];
         }
     }
 }
@@ -245,9 +281,17 @@ int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, in
     const int lw = ilog2x(d->W), lh = ilog2x(d->H);
     const bool p2 = lw >= 0 && lh >= 0;
     const unsigned short* dys = (const unsigned short*)dy;
-#define RPNET_W9S(NPL, P2)                                                                                                \
-    hipLaunchKernelGGL((conv_wgrad9_split_kernel<NPL, P2>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, \
-                       tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0)
+    const char* e = getenv("RPNET_WGRAD_WAVES");   // tuning override: 4 = one wave per quadrant, all nine taps
+    const bool kyw = !(e && atoi(e) == 4);
+#define RPNET_W9S(NPL, P2)                                                                                                     \
+    do {                                                                                                                       \
+        if (kyw)                                                                                                               \
+            hipLaunchKernelGGL((conv_wgrad9_split_kernel<NPL, P2, true>), dim3(tiles9 * ks9), dim3(768), 0, s, *d, dys, part9, \
+                               M, Cin, Cout, tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0);                           \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((conv_wgrad9_split_kernel<NPL, P2, false>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, \
+                               M, Cin, Cout, tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0);                           \
+    } while (0)
     if (d->split_planes == 3) { if (p2) RPNET_W9S(3, true); else RPNET_W9S(3, false); }
     else { if (p2) RPNET_W9S(2, true); else RPNET_W9S(2, false); }
 #undef RPNET_W9S
