@@ -481,6 +481,191 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                                             li, h);
 }
 
+template <int TW, int NP, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
+                                                                        const int tiles_n, const int ntiles) {
+    constexpr int NT = 256, BM = 128, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int A_BYTES = HALO * 64, B_BYTES = BN * 64;
+    constexpr int HJ = (HALO * 4 + NT - 1) / NT;
+    constexpr int WM = 2;
+    constexpr int BJ = (BN * 4 + NT - 1) / NT;                  // weight pieces per thread and plane
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * A_BYTES + NP * B_BYTES];   // one weight stage
+    unsigned char* const bsm = smem + NP * A_BYTES;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    const int tile = xcd_swizzle(blockIdx.x, ntiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int n0 = tn * BN;
+    const int H = d.H, W = d.W, HW = H * W;
+    const int ups = d.upsample;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const int pxn = W / TW, ppi = (H / TH) * pxn;
+    const int n = tm / ppi, prem = tm - n * ppi;
+    const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
+
+    // halo pieces this thread stages: halo row hr = e >> 2, k-group e & 3
+    int hoff[HJ], hdst[HJ];
+#pragma unroll
+    for (int j = 0; j < HJ; ++j) {
+        const int e = t + NT * j;
+        const int hr = e >> 2, kg = e & 3;
+        const int hy = hr / PW, hx = hr - hy * PW;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool inb = e < HALO * 4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        hoff[j] = inb ? (n * Hs + (iy >> ups)) * Ws + (ix >> ups) : -1;
+        hdst[j] = e < HALO * 4 ? hr * 64 + 16 * (kg ^ ((hr >> 2) & 3)) : -1;
+    }
+    const int skg16 = (t & 3) * 16;
+    const int kchunks = Cin >> 5;
+    const int nsteps = 9 * kchunks;
+    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << 5; };
+
+    const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
+    const size_t planew = (size_t)9 * Cin * Cout;
+    const unsigned short* x0p = reinterpret_cast<const unsigned short*>(d.x0);
+    const unsigned short* x1p = reinterpret_cast<const unsigned short*>(d.x1 ? d.x1 : d.x0);
+    const unsigned short* wq = reinterpret_cast<const unsigned short*>(d.w);
+    __amdgpu_buffer_rsrc_t rs0[NP], rs1[NP], rsw[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        rs0[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p + p * plane0), (short)0,
+                                                   (int)(plane0 * 2), 0x00020000);
+        rs1[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x1p + p * (d.x1 ? plane1 : plane0)), (short)0,
+                                                   (int)((d.x1 ? plane1 : plane0) * 2), 0x00020000);
+        rsw[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq + p * planew), (short)0,
+                                                   (int)(planew * 2), 0x00020000);
+    }
+    u32x4 ha[NP][HJ], rb[NP][BJ];
+    auto load_halo = [&](int c0) {
+        const bool first = c0 < d.C0;
+        const int Cs = first ? d.C0 : d.C1;
+        const int soff = (first ? c0 : c0 - d.C0) * 2;
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+            const int voff = hoff[j] * (Cs * 2) + skg16;     // -1 -> beyond num_records -> zeros (the padding)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                ha[p][j] = first ? __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0[p], voff, soff, 0))
+                                 : __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1[p], voff, soff, 0));
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int j = 0; j < HJ; ++j)
+                if (hdst[j] >= 0) *reinterpret_cast<u32x4*>(smem + p * A_BYTES + hdst[j]) = ha[p][j];
+    };
+    const int brow = t >> 2;                     // + 64 j
+    const bool stage_b = brow < BN;
+    const int bdst = brow * 64 + 16 * ((t & 3) ^ ((brow >> 2) & 3));
+    auto load_b = [&](int tap, int c0) {
+        const int wsoff = ((tap * kchunks + (c0 >> 5)) * Cout + n0) * 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int wvoff = (brow + 64 * j) < BN ? (brow + 64 * j) * 64 + skg16 : -1;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                rb[p][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw[p], wvoff, wsoff, 0));
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            if (brow + 64 * j < BN) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + j * 4096 + bdst) = rb[p][j];
+            }
+    };
+    (void)stage_b;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int hr00[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mloc = (wm * WM + i) * 32 + li;
+        hr00[i] = (mloc / TW) * PW + (mloc % TW);
+    }
+    const int sw = (li >> 2) & 3;
+    const int b_row = (wn * WN * 32 + li) * 64;
+    auto mma_tap = [&](int tap, int stage) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        int arow[WM], asw[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int hr = hr00[i] + ky * PW + kx;
+            arow[i] = hr * 64;
+            asw[i] = (hr >> 2) & 3;
+        }
+        const unsigned char* bst = bsm + stage * NP * B_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kg = 2 * s + h;
+            bf16x8 af[NP][WM], bfr[NP][WN];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    af[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * A_BYTES + arow[i] + 16 * (kg ^ asw[i]));
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    bfr[p][j] = *reinterpret_cast<const bf16x8*>(bst + p * B_BYTES + b_row + j * 2048 + 16 * (kg ^ sw));
+            }
+            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q) {
+                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // single weight stage, two barriers per K-step: a second resident block of the CU covers them (63 KB of LDS
+    // and <= 256 registers per block); the halo rewrite of a chunk switch shares the barrier pair.
+    load_halo(chunk_c0(0));
+    store_halo();
+    load_b(0, chunk_c0(0));
+    store_b();
+    __syncthreads();
+    int ci = 0, tap = 0;
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const bool more = ks + 1 < nsteps;
+        const bool next_chunk = ci + 1 < kchunks;
+        if (more) {
+            int t1 = tap + 1, c1 = ci;
+            if (t1 == 9) { t1 = 0; ++c1; }
+            load_b(t1, chunk_c0(c1));
+        }
+        if (tap == 0 && next_chunk) load_halo(chunk_c0(ci + 1));   // waits in registers for nine taps
+        mma_tap(tap, 0);
+        __syncthreads();
+        if (more) store_b();
+        if (tap == 8 && next_chunk) store_halo();
+        __syncthreads();
+        if (++tap == 9) { tap = 0; ++ci; }
+    }
+    conv_epilogue<WM, WN, 2, PatchRows<TW>>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
+                                            li, h);
+}
+
 template <int TW, int WN>
 static int launch_split_halo(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
     const int tiles_m = M / 256, tiles_n = Cout / (64 * WN);
@@ -490,6 +675,17 @@ static int launch_split_halo(const rpnet_conv_desc* d, int M, int Cin, int Cout,
     else
         hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 2, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split_halo");
+}
+
+template <int TW, int WN>
+static int launch_split_halo4(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+    const int tiles_m = M / 128, tiles_n = Cout / (64 * WN);
+    const int ntiles = tiles_m * tiles_n;
+    if (d->split_planes == 3)
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 2, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    return check_launch("conv_igemm_split_halo4");
 }
 
 // tile width of the halo variant: 128 output channels per block when they split that way, else 64
@@ -516,6 +712,7 @@ static const SplitVariant kSplitVariants[] = {
     {4, 2, 2, 0, 256},    // 5: 256 x 128, 8 waves, one stage
     {2, 2, 2, 1, 256},    // 6: 128 x 128 two stages
     {4, 2, 2, 1, 256},    // 7: 256 x 128 on an image patch, input halo resident in LDS (conv_igemm_split_halo_kernel)
+    {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -533,17 +730,29 @@ static int launch_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipS
     return check_launch("conv_igemm_split");
 }
 
+// 128-pixel patch variant: (128 / TW) x TW patches
+static int halo4_tw(const rpnet_conv_desc* d) {
+    if (d->taps != 9 || d->dilation > 1) return 0;
+    if (d->W % 32 == 0 && d->H % 4 == 0) return 32;
+    if (d->W % 16 == 0 && d->H % 8 == 0) return 16;
+    return 0;
+}
+
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const char* e = getenv("RPNET_SPLIT_TILE");   // tuning override (tools/bench_conv_split.py)
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (e) {
         const int v = atoi(e);
-        if (v == 7 && halo_tw(d, Cout)) return v;
+        if ((v == 7 && halo_tw(d, Cout)) || (v == 8 && halo4_tw(d))) return v;
         if (v >= 0 && v < 7 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
-    if (halo_tw(d, Cout) && (long)(M / 256) * (Cout / halo_bn(d, Cout)) >= 224) return 7;
+    // halo-resident patch kernels: 256 x 128 with one 8-wave block per CU when that grid fills the machine, else (and
+    // for 64-wide output tiles) 128-pixel patches with two 4-wave blocks per CU
+    const int hbn = halo_bn(d, Cout);
+    if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224) return 7;
+    if (halo4_tw(d) && (long)(M / 128) * (Cout / hbn) >= 128) return 8;
     int best = -1;
     double best_fill = -1.0;
     for (int c = 0; c < 4; ++c) {
@@ -572,6 +781,10 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 4: return launch_split<4, 2, 2, true>(d, M, Cin, Cout, s);
         case 5: return launch_split<4, 2, 2, false>(d, M, Cin, Cout, s);
         case 6: return launch_split<2, 2, 2, true>(d, M, Cin, Cout, s);
+        case 8:
+            if (halo_bn(d, Cout) == 128)
+                return halo4_tw(d) == 32 ? launch_split_halo4<32, 2>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2>(d, M, Cin, Cout, s);
+            return halo4_tw(d) == 32 ? launch_split_halo4<32, 1>(d, M, Cin, Cout, s) : launch_split_halo4<16, 1>(d, M, Cin, Cout, s);
         default:
             if (halo_bn(d, Cout) == 128)
                 return halo_tw(d, Cout) == 32 ? launch_split_halo<32, 2>(d, M, Cin, Cout, s) : launch_split_halo<16, 2>(d, M, Cin, Cout, s);
