@@ -209,6 +209,16 @@ static int corr_fwd_launch(const float* f1, const float* f2, float* corr, int B,
     return check_launch("local_corr_fwd");
 }
 
+// dcT for the split-bf16 backward (corr_split.hip)
+int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, int cstride, int r, hipStream_t s) {
+    const size_t total = (size_t)B * h * w * cstride;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 16384) nb = 16384;
+    if (r != 5) { set_error("corr_transpose: radius %d", r); return RPNET_ERR_SHAPE; }
+    hipLaunchKernelGGL((corr_transpose_kernel<5>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
+    return check_launch("corr_transpose");
+}
+
 }  // namespace rpnet
 
 #define RPNET_CORR_DISPATCH(R_, ...)                         \

@@ -1,0 +1,317 @@
+// Local-window correlation (Correlation(), net/rp_net.py:153-181; definition in corr.hip) and its gradients on
+// the bf16 matrix pipe with split-bf16 operands (the arithmetic of conv_split.hip: fp32 value = NP exact bf16
+// planes, NP = 3 -> six partial products, fp32 accumulate).
+//
+// Forward: a block owns an 8x8 pixel tile p and the (8 + 2R)^2 halo q of f2 around it and computes the dense
+// 64 x NQ score matrix S[p][q] = <f1[p,:], f2[q,:]> as a GEMM over the channels (K = C, 32 per step) — 2.9x more
+// products than the (2R+1)^2 window needs, on a pipe that is 16x the VALU; the window is then gathered out of S
+// through LDS and written as one contiguous [cstride] row per pixel.  Both operands are [pixel][channel] with the
+// channel contiguous = K-contiguous: the LDS images and fragment reads are those of the convolution kernels.
+//
+// Backward (one kernel, SIGN = +1 for d f1 from (dcorr, f2), SIGN = -1 for d f2 from (dcorr transposed, f1)):
+// df[p][ch] = sum_q G[p][q] fo[q][ch] with G the window gradient scattered onto the halo positions (zero outside
+// the window) — a GEMM over K = NQ halo positions.  G's 32-column slabs are built in LDS from the fp32 gradient
+// tile and split on the fly; fo's halo is [q][channel], i.e. K is the ROW index, so its fragments come from
+// ds_read_b64_tr_b16 as in conv_wgrad_split.hip.  A block computes 64 pixels x 128 channels.
+#include "common.h"
+#include "split_bf16.h"
+
+namespace rpnet {
+
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4c;
+
+template <int R, int NP>
+__global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsigned short* __restrict__ f1s,
+                                                                      const unsigned short* __restrict__ f2s,
+                                                                      float* __restrict__ corr, const int B, const int h,
+                                                                      const int w, const int C, const int cstride,
+                                                                      const float inv_sqrt_c) {
+    constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NT_N = (NQ + 31) / 32, NQP = NT_N * 32;
+    constexpr int A_BYTES = 64 * 64, B_BYTES = NQP * 64;            // one plane: [row][32 channels]
+    constexpr int BJ = (NQ * 4 + 255) / 256;                        // halo pieces per thread and plane
+    constexpr int JT = (NT_N + 3) / 4;                              // N tiles per wave
+    constexpr int SMEM = NP * (A_BYTES + B_BYTES) > 32 * NQP * 4 ? NP * (A_BYTES + B_BYTES) : 32 * NQP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    unsigned char* const bsm = smem + NP * A_BYTES;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    const int tiles_x = (w + 7) / 8;
+    const int b = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
+    const size_t plane = (size_t)B * h * w * C, img = (size_t)b * h * w * C;
+
+    __amdgpu_buffer_rsrc_t r1[NP], r2[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        r1[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(f1s + p * plane + img), (short)0, h * w * C * 2, 0x00020000);
+        r2[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(f2s + p * plane + img), (short)0, h * w * C * 2, 0x00020000);
+    }
+    const int skg = t & 3;
+    // f1 tile piece: row t >> 2 (pixel of the tile), k-group t & 3
+    int aoff, adst;
+    {
+        const int row = t >> 2, y = ty0 + (row >> 3), x = tx0 + (row & 7);
+        aoff = (y < h && x < w) ? (y * w + x) : -1;
+        adst = row * 64 + 16 * (skg ^ ((row >> 2) & 3));
+    }
+    int boff[BJ], bdst[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int e = t + 256 * j, q = e >> 2;
+        const int y = ty0 + q / HT - R, x = tx0 + q % HT - R;
+        boff[j] = (e < NQ * 4 && y >= 0 && y < h && x >= 0 && x < w) ? (y * w + x) : -1;
+        bdst[j] = e < NQ * 4 ? q * 64 + 16 * (skg ^ ((q >> 2) & 3)) : -1;
+    }
+    // rows NQ .. NQP-1 of the halo image are never gathered; keep them finite
+    for (int e = t; e < NP * (NQP - NQ) * 4; e += 256) {
+        const int p = e / ((NQP - NQ) * 4), r = e - p * ((NQP - NQ) * 4);
+        *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + NQ * 64 + r * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    f32x16 acc[2][JT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<u32x4*>(smem + p * A_BYTES + adst) =
+                __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r1[p], aoff * (C * 2) + skg * 16, c0 * 2, 0));
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r2[p], boff[j] * (C * 2) + skg * 16, c0 * 2, 0));
+                if (bdst[j] >= 0) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + bdst[j]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = 16 * ((2 * s + hh) ^ sw);
+            bf16x8 af[NP][2], bfr[NP][JT];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(smem + p * A_BYTES + (i * 32 + li) * 64 + koff);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const int jt = wv + 4 * j;
+                    bfr[p][j] = *reinterpret_cast<const bf16x8*>(bsm + p * B_BYTES + ((jt < NT_N ? jt : 0) * 32 + li) * 64 + koff);
+                }
+            }
+            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q) {
+                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
+                    if (wv + 4 * j < NT_N) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // gather the (2R+1)^2 window of every pixel out of S, half a tile (32 pixels) at a time
+    float* S = reinterpret_cast<float*>(smem);          // [32][NQP]
+    float* cb = corr + (size_t)b * h * w * cstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int jt = wv + 4 * j;
+            if (jt < NT_N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * hh) * NQP + jt * 32 + li] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < 32 * cstride; e += 256) {
+            const int pl = e / cstride, o = e - pl * cstride;
+            const int py = i * 4 + (pl >> 3), px = pl & 7;
+            const int y = ty0 + py, x = tx0 + px;
+            float v = 0.f;
+            if (o < KK) {
+                const int a = o / K, c = o - a * K;
+                v = S[pl * NQP + (py + c) * HT + px + a] * inv_sqrt_c;
+            }
+            if (y < h && x < w) cb[((size_t)y * w + x) * cstride + o] = v;
+        }
+    }
+}
+
+// df[b,p,ch] = inv_sqrt_c * sum_o g[b,p,o] * fo[b, p + SIGN*off(o), ch]   (see corr.hip)
+template <int R, int NP, int SIGN>
+__global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float* __restrict__ g, const unsigned short* __restrict__ fos,
+                                                                      float* __restrict__ df, const int B, const int h,
+                                                                      const int w, const int C, const int cstride,
+                                                                      const float inv_sqrt_c) {
+    constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NCH = (NQ + 31) / 32, GS = (KK + 3) & ~3;
+    constexpr int BN = 128, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
+    constexpr int A_BYTES = 64 * 64, B_BYTES = 32 * RSB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[64 * GS * 4 + NP * (A_BYTES + B_BYTES)];
+    float* gs = reinterpret_cast<float*>(smem);                     // [64][GS] window gradients of the tile
+    unsigned char* const asm_ = smem + 64 * GS * 4;
+    unsigned char* const bsm = asm_ + NP * A_BYTES;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    const int tiles_x = (w + 7) / 8;
+    const int b = blockIdx.z, n0 = blockIdx.y * BN;
+    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
+    const size_t plane = (size_t)B * h * w * C, img = (size_t)b * h * w * C;
+    __amdgpu_buffer_rsrc_t rf[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        rf[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(fos + p * plane + img), (short)0, h * w * C * 2, 0x00020000);
+
+    const float* gb = g + (size_t)b * h * w * cstride;
+    for (int e = t; e < 64 * GS; e += 256) {
+        const int p = e / GS, o = e - p * GS;
+        const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
+        gs[e] = (o < KK && y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] * inv_sqrt_c : 0.f;
+    }
+    // G slab piece of this thread: pixel row ap = t >> 2 (py, px), k-group t & 3
+    const int ap = t >> 2, apy = ap >> 3, apx = ap & 7, akg = t & 3;
+    const int adst = ap * 64 + 16 * (akg ^ ((ap >> 2) & 3));
+    // fo slab pieces: rows (t >> 4) + 16 j, 16-byte piece t & 15
+    const int brow = t >> 4, bpc = (t & 15) * 16;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int gq = lane >> 4, L = lane & 15;
+    const int b_lane = (8 * (gq >> 1) + (L >> 2)) * RSB + (wv * 32 + 16 * (gq & 1) + 4 * (L & 3)) * 2;
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int q0 = ch * 32;
+        __syncthreads();      // previous slab consumed (and gs complete on the first pass)
+        {   // G[p][q0 + 8 akg .. +7]
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = q0 + akg * 8 + i;
+                const int qy = q / HT, qx = q - qy * HT;
+                const int c = SIGN > 0 ? qy - apy : apy + 2 * R - qy;
+                const int a = SIGN > 0 ? qx - apx : apx + 2 * R - qx;
+                const bool in = q < NQ && c >= 0 && c < K && a >= 0 && a < K;
+                v[i] = in ? gs[ap * GS + a * K + c] : 0.f;
+            }
+            u32x4 o[NP];
+            split8<NP>(v, o);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(asm_ + p * A_BYTES + adst) = o[p];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = brow + 16 * j, q = q0 + r;
+            const int y = ty0 + q / HT - R, x = tx0 + q % HT - R;
+            const int voff = (q < NQ && y >= 0 && y < h && x >= 0 && x < w) ? (y * w + x) * (C * 2) + bpc : (int)0x80000000;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + r * RSB + bpc) =
+                    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rf[p], voff, n0 * 2, 0));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int koff = 16 * ((2 * s + hh) ^ sw);
+            bf16x8 af[NP][2], bfr[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(asm_ + p * A_BYTES + (i * 32 + li) * 64 + koff);
+                const unsigned char* bp = bsm + p * B_BYTES + b_lane + 16 * s * RSB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)bp);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(bp + 4 * RSB));
+                bfr[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+#pragma unroll
+            for (int q = 0; q < NPROD; ++q) {
+                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float* dfb = df + (size_t)b * h * w * C;
+    const int col = n0 + wv * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
+            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = acc[i][r];
+        }
+}
+
+int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, int cstride, int r, hipStream_t s);   // corr.hip
+
+}  // namespace rpnet
+
+extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, float* corr, int B, int h, int w, int C, int r,
+                                          int cstride, int planes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
+    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && (planes == 2 || planes == 3), RPNET_ERR_SHAPE,
+                  "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d", r, C, cstride, planes);
+    RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_fwd: image too large");
+    const int tiles = cdiv(h, 8) * cdiv(w, 8);
+    const float isc = 1.0f / sqrtf((float)C);
+    const unsigned short* a = (const unsigned short*)f1s;
+    const unsigned short* b2 = (const unsigned short*)f2s;
+    if (planes == 3)
+        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc);
+    return check_launch("local_corr_split_fwd");
+}
+
+extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, const float* dcorr, float* df1, float* df2, int B,
+                                          int h, int w, int C, int r, int cstride, int planes, void* workspace,
+                                          size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(f1s && f2s && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_split_bwd: null pointer");
+    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 2 || planes == 3), RPNET_ERR_SHAPE,
+                  "local_corr_split_bwd: r=%d (5) C=%d (multiple of 128) cstride=%d planes=%d", r, C, cstride, planes);
+    RPNET_REQUIRE(workspace_bytes >= rpnet_local_corr_bwd_workspace_bytes(B, h, w, cstride), RPNET_ERR_WORKSPACE,
+                  "local_corr_split_bwd: workspace too small");
+    RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_bwd: image too large");
+    hipStream_t s = (hipStream_t)stream;
+    float* dct = (float*)workspace;
+    const float isc = 1.0f / sqrtf((float)C);
+    const int tiles = cdiv(h, 8) * cdiv(w, 8);
+    const unsigned short* a = (const unsigned short*)f1s;
+    const unsigned short* b2 = (const unsigned short*)f2s;
+    const dim3 grid(tiles, C / 128, B);
+    if (planes == 3)
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc);
+    if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;
+    if (planes == 3)
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc);
+    return check_launch("local_corr_split_bwd");
+}

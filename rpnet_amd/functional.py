@@ -487,27 +487,38 @@ CORR_STRIDE = 128  # (2*5+1)^2 = 121 window channels padded to a GEMM-friendly 1
 
 
 class LocalCorr(Function):
-    """Correlation(fm1, fm2, r) (net/rp_net.py:153-181), NHWC, output [B,h,w,128] (zero padded)."""
+    """Correlation(fm1, fm2, r) (net/rp_net.py:153-181), NHWC, output [B,h,w,128] (zero padded).  With the split
+    arithmetic on (and r = 5, C % 128 == 0) it runs on the bf16 matrix pipe from the split planes of fm1 / fm2."""
 
     @staticmethod
     def forward(ctx, f1, f2, r):
         B, h, w, Cc = f1.shape
         corr = _empty((B, h, w, CORR_STRIDE), f1)
-        call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
-        ctx.save_for_backward(f1, f2)
-        ctx.r = r
+        np_ = _MATH["planes"] if (r == 5 and Cc % 128 == 0) else 0
+        if np_:
+            f1s, f2s = _split_operand(f1, np_), _split_operand(f2, np_)
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_)
+            ctx.save_for_backward(f1s, f2s)
+        else:
+            call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
+            ctx.save_for_backward(f1, f2)
+        ctx.r, ctx.np_, ctx.shape = r, np_, tuple(f1.shape)
         return corr
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dcorr):
         f1, f2 = ctx.saved_tensors
-        B, h, w, Cc = f1.shape
-        df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+        B, h, w, Cc = ctx.shape
+        df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
-        ws = _ws(wb, f1)
-        call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
-             CORR_STRIDE, ptr(ws), wb)
+        ws = _ws(wb, dcorr)
+        if ctx.np_:
+            call("rpnet_local_corr_split_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc,
+                 ctx.r, CORR_STRIDE, ctx.np_, ptr(ws), wb)
+        else:
+            call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
+                 CORR_STRIDE, ptr(ws), wb)
         return df1, df2, None
 
 

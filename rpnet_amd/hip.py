@@ -54,6 +54,8 @@ _SIGS = {
     "rpnet_local_corr_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_mask_adjoint": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_masked_pool_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_masked_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),

@@ -209,8 +209,9 @@ class ContextCorrelationEncoder(nn.Module):
         (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC, mask [B,h,w] or None."""
         t = self.training
         m1, m2 = (1, 2) if mask is not None else (0, 0)
-        fm1 = RF.conv_bn_relu(fts, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=False)
-        fm2 = RF.conv_bn_relu(fts, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=False)
+        sp = self.radius == 5        # the correlation then takes the split planes of fm1 / fm2
+        fm1 = RF.conv_bn_relu(fts, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp)
+        fm2 = RF.conv_bn_relu(fts, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp)
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
@@ -222,8 +223,8 @@ class ContextCorrelationEncoder(nn.Module):
     def forward(self, fm1, fm2):
         cache = RF.WeightCache()
         t = self.training
-        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=False)
-        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=False)
+        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=self.radius == 5)
+        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=self.radius == 5)
         return _to_nchw(self._tail(a, b, cache))
 
 
