@@ -713,6 +713,7 @@ static const SplitVariant kSplitVariants[] = {
     {2, 2, 2, 1, 256},    // 6: 128 x 128 two stages
     {4, 2, 2, 1, 256},    // 7: 256 x 128 on an image patch, input halo resident in LDS (conv_igemm_split_halo_kernel)
     {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
+    {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -744,7 +745,7 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (e) {
         const int v = atoi(e);
-        if ((v == 7 && halo_tw(d, Cout)) || (v == 8 && halo4_tw(d))) return v;
+        if ((v == 7 && halo_tw(d, Cout)) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
         if (v >= 0 && v < 7 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
@@ -752,7 +753,11 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     // for 64-wide output tiles) 128-pixel patches with two 4-wave blocks per CU
     const int hbn = halo_bn(d, Cout);
     if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224) return 7;
-    if (halo4_tw(d) && (long)(M / 128) * (Cout / hbn) >= 128) return 8;
+    if (halo4_tw(d)) {
+        const long t8 = (long)(M / 128) * (Cout / hbn);
+        if (t8 >= 256) return 8;
+        if (t8 >= 64) return hbn == 128 ? 9 : 8;       // 64-wide tiles: twice the blocks on a grid that small
+    }
     int best = -1;
     double best_fill = -1.0;
     for (int c = 0; c < 4; ++c) {
@@ -781,6 +786,8 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 4: return launch_split<4, 2, 2, true>(d, M, Cin, Cout, s);
         case 5: return launch_split<4, 2, 2, false>(d, M, Cin, Cout, s);
         case 6: return launch_split<2, 2, 2, true>(d, M, Cin, Cout, s);
+        case 9:
+            return halo4_tw(d) == 32 ? launch_split_halo4<32, 1>(d, M, Cin, Cout, s) : launch_split_halo4<16, 1>(d, M, Cin, Cout, s);
         case 8:
             if (halo_bn(d, Cout) == 128)
                 return halo4_tw(d) == 32 ? launch_split_halo4<32, 2>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2>(d, M, Cin, Cout, s);
