@@ -321,45 +321,65 @@ void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split, in
 }
 
 // partial [ksplit][taps][Cin_g][Cout]  ->  dw [Cout][cin_w][taps]
-// grid (cin/32, cout/32, taps): a block sums one 32x32 tile of one tap over the K splits
+// grid (cin/32, cout/32[, taps]): a block sums one 32x32 tile (of one tap, or of all taps) over the K splits
 // (8 row groups x 32 lanes read 128-byte rows of every split) and writes it transposed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                             int ksplit, int taps, int Cin_g, int Cout, int cin_w,
                                                             int off0, int split, int off1, int accumulate) {
-    __shared__ float tile[32][33];
+    // one block = a 32 (cin) x 32 (cout) tile of ALL taps: the sums over the K splits land in LDS as
+    // [tap][cin][cout] and leave as rows of 32 cin x taps contiguous floats per output channel — the
+    // state_dict layout [Cout][Cin][taps] written with full lines instead of 4-byte pieces 36 bytes apart
+    __shared__ float tile[9][32][33];
     const int t = threadIdx.x;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int cl = t & 31;
     const size_t zstride = (size_t)taps * Cin_g * Cout;
+    // gridDim.z == taps: one tap per block (small layers: more blocks matter more than full-line writes)
+    const int tap_lo = gridDim.z > 1 ? blockIdx.z : 0, tap_hi = gridDim.z > 1 ? blockIdx.z + 1 : taps;
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int rr = (t >> 5) + 8 * jj;
-        const int cin = ci0 + rr;
-        float s = 0.f;
-        if (cin < cin_w) {
-            const int row = cin < split ? off0 + cin : off1 + (cin - split);
-            const float* p = partial + ((size_t)tap * Cin_g + row) * Cout + co0 + cl;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int z = 0;
-            for (; z + 4 <= ksplit; z += 4) {
-                s0 += p[(size_t)z * zstride]; s1 += p[(size_t)(z + 1) * zstride];
-                s2 += p[(size_t)(z + 2) * zstride]; s3 += p[(size_t)(z + 3) * zstride];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int rr = (t >> 5) + 8 * jj;
+            const int cin = ci0 + rr;
+            float s = 0.f;
+            if (cin < cin_w) {
+                const int row = cin < split ? off0 + cin : off1 + (cin - split);
+                const float* p = partial + ((size_t)tap * Cin_g + row) * Cout + co0 + cl;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int z = 0;
+                for (; z + 4 <= ksplit; z += 4) {
+                    s0 += p[(size_t)z * zstride]; s1 += p[(size_t)(z + 1) * zstride];
+                    s2 += p[(size_t)(z + 2) * zstride]; s3 += p[(size_t)(z + 3) * zstride];
+                }
+                for (; z < ksplit; ++z) s0 += p[(size_t)z * zstride];
+                s = (s0 + s1) + (s2 + s3);
             }
-            for (; z < ksplit; ++z) s0 += p[(size_t)z * zstride];
-            s = (s0 + s1) + (s2 + s3);
+            tile[tap][rr][cl] = s;
         }
-        tile[rr][cl] = s;
     }
     __syncthreads();
-    // thread -> (cout = t >> 3, 4 consecutive cin): writes are taps*4 B apart along cin
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int col = t >> 3, c = (t & 7) * 4 + jj;
-        if (ci0 + c < cin_w) {
-            float* o = dw + ((size_t)(co0 + col) * cin_w + ci0 + c) * taps + tap;
-            *o = accumulate ? *o + tile[c][col] : tile[c][col];
+    const int ncin = min(32, cin_w - ci0);
+    if (gridDim.z > 1) {
+        for (int e = t; e < 32 * ncin; e += 256) {
+            const int col = e / ncin, c = e - col * ncin;
+            float* o = dw + ((size_t)(co0 + col) * cin_w + ci0 + c) * taps + tap_lo;
+            *o = accumulate ? *o + tile[tap_lo][c][col] : tile[tap_lo][c][col];
         }
+        return;
     }
+    const int rowlen = ncin * taps;               // contiguous floats per output channel
+    for (int e = t; e < 32 * rowlen; e += 256) {
+        const int col = e / rowlen, r = e - col * rowlen;
+        const int c = r / taps, tap = r - c * taps;
+        float* o = dw + ((size_t)(co0 + col) * cin_w + ci0) * taps + r;
+        *o = accumulate ? *o + tile[tap][c][col] : tile[tap][c][col];
+    }
+}
+
+// grid of the reduce: all taps per block (full-line writes) once there are enough 32 x 32 tiles to fill the machine
+static dim3 reduce_grid(int cin_w, int Cout, int taps) {
+    const int tx = cdiv(cin_w, 32), ty = Cout / 32;
+    return dim3(tx, ty, (long)tx * ty >= 256 ? 1 : taps);
 }
 
 // w [Cout][cin_w][taps] -> wp [taps][Cin_g/4][Cout][4] (+ wd [taps][Cout/4][Cin_g][4], taps flipped)
@@ -463,7 +483,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
             RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
                           "conv_wgrad: split operands take 2 or 3 planes and no in_scale");
             if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
                                Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
             return check_launch("wgrad_reduce");
         }
@@ -478,7 +498,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
 #undef RPNET_W9
         int rc9 = check_launch("conv_wgrad9");
         if (rc9) return rc9;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
                            Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
         return check_launch("wgrad_reduce");
     }
@@ -500,7 +520,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, *d, dy, part, M, Cin, Cout, tiles_n, sps);
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cin_w, 32), Cout / 32, d->taps), dim3(256), 0, s, part, dw, ks, d->taps,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, d->taps), dim3(256), 0, s, part, dw, ks, d->taps,
                        Cin, Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
     return check_launch("wgrad_reduce");
 }
