@@ -105,7 +105,7 @@ typedef struct rpnet_conv_desc {
     int upsample;                      /* sources are [N][H/2][W/2][C] */
     int groups;                        /* for ep_scale/ep_shift rows and the statistics below */
     int dilation;                      /* 3x3 tap spacing: 0/1 = dense, 2 = the dilated last VGG block (net/vgg.py:31) */
-    double* stats_partial;             /* optional: per (M-tile half, channel) sum / sum-of-squares of the
+    double* stats_partial;             /* optional: per (M tile, channel) sum / sum-of-squares of the
                                           output, [groups * rpnet_conv_stats_blocks()][Cout][2] — the
                                           train-mode BatchNorm batch statistics fused into the epilogue */
     int split_planes;                  /* 0: x0/x1/w are fp32 (v_mfma_f32_32x32x2_f32).  2 or 3: x0/x1/w point at

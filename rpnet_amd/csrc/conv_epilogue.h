@@ -20,13 +20,18 @@ struct PatchRows {    // the block's rows walk a (rows / TW) x TW patch of one i
 template <int WM, int WN, int WGM = 2, typename RowMap = LinearRows>
 __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows,
                                               const int M, const int Cout, const int HW, const int n0, const int tm,
-                                              const int wm, const int wn, const int li, const int h) {
+                                              const int wm, const int wn, const int li, const int h, void* lds) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
     if (d.stats_partial) {
         // train-mode BatchNorm statistics of y = acc + bias, fused: this wave's 32*WM rows of each of
-        // its columns -> one (sum, sum of squares) pair per column; the two lane halves hold the same
-        // columns.  Row blocks never straddle a statistic group (host-checked).
+        // its columns -> one (sum, sum of squares) pair per column (the two lane halves hold the same
+        // columns); the WGM wave rows of the block are then added up through LDS (`lds`: the kernel's
+        // staging memory, free by now) so that ONE partial row per block tile goes to memory.
+        // Row blocks never straddle a statistic group (host-checked).
+        constexpr int BNC = 64 * WN;
+        double* red = reinterpret_cast<double*>(lds);     // [WGM][BNC][2]
+        __syncthreads();                                   // every wave is done with the staging memory
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn * WN * 32 + j * 32 + li;
@@ -44,10 +49,17 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             sm += __shfl_xor(sm, 32, 64);
             sq += __shfl_xor(sq, 32, 64);
             if (h == 0) {
-                double* o = d.stats_partial + ((size_t)(tm * WGM + wm) * Cout + col) * 2;
+                double* o = red + ((size_t)wm * BNC + wn * WN * 32 + j * 32 + li) * 2;
                 o[0] = (double)sm;
                 o[1] = (double)sq;
             }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < BNC * 2; e += WGM * 128) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int r = 0; r < WGM; ++r) sacc += red[(size_t)r * BNC * 2 + e];
+            d.stats_partial[((size_t)tm * Cout + n0) * 2 + e] = sacc;
         }
     }
 #pragma unroll

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
         __syncthreads();
     }
 
-    conv_epilogue<WM, WN>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h);
+    conv_epilogue<WM, WN>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h, smem);
 }
 
 template <int WM, int WN, bool INSCALE>
@@ -246,7 +246,7 @@ extern "C" int rpnet_conv_stats_blocks(const rpnet_conv_desc* d) {
     }
     const long per_group = (long)(d->N / d->groups) * d->H * d->W;
     if (per_group % bm) return 0;
-    return (int)(per_group / bm) * wave_rows;
+    return (int)(per_group / bm);        // one partial row per block tile (the wave rows are summed in the epilogue)
 }
 
 extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {

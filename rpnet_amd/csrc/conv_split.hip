@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
             __syncthreads();
         }
     }
-    conv_epilogue<WM, WN, WGM>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h);
+    conv_epilogue<WM, WN, WGM>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h, smem);
 }
 
 // 256 x 128 tile whose 256 output pixels are a (256 / TW) x TW PATCH of one image, 8 waves (4 x 2), 3x3 taps only.
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
         }
     }
     conv_epilogue<WM, WN, 4, PatchRows<TW>>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
-                                            li, h);
+                                            li, h, smem);
 }
 
 template <int TW, int NP, int WN>
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
         if (++tap == 9) { tap = 0; ++ci; }
     }
     conv_epilogue<WM, WN, 2, PatchRows<TW>>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
-                                            li, h);
+                                            li, h, smem);
 }
 
 template <int TW, int WN>
