@@ -145,6 +145,34 @@ def pmc_traffic():
     return round(b / n) if n else None
 
 
+def conv_accuracy_probe(dev):
+    """max |err| / max |ref| of one 3x3 convolution (2x32x32, 256 -> 256) against an fp64 CPU reference under each
+    arithmetic: the evidence that the default split arithmetic is fp32-accurate (same probe as
+    tests/test_gpu_ops.py::test_split_conv_accuracy, forward only)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    import rpnet_amd.functional as RF
+    from rpnet_amd.hip import call
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 32, 32, 256, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) * 0.05
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    xd, wd = x.to(dev), w.to(dev)
+    pw = RF.PackedWeight(wd)
+    out = {}
+    for name, planes in (("f32", 0), ("bf16x3", 3), ("bf16x2", 2)):
+        y = torch.empty(2, 32, 32, 256, device=dev)
+        if planes:
+            xs = RF.split_bf16(xd, planes)
+            d = RF._desc(xs[0], None, pw.split_packs(planes)[0], None, None, 0, y, None, 2, 32, 32, 9, 0)
+            d.split_planes = planes
+        else:
+            d = RF._desc(xd, None, pw.wp, None, None, 0, y, None, 2, 32, 32, 9, 0)
+        call("rpnet_conv_fwd", C.byref(d))
+        out[name] = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    return out
+
+
 def cpu_baseline(cfg, size, T, seconds_budget=25.0):
     """The CPU oracle in as-written mode (the reference's operator sequence: all-pairs
     correlation + grid_sample, explicit bilinear up-sampling in getFeatures, prototypes per
@@ -306,6 +334,8 @@ def main():
         }
         if alt:
             result["alt_math"] = alt
+        if world == 1 and not args.no_cpu_baseline:
+            result["conv_math_error_vs_fp64"] = {k: float(f"{v:.3g}") for k, v in conv_accuracy_probe(dev).items()}
         if world == 1 and not args.no_cpu_baseline and args.shots == 1:
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
