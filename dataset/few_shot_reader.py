@@ -1,16 +1,19 @@
 """`dataset.few_shot_reader.FewshotRegReader` with the item contract test_rpnet.py consumes
 (test_rpnet.py:70,166-184; reference dataset/few_shot_reader.py:592-650).
 
-The reference reader needs the private ABD-110 NRRD volumes plus nrrd / nibabel / SimpleITK
-and a per-slice registration optimiser; none exists offline.  This reader serves SYNTHETIC
-volumes with the same keys, shapes and dtypes (rpnet_amd.utils.synth), so the evaluation
-loop runs end to end on the MI355X path.  Real-data reading is §8(f).4 and raises.
+The reference reader needs the private ABD-110 NRRD volumes plus nrrd / nibabel / SimpleITK; none exists offline.  This reader serves SYNTHETIC volumes with the same keys, shapes and dtypes
+(rpnet_amd.utils.synth), so the evaluation loop runs end to end on the MI355X path.  Real-data reading is
+§8(f).4 and raises.  The per-slice registration pre-step of the reference reader (few_shot_reader.py:556-566:
+`use_registration_loss`, `do_deformable: False`) is `get_registration_field` = rpnet_amd.registration (one HIP
+launch for all slices); on a GPU box the reader derives `appr_query_labels` from it exactly as the reference does
+(:608), elsewhere it serves the generator's approximate labels.
 """
 import os
 
 import numpy as np
 import torch
 
+from rpnet_amd.registration import get_registration_field  # noqa: F401  (reference few_shot_reader.py:109, HIP path)
 from rpnet_amd.utils.synth import make_episode
 
 
@@ -48,8 +51,17 @@ class FewshotRegReader(torch.utils.data.Dataset):
         ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, H), indexing="ij")
         grid = torch.stack([xs, ys], -1)[None].repeat(S, 1, 1, 1)
         supp_idx = (vol + 1) % self.n_volumes
-        return {"support_images": [[supp_img]], "support_labels": [[supp_lab]], "warped_supp": supp_img[:, 0],
+        item = {"support_images": [[supp_img]], "support_labels": [[supp_lab]], "warped_supp": supp_img[:, 0],
                 "query_images": t(ep["query_images"]), "query_labels": t(ep["query_labels"]),
                 "appr_query_labels": t(ep["appr_query_labels"]), "grid": grid, "class_id": class_id,
                 "pid": self.fewshot_reader.fewshot_volume_reader.data_info[class_id][vol]["pid"],
                 "supp_pids": [(class_id, supp_idx)], "registration_field": None}
+        if self.config.get("use_registration_loss", False) and torch.cuda.is_available():
+            # reference few_shot_reader.py:556-566,582,608: warp the support label onto the query slice by slice
+            field, reg_pred, warped_src, aff_pred, aff_src = get_registration_field(
+                item["query_images"], item["support_images"], item["support_labels"],
+                do_deformable=self.config.get("do_deformable", True))
+            item.update({"registration_field": field, "warped_supp": torch.from_numpy(warped_src),
+                         "warped_supp_label": reg_pred, "affine_warped_supp": torch.from_numpy(aff_src),
+                         "affine_warped_supp_label": aff_pred, "appr_query_labels": (reg_pred[:, 0] > 0.5).float()})
+        return item

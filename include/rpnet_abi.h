@@ -284,6 +284,27 @@ int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, const float* s
 int rpnet_argmax_masks(const float* pred, float* masks, float* counts, int B, int K, int hw, rpnet_stream_t stream);
 int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, size_t n, rpnet_stream_t stream);
 
+/* ------------------------------------------------- registration pre-step
+ * dataset/few_shot_reader.py:109-198 get_registration_field with do_deformable=False (yamls/example.yml:101):
+ * per slice, AffineRegistration (net/registration.py:316-357): theta [2][3] from identity by `iters` steps of
+ * torch.optim.Adam(lr, betas, eps) on MSE(grid_sample(moving, affine_grid(theta)), fixed) (align_corners=False,
+ * zero padding).  ONE launch: a block per slice runs the whole optimisation; slices in parallel.
+ * moving / fixed [B][H][W] in [0, 1]; xs [W], ys [H] = the base grid of F.affine_grid (torch.linspace(-1, 1, n) *
+ * (n - 1) / n, handed in so that the samples that sit exactly on pixel centres at theta = identity — a kink of the
+ * interpolant — round as in the reference); theta out [B][2][3]; loss out [B] (may be NULL) = MSE at the last
+ * evaluated theta.
+ * rpnet_affine_warp          out = post(grid_sample(x, affine_grid(theta)))        (:337-345)
+ * rpnet_identity_grid_warp   out = post(grid_sample(x, compute_grid()))            (:171-187,246-261: the demons stage
+ *                            with zero iterations: an align_corners=True identity grid sampled with align_corners=False)
+ * post(v) = scale * (threshold >= 0 ? (v > threshold) : v) + shift                  (few_shot_reader.py:168,172,190,196) */
+int rpnet_affine_register(const float* moving, const float* fixed, const float* xs, const float* ys, float* theta,
+                          float* loss, int B, int H, int W, int iters, float lr, float beta1, float beta2, float eps,
+                          rpnet_stream_t stream);
+int rpnet_affine_warp(const float* x, const float* theta, const float* xs, const float* ys, float* out, int B, int H, int W,
+                      float threshold, float scale, float shift, rpnet_stream_t stream);
+int rpnet_identity_grid_warp(const float* x, float* out, int B, int H, int W, float threshold, float scale, float shift,
+                             rpnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""CPU restatement of the reference's per-slice registration pre-step for the shipped configuration
+(yamls/example.yml: use_registration_loss: True, do_deformable: False).  TEST INFRASTRUCTURE ONLY: imported by
+tests/ and tools/bench_registration.py's cpu_baseline leg, never by the product path (rpnet_amd/registration.py,
+which has no CPU fallback).
+
+Follows, line by line:
+  dataset/few_shot_reader.py:109-198  get_registration_field: images to [0, 1] (:111-116), one
+      AffineDemonsRegistration per slice (:133), Adam(lr=0.01) on the affine theta (:147), iters=[50, 0] when
+      do_deformable is False (:135-137,152-161), warped label / source through registration(...) and
+      registration.affine_reg(...) (:166-180), label threshold 0.1 (:168,172), sources back to [-1, 1] (:190,196)
+  net/registration.py:316-357        AffineRegistration: theta = identity (:320-322), forward =
+      F.grid_sample(x, F.affine_grid(theta, x.size())) (:343-345, align_corners=False defaults), 50 x
+      {zero_grad, MSE(warped, fixed), backward, Adam.step} (:347-357)
+  net/registration.py:147-154        MSE = mean((y_true - y_pred)^2)
+  net/registration.py:474-488        AffineDemonsRegistration.forward = demons(affine_reg(x), grid)
+  net/registration.py:225-261        DemonsRegistration with zero iterations: flow = 0, the diffeomorphic
+      scaling-and-squaring of a zero field is zero (:195-212), so forward = F.grid_sample(x, grid^T) with
+  net/registration.py:171-187        compute_grid: coordinates 2 (j / (W - 1) - 0.5), i.e. an align_corners=True
+      identity grid sampled with align_corners=False (a zoom by W / (W - 1) about the corner)
+
+Pinned by tests/golden/registration.npz, produced by tests/golden/gen_golden_registration.py from the reference's
+own get_registration_field (which runs on the CPU in this configuration).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def compute_grid(h, w):
+    """net/registration.py:171-187 for a 2-D image: [1, 2, h, w], channel 0 = x, channel 1 = y."""
+    ys, xs = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
+    grid = torch.stack([xs, ys]).unsqueeze(0).float()
+    grid[:, 0] = 2 * (grid[:, 0] / (w - 1) - 0.5)
+    grid[:, 1] = 2 * (grid[:, 1] / (h - 1) - 0.5)
+    return grid
+
+
+def affine_warp(x, theta):
+    """AffineRegistration.forward (net/registration.py:337-345), x [1,1,h,w], theta [1,2,3]."""
+    return F.grid_sample(x, F.affine_grid(theta, x.size(), align_corners=False), align_corners=False)
+
+
+def identity_grid_warp(x):
+    """DemonsRegistration.forward with a zero flow (net/registration.py:246-261)."""
+    h, w = x.shape[-2:]
+    return F.grid_sample(x, compute_grid(h, w).permute(0, 2, 3, 1), align_corners=False)
+
+
+def affine_register(moving, fixed, iters=50, lr=0.01):
+    """AffineRegistration.train_registraion with torch.optim.Adam(lr) (net/registration.py:347-357,
+    few_shot_reader.py:147): moving / fixed [1,1,h,w] in [0,1] -> theta [1,2,3]."""
+    theta = torch.nn.Parameter(torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]]))
+    opt = torch.optim.Adam([theta], lr=lr)
+    for _ in range(iters):
+        opt.zero_grad()
+        loss = torch.mean((fixed - affine_warp(moving, theta)) ** 2)
+        loss.backward()
+        opt.step()
+    return theta.detach()
+
+
+def get_registration_field(query_images, support_images, support_labels, iters=50):
+    """dataset/few_shot_reader.py:109-198 with do_deformable=False.  query_images [S,1,h,w] in [-1,1],
+    support_images [[ [S,1,h,w] ]], support_labels [[ [S,h,w] ]].  Returns
+    (thetas [S,2,3], py_reg_pred [S,1,h,w], warped_src [S,h,w], py_affine_reg_pred [S,1,h,w],
+    affine_warped_src [S,h,w]) — the reference returns per-slice module objects in place of the thetas."""
+    src_all = (support_images[0][0][:, 0] + 1) / 2.0
+    dst_all = (query_images[:, 0] + 1) / 2.0
+    lab_all = support_labels[0][0]
+    thetas, reg, wsrc, areg, asrc = [], [], [], [], []
+    for s in range(dst_all.shape[0]):
+        src, dst, lab = src_all[s][None, None], dst_all[s][None, None], lab_all[s][None, None].float()
+        theta = affine_register(src, dst, iters)
+        aw_lab, aw_src = affine_warp(lab, theta), affine_warp(src, theta)
+        thetas.append(theta[0])
+        reg.append((identity_grid_warp(aw_lab)[0, 0] > 0.1).float())
+        wsrc.append(identity_grid_warp(aw_src)[0, 0])
+        areg.append((aw_lab[0, 0] > 0.1).float())
+        asrc.append(aw_src[0, 0])
+    return (torch.stack(thetas), torch.stack(reg)[:, None], torch.stack(wsrc) * 2 - 1, torch.stack(areg)[:, None],
+            torch.stack(asrc) * 2 - 1)
+
+
+def adam_constants(iters, lr=0.01, b1=0.9, b2=0.999):
+    """step_size and sqrt(bias_correction2) of torch.optim.Adam's single-tensor path, as python floats per step"""
+    return [(lr / (1 - b1 ** t), float(np.sqrt(1 - b2 ** t))) for t in range(1, iters + 1)]

@@ -56,6 +56,9 @@ _SIGS = {
     "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, cf, vp]),
+    "rpnet_affine_warp": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, vp]),
+    "rpnet_identity_grid_warp": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, vp]),
     "rpnet_mask_adjoint": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_masked_pool_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_masked_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),

@@ -1,0 +1,106 @@
+"""Registration pre-step (dataset/few_shot_reader.py:109-198 with do_deformable=False).
+CPU: the oracle (oracle/registration_oracle.py) against the golden vectors the reference's own
+get_registration_field produced (tests/golden/registration.npz, gen_golden_registration.py).
+GPU: the HIP path (rpnet_amd/registration.py -> rpnet_affine_register / rpnet_affine_warp /
+rpnet_identity_grid_warp through the C ABI) against the same vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from rpnet_amd.utils.synth import make_episode
+
+CASES = ["s64", "s128", "s96x"]
+
+
+def _inputs(g, tag):
+    seed, S, size = (int(v) for v in g[f"{tag}_dims"])
+    ep = make_episode(seed, S, size)
+    t = torch.from_numpy
+    return [[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], t(ep["query_images"])
+
+
+@pytest.mark.parametrize("tag", CASES[:2])
+def test_oracle_matches_reference_golden(golden, tag):
+    from oracle import registration_oracle as RO
+    g = golden("registration")
+    supp, lab, qry = _inputs(g, tag)
+    th, reg, wsrc, areg, asrc = RO.get_registration_field(qry, supp, lab)
+    assert np.abs(th.numpy() - g[f"{tag}_theta"]).max() < 1e-6
+    assert np.abs(wsrc.numpy() - g[f"{tag}_warped_src"]).max() < 1e-5
+    assert np.abs(asrc.numpy() - g[f"{tag}_aff_src"]).max() < 1e-5
+    assert (reg.numpy().astype(np.uint8) != g[f"{tag}_reg_pred"]).sum() == 0
+    assert (areg.numpy().astype(np.uint8) != g[f"{tag}_aff_pred"]).sum() == 0
+
+
+def test_do_deformable_raises_and_reader_exports():
+    import dataset.few_shot_reader as fsr
+    assert callable(fsr.get_registration_field)
+    with pytest.raises(NotImplementedError):
+        fsr.get_registration_field(torch.zeros(1, 1, 8, 8), [[torch.zeros(1, 1, 8, 8)]], [[torch.zeros(1, 8, 8)]],
+                                   do_deformable=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_hip_registration_vs_reference_golden(golden, tag):
+    """theta after 50 Adam steps within 2e-4 of the reference's (measured <= 1e-5: fp32 reduction order is the only
+    difference), warped sources within 2e-3 of a [-1,1] image, thresholded labels differ in < 0.2 % of the pixels
+    (a bilinear value within rounding of the 0.1 threshold).
+
+    The optimisation starts at a kink of the bilinear interpolant (theta = identity puts every sample on a pixel
+    centre) and its first step is lr * sign(gradient), so the result depends on how torch.linspace rounds the base
+    grid on the HOST CPU (one column in 128 lands below its centre), and the reference is only reproducible to
+    ~1e-3 in theta across CPU models even with the same grid (measured: EPYC 9575F vs the build container).  The HIP
+    path takes the grid from the same library call and is deterministic; it is held to the golden vectors (2e-4)
+    whenever this host's base grid equals the one they were made with, and to the oracle evaluated on this host
+    with the reference's own cross-CPU spread (2e-3 in theta, 1 % of the label pixels)."""
+    from oracle import registration_oracle as RO
+    from rpnet_amd.registration import base_grid, get_registration_field
+    g = golden("registration")
+    supp, lab, qry = _inputs(g, tag)
+    th, reg, wsrc, areg, asrc = get_registration_field(qry, supp, lab)
+    n = reg.numel()
+    if np.array_equal(base_grid(qry.shape[-1], "cpu").numpy(), g[f"{tag}_base_grid"]):
+        assert np.abs(th.numpy() - g[f"{tag}_theta"]).max() < 2e-4
+        assert np.abs(wsrc - g[f"{tag}_warped_src"]).max() < 2e-3 and np.abs(asrc - g[f"{tag}_aff_src"]).max() < 2e-3
+        assert (reg.numpy().astype(np.uint8) != g[f"{tag}_reg_pred"]).sum() <= 2e-3 * n
+        assert (areg.numpy().astype(np.uint8) != g[f"{tag}_aff_pred"]).sum() <= 2e-3 * n
+    o_th, o_reg, o_wsrc, o_areg, o_asrc = RO.get_registration_field(qry, supp, lab)
+    assert (th - o_th).abs().max() < 2e-3
+    assert (reg != o_reg).sum() <= 1e-2 * n and (areg != o_areg).sum() <= 1e-2 * n
+
+
+@pytest.mark.gpu
+def test_hip_registration_pieces_vs_oracle():
+    """the three entry points one by one on a non-square, odd-sized slice pair; empty label; zero iterations"""
+    from oracle import registration_oracle as RO
+    from rpnet_amd import registration as R
+    g = torch.Generator().manual_seed(5)
+    S, H, W = 2, 37, 52
+    mov, fix = torch.rand(S, H, W, generator=g), torch.rand(S, H, W, generator=g)
+    fix = 0.5 * fix + 0.5 * torch.roll(mov, (2, -3), (1, 2))
+    th, loss = R.affine_register(mov.cuda(), fix.cuda())
+    for s in range(S):
+        ref = RO.affine_register(mov[s][None, None], fix[s][None, None])
+        assert (th[s].cpu() - ref[0]).abs().max() < 2e-4
+    theta = torch.tensor([[[0.9, 0.1, 0.05], [-0.08, 1.1, -0.02]], [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]])
+    out = R.affine_warp(mov.cuda(), theta.cuda()).cpu()
+    out2 = R.identity_grid_warp(mov.cuda()).cpu()
+    for s in range(S):
+        assert (out[s] - RO.affine_warp(mov[s][None, None], theta[s][None])[0, 0]).abs().max() < 1e-5
+        assert (out2[s] - RO.identity_grid_warp(mov[s][None, None])[0, 0]).abs().max() < 1e-5
+    th0, _ = R.affine_register(mov.cuda(), fix.cuda(), iters=0)
+    assert (th0.cpu() - torch.tensor([[1.0, 0, 0], [0, 1.0, 0]])).abs().max() == 0
+    zero = torch.zeros(1, H, W).cuda()
+    assert R.affine_warp(zero, theta[:1].cuda(), threshold=0.1).abs().max() == 0
+
+
+@pytest.mark.gpu
+def test_reader_uses_registration_on_gpu():
+    """FewshotRegReader with use_registration_loss: appr_query_labels = warped support label > 0.5 (reference :608)"""
+    from dataset.few_shot_reader import FewshotRegReader
+    cfg = {"use_registration_loss": True, "do_deformable": False, "eval_classes": ["Liver"]}
+    item = FewshotRegReader("/nonexistent", "test", cfg, mode="eval", n_volumes=2, n_slices=3, size=64)[0]
+    assert item["appr_query_labels"].shape == item["query_labels"].shape
+    assert item["warped_supp_label"].shape == (3, 1, 64, 64) and item["registration_field"].shape == (3, 2, 3)
+    assert set(np.unique(item["appr_query_labels"].numpy())) <= {0.0, 1.0}
