@@ -708,9 +708,9 @@ static const SplitVariant kSplitVariants[] = {
     {2, 2, 1, 0, 1024},   // 1: 128 x 64
     {2, 1, 2, 0, 1024},   // 2:  64 x 128
     {2, 1, 1, 0, 1536},   // 3:  64 x 64
-    {4, 2, 2, 1, 256},    // 4: 256 x 128, 8 waves, two LDS stages, 1 block per CU
-    {4, 2, 2, 0, 256},    // 5: 256 x 128, 8 waves, one stage
-    {2, 2, 2, 1, 256},    // 6: 128 x 128 two stages
+    {4, 2, 2, 1, 256},    // 4-6: 8-wave / two-stage forms of this kernel (213 / 205 / 168 TF on 512 -> 512 at M = 16384
+    {4, 2, 2, 0, 256},    //      against 187 for variant 0): superseded by the patch kernels below, not instantiated
+    {2, 2, 2, 1, 256},
     {4, 2, 2, 1, 256},    // 7: 256 x 128 on an image patch, input halo resident in LDS (conv_igemm_split_halo_kernel)
     {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
     {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
@@ -746,7 +746,7 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     if (e) {
         const int v = atoi(e);
         if ((v == 7 && halo_tw(d, Cout)) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
-        if (v >= 0 && v < 7 && (kSplitVariants[v].wn == 1 || n128)) return v;
+        if (v >= 0 && v < 4 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
     // halo-resident patch kernels: 256 x 128 with one 8-wave block per CU when that grid fills the machine, else (and
@@ -783,9 +783,6 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);
         case 2: return launch_split<2, 1, 2, false>(d, M, Cin, Cout, s);
         case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
-        case 4: return launch_split<4, 2, 2, true>(d, M, Cin, Cout, s);
-        case 5: return launch_split<4, 2, 2, false>(d, M, Cin, Cout, s);
-        case 6: return launch_split<2, 2, 2, true>(d, M, Cin, Cout, s);
         case 9:
             return halo4_tw(d) == 32 ? launch_split_halo4<32, 1>(d, M, Cin, Cout, s) : launch_split_halo4<16, 1>(d, M, Cin, Cout, s);
         case 8:
