@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 tools/probe/tr_probe.cpp -o tools/probe/tr_probe; run: tr_probe <row bytes> 0
 // Probe of ds_read_b64_tr_b16 (gfx950): LDS holds u16 value = its own element index; every lane passes the
 // byte address  (lane >> 2) * ROWB + (lane & 3) * 8  [+ 16-lane group offsets]  and we print what each lane gets.
 #include <hip/hip_runtime.h>
