@@ -1,7 +1,7 @@
 """The per-slice registration pre-step of the reference's reader (dataset/few_shot_reader.py:109-198,
 net/registration.py:316-357,474-502) for the shipped configuration `do_deformable: False`
 (yamls/example.yml:99-101), batched: all slices of a volume are registered in ONE kernel launch
-(rpnet_affine_register: a block per slice runs the 50 Adam steps on-chip), then warped in four more.
+(rpnet_affine_register: a block per slice runs the 50 Adam steps on-chip), then warped in six more.
 
 The reference does this slice by slice with ~20 small torch operators per Adam step — on the CPU in this
 configuration (few_shot_reader.py:135-143) — and it dominates the wall-clock of real evaluation outside the
@@ -65,6 +65,6 @@ def get_registration_field(query_images, support_images, support_labels, do_defo
     aw_lab, aw_src = affine_warp(lab, theta), affine_warp(src, theta)
     py_reg_pred = identity_grid_warp(aw_lab, threshold=0.1)[:, None].cpu()
     warped_src = identity_grid_warp(aw_src, scale=2.0, shift=-1.0).cpu().numpy()
-    py_affine_reg_pred = (aw_lab > 0.1).float()[:, None].cpu()
-    affine_warped_src = (aw_src * 2 - 1).cpu().numpy()
+    py_affine_reg_pred = affine_warp(lab, theta, threshold=0.1)[:, None].cpu()
+    affine_warped_src = affine_warp(src, theta, scale=2.0, shift=-1.0).cpu().numpy()
     return theta.cpu(), py_reg_pred, warped_src, py_affine_reg_pred, affine_warped_src
