@@ -125,7 +125,10 @@ int rpnet_conv_stats_blocks(const rpnet_conv_desc* d);
  * (rpnet_conv_wgrad_workspace_bytes), then reduced and transposed into the state_dict
  * layout.  Channels [cin_off0, cin_off0+cin_split) and [cin_off1, ...) of the gathered A
  * map to dW input channels 0.. (skips the zero padding rows).
- * d->split_planes != 0 (dense 3x3 only): x0/x1 AND dy are split-bf16 planes ([planes][pixels][C]). */
+ * d->split_planes != 0 (dense 3x3 only): x0/x1 AND dy are split-bf16 planes ([planes][pixels][C]); then the call
+ * may also be made in two phases on two streams — dw == NULL: the split-K GEMM only (partial sums stay in
+ * `workspace`), dy == NULL: the reduce + transpose only — so that the HBM-bound reduce of one layer runs under the
+ * GEMM of the next. */
 size_t rpnet_conv_wgrad_workspace_bytes(int N, int H, int W, int cin_gathered, int cout, int taps);
 int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int cin_w,
                      int cin_off0, int cin_split, int cin_off1,

@@ -459,7 +459,9 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
                                 int cin_split, int cin_off1, void* workspace, size_t workspace_bytes,
                                 rpnet_stream_t stream) {
     using namespace rpnet;
-    RPNET_REQUIRE(d && d->x0 && dy && dw && workspace, RPNET_ERR_ARG, "conv_wgrad: null pointer");
+    RPNET_REQUIRE(d && d->x0 && workspace && (dy || dw), RPNET_ERR_ARG, "conv_wgrad: null pointer");
+    RPNET_REQUIRE((dy && dw) || (d->split_planes && d->taps == 9 && d->dilation <= 1), RPNET_ERR_ARG,
+                  "conv_wgrad: the two-phase form (dy or dw NULL) exists for the split 3x3 kernel only");
     const int Cin = d->C0 + d->C1, Cout = d->Co0 + d->Co1;
     RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
     RPNET_REQUIRE(!d->split_planes || (d->taps == 9 && d->dilation <= 1), RPNET_ERR_ARG,
@@ -482,7 +484,9 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         if (d->split_planes) {   // x0/x1 and dy are split-bf16 planes
             RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
                           "conv_wgrad: split operands take 2 or 3 planes and no in_scale");
-            if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
+            if (dy)      // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
+                if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
+            if (!dw) return RPNET_OK;       // GEMM phase only: the partial sums stay in the workspace
             hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
                                Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
             return check_launch("wgrad_reduce");

@@ -54,6 +54,14 @@ def _direct(p):
             and not getattr(p, "_rpnet_autograd_grad", False))
 
 
+def _reduce_stream(device):
+    key = ("reduce", device)
+    s = _ASYNC["side"].get(key)
+    if s is None:
+        s = _ASYNC["side"][key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _side_stream(device):
     s = _ASYNC["side"].get(device)
     if s is None:
@@ -65,6 +73,9 @@ def join_side_streams():
     """Make the current stream wait for every async weight-gradient launch issued so far."""
     for dev in list(_ASYNC["pending"]):
         torch.cuda.current_stream(dev).wait_stream(_ASYNC["side"][dev])
+        red = _ASYNC["side"].get(("reduce", dev))
+        if red is not None:
+            torch.cuda.current_stream(dev).wait_stream(red)
     _ASYNC["pending"].clear()
 
 
@@ -315,8 +326,17 @@ class ConvBnRelu(Function):
                 d.accumulate = 1
                 with torch.cuda.stream(side):
                     ws2 = _ws(wb, y)
-                    call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
-                         ptr(ws2), wb)
+                    if wsplit:   # GEMM on the side stream, its HBM-bound reduce on a third one under the next layer's GEMM
+                        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                        red = _reduce_stream(dev)
+                        red.wait_stream(side)
+                        ws2.record_stream(red)
+                        with torch.cuda.stream(red):
+                            call("rpnet_conv_wgrad", C.byref(d), None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                                 ptr(ws2), wb)
+                    else:
+                        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                             ptr(ws2), wb)
                 for tns in (x0, x1, in_scale, dy, dyp) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
                     if tns is not None:
                         tns.record_stream(side)
