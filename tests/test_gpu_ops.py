@@ -1,6 +1,8 @@
 """GPU parity, op level: every HIP kernel family through the C ABI against the CPU oracle
 (oracle/rpnet_oracle.py, pinned to the reference) and the committed golden vectors.
 Tolerance: fp32, 1e-3 relative as BASELINE.json's north_star states (most ops sit at 1e-5)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -173,6 +175,50 @@ def test_split_halo_kernel(RF, monkeypatch, tile, N, H, W, c0, c1, cout, ups):
             assert rel_err(nchw(bg.grad), br.grad) < TOL
         assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
         assert rel_err(bn.running_var, b_ref.running_var) < 1e-5
+    finally:
+        RF.set_conv_math(old)
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,ups", [
+    (4, 64, 64, 64, 512, False),     # 256 tiles of 256 x 128: the 8-wave patch kernel by the default policy
+    (2, 32, 64, 128, 256, False),    # 16 x 2 tiles of 256: too few -> 128-pixel patches (64 x 2 = 128 tiles -> 64-wide)
+    (1, 16, 16, 256, 1024, False),   # M = 256: 2 x 8 tiles of 128-pixel patches, W % 16 path
+    (2, 24, 40, 64, 128, False),     # W % 16 != 0: no patch kernel, plain split implicit GEMM with ragged tiles
+    (2, 32, 32, 64, 192, True),      # nearest x2 in front, 192 = 64-wide tiles
+    (2, 64, 64, 64, 64, False),      # Cout = 64 (the Conv1b class): 64-wide 128-pixel patches
+])
+def test_split_conv_default_policy_shapes(RF, N, H, W, cin, cout, ups):
+    """the tile / kernel choice of the split convolution is made per launch from the shape; sweep shapes that land
+    on each kernel (8-wave patch, 4-wave patch 128- and 64-wide, TW = 16, plain split GEMM, up-sampled gather) and
+    check forward, input gradient, weight gradient and the fused statistics against the torch reference"""
+    old = RF.conv_math()
+    RF.set_conv_math("bf16x3")
+    try:
+        conv, bn = _mk_layer(cin, cout, 3, 51)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        go = rnd(53, N, cout, H, W)
+        for seed in (52, 152, 252, 352, 452, 552):
+            # a pre-activation within rounding of the ReLU threshold flips its mask between any two fp32
+            # evaluations (seen: one element of 245 760 -> 1.5e-2 in dx, on the fp32-MFMA kernel too): such an input
+            # tests the conditioning of ReLU, not the kernels — take the next seed
+            x = rnd(seed, N, cin, hs, ws)
+            with torch.no_grad():
+                xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+                pre = copy.deepcopy(bn).train()(conv(xin))
+            if pre.abs().min() > 2e-6:
+                break
+        xr = x.clone().requires_grad_(True)
+        ref, c_ref, b_ref = _ref_layer(conv, bn, xr, True, upsample=ups)
+        ref.backward(go)
+        conv, bn = conv.to(DEV), bn.to(DEV).train()
+        xg = nhwc(x).to(DEV).requires_grad_(True)
+        z = RF.conv_bn_relu(xg, conv, bn, RF.WeightCache(), True, upsample=ups)
+        z.backward(nhwc(go).to(DEV))
+        assert rel_err(nchw(z), ref) < TOL
+        assert rel_err(nchw(xg.grad), xr.grad) < TOL
+        assert rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
+        assert rel_err(bn.weight.grad, b_ref.weight.grad) < TOL and rel_err(bn.bias.grad, b_ref.bias.grad) < TOL
+        assert rel_err(bn.running_mean, b_ref.running_mean) < 1e-5 and rel_err(bn.running_var, b_ref.running_var) < 1e-5
     finally:
         RF.set_conv_math(old)
 
