@@ -240,23 +240,29 @@ __global__ void bilinear_up_fwd_kernel(const float* __restrict__ in, float* __re
     }
 }
 
+// gather form (no atomics): four lanes share a low-resolution pixel, each takes every fourth row of the window of
+// high-resolution gradients that touch it, and a two-step shuffle adds them up
 __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int planes, int h, int w, int H, int W) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= planes * h * w) return;
-    const int x = i % w, y = (i / w) % h, pl = i / (w * h);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, part = t & 3;
+    const bool live = i < planes * h * w;
+    const int ii = live ? i : 0;
+    const int x = ii % w, y = (ii / w) % h, pl = ii / (w * h);
     const float rsy = (float)h / (float)H, rsx = (float)w / (float)W;
     const int Y0 = max(0, (y - 1) * (H / h) - 1), Y1 = min(H - 1, (y + 1) * (H / h) + H / h + 1);
     const int X0 = max(0, (x - 1) * (W / w) - 1), X1 = min(W - 1, (x + 1) * (W / w) + W / w + 1);
     const float* g = dout + (size_t)pl * H * W;
     float acc = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) {
+    for (int Y = Y0 + part; Y <= Y1; Y += 4) {
         const float wy = bl_weight(Y, y, rsy, h);
         if (wy == 0.f) continue;
         float row = 0.f;
         for (int X = X0; X <= X1; ++X) row += g[(size_t)Y * W + X] * bl_weight(X, x, rsx, w);
         acc += wy * row;
     }
-    din[i] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (live && part == 0) din[i] = acc;
 }
 
 __global__ void softmax_thresh_pool_kernel(const float* __restrict__ logits, float* __restrict__ mask, int B, int K, int H,
@@ -450,7 +456,7 @@ extern "C" int rpnet_bilinear_up_bwd(const float* dout, float* din, int planes, 
     using namespace rpnet;
     RPNET_REQUIRE(dout && din, RPNET_ERR_ARG, "bilinear_up_bwd: null pointer");
     RPNET_REQUIRE(H % h == 0 && W % w == 0, RPNET_ERR_SHAPE, "bilinear_up_bwd: %dx%d -> %dx%d", h, w, H, W);
-    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(cdiv((long)planes * h * w, 256)), dim3(256), 0, (hipStream_t)stream, dout, din, planes, h, w, H, W);
+    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(cdiv((long)planes * h * w * 4, 256)), dim3(256), 0, (hipStream_t)stream, dout, din, planes, h, w, H, W);
     return check_launch("bilinear_up_bwd");
 }
 
