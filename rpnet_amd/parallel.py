@@ -18,53 +18,77 @@ class FlatGradBucket:
     """Gradients of `module` as views into one contiguous buffer.
 
     p.grad is pre-set to a view of the flat buffer, so autograd accumulates straight into it
-    (no gather copy); `zero()` is one memset.  The exchange is split in two so that most of it
-    hides under the backward pass: backward reaches the parameters in reverse module order
-    (cre.* and the decoder half Up_conv4..Up5 first, Conv5..Conv1 last), so the TAIL of the buffer
-    (everything from `split_at` on, ~46 % of the bytes) is final as soon as the first gradient of
-    the HEAD has been accumulated — a post-accumulate hook on that parameter launches the tail's
-    all-reduce asynchronously (RCCL stream) while the rest of backward still runs; `allreduce()`
-    then only exposes the head's all-reduce.  Both are plain sums over identical buffers on every
-    rank, so results do not depend on the overlap.
+    (no gather copy); `zero()` is one memset.  The exchange is cut into SEGMENTS at the `split_at` name
+    prefixes so that most of it hides under the backward pass: backward reaches the parameters in reverse
+    module order (cre.* and the decoder half Up_conv4..Up5 first, then Conv5, then Conv4..Conv1), so a
+    segment is final as soon as the first gradient of the segment in front of it has been accumulated — a
+    post-accumulate hook on that parameter launches the finished segment's all-reduce asynchronously (RCCL
+    stream) while the rest of backward still runs.  With the default cuts (Conv5 = 41 % of the bytes, the
+    decoder half + cre = 46 %) only the Conv1..Conv4 segment (13 %, 18 MB) is exchanged after backward.
+    All are plain sums over identical buffers on every rank, so results do not depend on the overlap.
     """
 
-    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES, split_at="encoder.Up5."):
+    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES, split_at=("encoder.Conv5.", "encoder.Up5.")):
+        if isinstance(split_at, str):
+            split_at = (split_at,)
         self.params = [(n, p) for n, p in module.named_parameters()
                        if p.requires_grad and not n.startswith(tuple(skip_prefixes))]
         total = sum(p.numel() for _, p in self.params)
         p0 = self.params[0][1]
         self.flat = torch.zeros(total, device=p0.device, dtype=torch.float32)
-        off, self.split = 0, None
+        cuts, want = [], list(split_at or ())
+        off = 0
         for n, p in self.params:
-            if self.split is None and split_at and n.startswith(split_at):
-                self.split = off
+            if want and n.startswith(want[0]):
+                if off > 0:
+                    cuts.append(off)
+                want.pop(0)
             k = p.numel()
             p.grad = self.flat[off:off + k].view_as(p)
             off += k
         self.numel = total
-        self._tail_work = None
-        self._hook = None
-        if self.split:   # the last head parameter in module order is the FIRST head gradient backward produces
-            head_last = None
-            o = 0
+        self.cuts = cuts                                  # ascending offsets; segment i = [bounds[i], bounds[i+1])
+        self.bounds = [0] + cuts + [total]
+        self.split = cuts[-1] if cuts else None           # start of the last (first finished) segment
+        self._work = {}                                   # segment index -> in-flight all-reduce
+        self._hooks = []
+        # the last parameter (module order) of segment i-1 is the FIRST gradient of that segment backward produces:
+        # when it lands, segment i (everything behind it) is complete
+        for i in range(1, len(self.bounds) - 1):
+            last, o = None, 0
             for n, p in self.params:
-                if o + p.numel() <= self.split:
-                    head_last = p
+                if o + p.numel() <= self.bounds[i]:
+                    last = p
                 o += p.numel()
-            if head_last is not None and hasattr(head_last, "register_post_accumulate_grad_hook"):
-                head_last._rpnet_autograd_grad = True    # keep this one on AccumulateGrad so that the hook fires
-                self._hook = head_last.register_post_accumulate_grad_hook(self._launch_tail)
+            if last is not None and hasattr(last, "register_post_accumulate_grad_hook"):
+                last._rpnet_autograd_grad = True          # keep this one on AccumulateGrad so that the hook fires
+                self._hooks.append(last.register_post_accumulate_grad_hook(self._launcher(i)))
+        self._hook = self._hooks[-1] if self._hooks else None
+        self._tail_work = None
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def _launch_tail(self, _param=None):
-        if self._active() and self._tail_work is None and self.split:
+    def _launcher(self, seg):
+        def launch(_param=None):
+            # segments finish back to front; launch this one and any later one that has not gone out yet
+            if not self._active():
+                return
             from .functional import join_side_streams
-            join_side_streams()      # async weight gradients of the tail must have landed in the bucket
-            self._tail_work = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
+            join_side_streams()      # async weight gradients of the segment must have landed in the bucket
+            for s in range(len(self.bounds) - 2, seg - 1, -1):
+                if s not in self._work:
+                    self._work[s] = dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM,
+                                                    async_op=True)
+            self._tail_work = self._work.get(len(self.bounds) - 2)
+        return launch
+
+    def _launch_tail(self, _param=None):
+        if len(self.bounds) > 2:
+            self._launcher(len(self.bounds) - 2)()
 
     def zero(self):
+        self._work = {}
         self._tail_work = None
         self.flat.zero_()
 
@@ -74,12 +98,13 @@ class FlatGradBucket:
             return None
         from .functional import join_side_streams
         join_side_streams()
-        if self.split and self._tail_work is not None:     # tail already in flight (or done): only the head remains
-            dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM)
-            self._tail_work.wait()
-            self._tail_work = None
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        for s in range(len(self.bounds) - 1):             # whatever has not been launched during backward
+            if s not in self._work:
+                dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM)
+        for w in self._work.values():
+            w.wait()
+        self._work = {}
+        self._tail_work = None
         self.flat.mul_(1.0 / dist.get_world_size())
         return None
 

@@ -106,6 +106,50 @@ def test_gradient_bucket_allreduce_gloo_world2():
     assert not torch.equal(s0, s1)                           # the skipped tensor was not exchanged
 
 
+def _ddp_worker3(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters, shard_episodes
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    broadcast_parameters(net)
+    bucket = FlatGradBucket(net, skip_prefixes=(), split_at=("2.", "4."))      # three segments: layer 0 | layer 2 | layer 4
+    assert bucket.bounds == [0, 35, 59, 74] and len(bucket._hooks) == 2
+    xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    lo, hi = shard_episodes(8, rank, world)
+    bucket.zero()
+    net(xs[lo:hi]).square().sum().backward()
+    launched = sorted(bucket._work)                          # segments 2 and 1 went out during backward, 0 is left
+    bucket.allreduce()
+    q.put((rank, launched, bucket.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_three_segments_gloo_world2():
+    """progressive exchange: the segments behind the gradient front are all-reduced while backward still runs
+    (hooks), the front segment after it; the averaged gradients equal the single-process ones"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker3, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, l0, f0), (_, l1, f1) = res
+    assert l0 == [1, 2] and l1 == [1, 2]
+    assert torch.equal(f0, f1)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    net(xs).square().sum().backward()
+    ref = torch.cat([p.grad.flatten() for p in net.parameters()]) / 2
+    assert torch.allclose(f0, ref, rtol=1e-5, atol=1e-6)
+
+
 def test_shard_episodes_ragged():
     from rpnet_amd.parallel import shard_episodes
     spans = [shard_episodes(10, r, 4) for r in range(4)]
