@@ -18,6 +18,10 @@
  *     BatchNorm batch statistics (the reference calls the encoder once for the support
  *     images and once for the query images, net/rp_net.py:248,257 — one launch here,
  *     two statistic groups, two running-stat updates in call order).
+ *   - the 3x3 convolutions, their weight gradients and the local correlation also exist on "split-bf16"
+ *     operands (an fp32 value as 3 exact bf16 planes, 6 partial products on the bf16 matrix pipe, fp32
+ *     accumulation: fp32 accuracy at 16/6 of the fp32 matrix rate) — the default arithmetic of the host side;
+ *     see rpnet_split_bf16 and the split_planes field of rpnet_conv_desc.
  *   - return value: 0 on success, a negative rpnet_status, or a positive hipError_t;
  *     rpnet_last_error_string() gives thread-local text for the last failure.
  *   - re-entrant: no global mutable state.
