@@ -226,9 +226,14 @@ class ConvBnRelu(Function):
         first = weight.shape[1] == 1 and weight.shape[2] == 3  # Cin = 1 direct convolution
         z = _empty((N, H, W, cout), x0)
         if not training:
-            scale, shift = _empty((cout,), x0), _empty((cout,), x0)
-            call("rpnet_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(scale),
-                 ptr(shift), cout)
+            aff = getattr(pw, "eval_affine", None)     # the folded BatchNorm lives as long as the layer's packed weights
+            if aff is None:
+                aff = (_empty((cout,), x0), _empty((cout,), x0))
+                call("rpnet_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(aff[0]),
+                     ptr(aff[1]), cout)
+                if pw is not None:
+                    pw.eval_affine = aff
+            scale, shift = aff
             if first:
                 call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout)
             elif _use_split(pw, x0, x1):

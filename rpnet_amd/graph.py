@@ -6,7 +6,9 @@ by host launch latency, not by the GPU.  Every shape on that path is static per 
 the whole `RP_Net.forward` (eval mode, no autograd) is captured once into a HIP graph and replayed:
 inputs are copied into static buffers, one graph launch runs the pass, outputs are static tensors.
 All kernels go through the same C ABI on the capturing stream; the library never allocates or
-synchronises, which is what makes it capturable.
+synchronises, which is what makes it capturable.  The weights are static for a captured graph, so the weight
+packs and the folded BatchNorm affines are produced once in the warm-up and stay out of the replay
+(`RP_Net.freeze_packs`).
 """
 import torch
 
@@ -17,6 +19,8 @@ class GraphedEval:
 
     def __init__(self, net, warmup=2):
         self.net = net.eval()
+        self.net.freeze_packs = True      # packs and folded BN affines are made in the warm-up, outside the graph
+        self.net._cache.clear()
         self.warmup = warmup
         self._graphs = {}
 

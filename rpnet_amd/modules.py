@@ -239,6 +239,10 @@ class RP_Net(nn.Module):
         self.pretrained_path = pretrained_path
         self.config = cfg or {"align": False}
         self.backbone_cfg = backbone_cfg
+        # serving switch (off by default): in eval mode keep the packed weights and folded BatchNorm affines between
+        # calls; the caller promises not to change parameters / running statistics meanwhile (rpnet_amd.graph sets it:
+        # a captured graph assumes static weights anyway).  `net._cache.clear()` drops the packs.
+        self.freeze_packs = False
         self.scale = backbone_cfg.get("scale", 4)
         self.num_iter = backbone_cfg["n_iter_refinement"]
         self.use_relation_enc = backbone_cfg.get("use_relation_enc", "relation")
@@ -274,7 +278,8 @@ class RP_Net(nn.Module):
         H, W = qry_imgs[0].shape[-2:]
         h, w = H // self.scale, W // self.scale
         cache = self._cache
-        cache.clear()  # packed weights live for one forward only
+        if self.training or not self.freeze_packs:
+            cache.clear()  # packed weights live for one forward only (never reused across optimizer steps)
 
         # ---- features: support and query through the encoder, separate BN statistics (:245-258)
         supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
