@@ -116,6 +116,9 @@ typedef struct rpnet_conv_desc {
                                           split-bf16 operands (rpnet_split_bf16 / rpnet_pack_conv_weight_split),
                                           plane p of a source at +p*N*Hin*Win*C elements, of w at
                                           +p*taps*Cin*Cout; in_scale must already be folded into the split */
+    void* y_split;                     /* optional (single destination, Co1 == 0): the final output also as split-bf16
+                                          planes [split_out_planes][N*H*W][Cout] — what the next convolution reads */
+    int split_out_planes;              /* 2 or 3 when y_split is set */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);

@@ -3,6 +3,7 @@
 // MFMA tiles of 32x32 in the C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma once
 #include "common.h"
+#include "split_bf16.h"
 
 namespace rpnet {
 
@@ -16,6 +17,14 @@ struct PatchRows {    // the block's rows walk a (rows / TW) x TW patch of one i
     int base, W;      // linear index of the patch's top-left pixel
     __device__ __forceinline__ int operator()(int local) const { return base + (local / TW) * W + (local % TW); }
 };
+
+// LDS bytes the epilogue may use (statistics reduction; per-wave 32-row slabs of the split output)
+template <int WN, int WGM>
+constexpr int epilogue_lds_bytes() {
+    constexpr int stats = WGM * 64 * WN * 2 * 8, slabs = WGM * 2 * 32 * (WN * 32 + 4) * 4;
+    return stats > slabs ? stats : slabs;
+}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <int WM, int WN, int WGM = 2, typename RowMap = LinearRows>
 __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows,
@@ -88,6 +97,48 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
                     float* p = dst + (size_t)row * Cd + cd;
                     if (d.accumulate) v += *p;
                     *p = v;
+                    acc[i][j][r] = v;
+                }
+            }
+        }
+    }
+    if (d.y_split) {
+        // the output also as split-bf16 planes (the operand format of the next convolution; eval mode, where the
+        // BatchNorm affine + ReLU are applied right here): each wave turns its 32-row MFMA tiles through a private
+        // LDS slab so that a lane holds 8 consecutive channels of a pixel = one 16-byte store per plane
+        constexpr int SW = WN * 32 + 4;
+        float* slab = reinterpret_cast<float*>(lds) + (size_t)(wm * 2 + wn) * 32 * SW;
+        unsigned short* ys = reinterpret_cast<unsigned short*>(d.y_split);
+        const size_t plane = (size_t)M * Cout;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * h) * SW + j * 32 + li] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2 * WN; ++q) {
+                const int gidx = q * 64 + h * 32 + li;            // (row, 8-channel group) of the 32 x (WN*32) tile
+                const int rr = gidx / (WN * 4), cg = gidx - rr * (WN * 4);
+                const int row = rows(wm * WM * 32 + i * 32 + rr);
+                if (row >= 0) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8]);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8 + 4]);
+                    const float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    const size_t o = (size_t)row * Cout + n0 + wn * WN * 32 + cg * 8;
+                    if (d.split_out_planes == 3) {
+                        u32x4 pl[3];
+                        split8<3>(v8, pl);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(ys + p * plane + o) = pl[p];
+                    } else {
+                        u32x4 pl[2];
+                        split8<2>(v8, pl);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * plane + o) = pl[p];
+                    }
                 }
             }
         }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : (WM * WN == 4 ? 3 : 4))) v
     // single LDS stage (34 KB at 128x128): three blocks per CU.  A double-buffered variant (one
     // barrier per K-step, 70 KB, two blocks per CU) measured 15 % SLOWER: occupancy hides the
     // barrier better than removing it does.
-    __shared__ __attribute__((aligned(16))) float smem[BM * ASTR + BK * BN];
+    __shared__ __attribute__((aligned(16))) float smem[cmax(BM * ASTR + BK * BN, epilogue_lds_bytes<WN, 2>() / 4)];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -261,6 +261,8 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     RPNET_REQUIRE(!d->stats_partial || rpnet_conv_stats_blocks(d) > 0, RPNET_ERR_SHAPE,
                   "conv_fwd: statistic groups do not split into whole tiles; use rpnet_bn_stats");
     RPNET_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), RPNET_ERR_SHAPE, "conv_fwd: odd size with upsample");
+    RPNET_REQUIRE(!d->y_split || (d->Co1 == 0 && (d->split_out_planes == 2 || d->split_out_planes == 3)), RPNET_ERR_ARG,
+                  "conv_fwd: y_split needs a single destination and 2 or 3 planes");
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
     RPNET_REQUIRE((size_t)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) &&
                       (size_t)d->taps * Cin * Cout * 4 < (1UL << 31),

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
     constexpr bool B_PART = BN < RP;              // fewer B rows than one pass: only the first threads stage B
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;       // one plane of a tile
     constexpr int STAGE = NP * (A_BYTES + B_BYTES);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[cmax((DB ? 2 : 1) * STAGE, epilogue_lds_bytes<WN, WGM>())];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
     constexpr int A_BYTES = HALO * 64, B_BYTES = BN * 64;
     constexpr int HJ = (HALO * 4 + NT - 1) / NT;
     constexpr int WM = 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * A_BYTES + 2 * NP * B_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(NP * A_BYTES + 2 * NP * B_BYTES, epilogue_lds_bytes<WN, 4>())];
     unsigned char* const bsm = smem + NP * A_BYTES;
 
     const int t = threadIdx.x;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
     constexpr int HJ = (HALO * 4 + NT - 1) / NT;
     constexpr int WM = 2;
     constexpr int BJ = (BN * 4 + NT - 1) / NT;                  // weight pieces per thread and plane
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * A_BYTES + NP * B_BYTES];   // one weight stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(NP * A_BYTES + NP * B_BYTES, epilogue_lds_bytes<WN, 2>())];   // one weight stage
     unsigned char* const bsm = smem + NP * A_BYTES;
 
     const int t = threadIdx.x;

@@ -234,6 +234,8 @@ class ConvBnRelu(Function):
                 if pw is not None:
                     pw.eval_affine = aff
             scale, shift = aff
+            np_out = _MATH["planes"] if (out_split and cout % 32 == 0 and not first) else 0
+            zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
             if first:
                 call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout)
             elif _use_split(pw, x0, x1):
@@ -241,10 +243,14 @@ class ConvBnRelu(Function):
                 d = _desc(_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_),
                           pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                 d.split_planes = np_
+                d.y_split, d.split_out_planes = ptr(zs), np_out
                 call("rpnet_conv_fwd", C.byref(d))
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
+                d.y_split, d.split_out_planes = ptr(zs), np_out
                 call("rpnet_conv_fwd", C.byref(d))
+            if zs is not None:
+                z._rp_split = zs      # written by the conv epilogue: no separate split pass in eval mode
             ctx.eval_mode = True
             return z
         y = _empty((N, H, W, cout), x0)
