@@ -1,9 +1,12 @@
 """`dataset.few_shot_reader.FewshotRegReader` with the item contract test_rpnet.py consumes
 (test_rpnet.py:70,166-184; reference dataset/few_shot_reader.py:592-650).
 
-The reference reader needs the private ABD-110 NRRD volumes plus nrrd / nibabel / SimpleITK; none exists offline.  This reader serves SYNTHETIC volumes with the same keys, shapes and dtypes
-(rpnet_amd.utils.synth), so the evaluation loop runs end to end on the MI355X path.  Real-data reading is
-§8(f).4 and raises.  The per-slice registration pre-step of the reference reader (few_shot_reader.py:556-566:
+Two sources behind the one name:
+  * `data_dir` holds `<pid>_clean.nrrd` / `<pid>_<roi>.nrrd` volumes (the reference's layout, few_shot_reader.py:314-321)
+    -> rpnet_amd.utils.volume_reader.FewshotRegReader, the real volume / slice / registration readers;
+  * otherwise (the private ABD-110 data is not available offline) SYNTHETIC volumes with the same keys, shapes and
+    dtypes (rpnet_amd.utils.synth), so the evaluation loop runs end to end on the MI355X path.
+The per-slice registration pre-step of the reference reader (few_shot_reader.py:556-566:
 `use_registration_loss`, `do_deformable: False`) is `get_registration_field` = rpnet_amd.registration (one HIP
 launch for all slices); on a GPU box the reader derives `appr_query_labels` from it exactly as the reference does
 (:608), elsewhere it serves the generator's approximate labels.
@@ -15,6 +18,15 @@ import torch
 
 from rpnet_amd.registration import get_registration_field  # noqa: F401  (reference few_shot_reader.py:109, HIP path)
 from rpnet_amd.utils.synth import make_episode
+from rpnet_amd.utils import volume_reader as _vr
+from rpnet_amd.utils.volume_reader import (FewshotSliceReader, FewshotVolumeReader, crop, elastic_transform_all,  # noqa: F401
+                                           gamma_tansform, gamma_tansform_with_label, keep_only_annotation_z_slices,
+                                           make_support_query_same_size, random_label_transform, random_transform,
+                                           train_collate)
+
+
+def _has_nrrd(data_dir):
+    return bool(data_dir) and os.path.isdir(data_dir) and any(f.endswith(".nrrd") for f in os.listdir(data_dir))
 
 
 class _VolumeInfo:
@@ -28,10 +40,12 @@ class _SliceReader:
 
 
 class FewshotRegReader(torch.utils.data.Dataset):
+    def __new__(cls, data_dir=None, set_name=None, config=None, mode="train", **kw):
+        if _has_nrrd(data_dir):
+            return _vr.FewshotRegReader(data_dir, set_name, config, mode=mode)      # not a subclass: __init__ below is skipped
+        return super().__new__(cls)
+
     def __init__(self, data_dir, set_name, config, mode="train", n_volumes=4, n_slices=6, size=256):
-        if data_dir and os.path.isdir(data_dir) and any(f.endswith(".nrrd") for f in os.listdir(data_dir)):
-            raise NotImplementedError("NRRD volume reading (reference few_shot_reader.py:232-398) is out of scope; "
-                                      "point data_dir at a non-existing path to get synthetic volumes")
         self.config, self.mode = config, mode
         self.classes = config.get("eval_classes" if mode == "eval" else "train_classes", ["Liver"])
         self.n_volumes, self.n_slices, self.size = n_volumes, n_slices, size

@@ -46,3 +46,23 @@ def dice_score_seperate(y_pred, y_true, num_class=1, decimal=4):
         else:
             scores.append(None)
     return scores
+
+
+def pad2factor(image, factor=16, pad_value=0):
+    """[D,H,W] padded at the far end of every axis up to the next multiple of `factor` (reference utils/util.py:406-419)."""
+    import numpy as np
+    widths = [(0, -s % factor) for s in image.shape]
+    return np.pad(image, widths, "constant", constant_values=pad_value)
+
+
+def normalize(img, minimum=-1024, maximum=3076):
+    """HU window -> [-1, 1] (reference utils/util.py:455-467): clip at the 99.5th percentile of THIS array, then at
+    [minimum, maximum], scale by max(1, maximum - minimum).  Returns a new array of the input dtype family."""
+    import numpy as np
+    out = np.array(img, copy=True)
+    top = float(np.percentile(out, 100.0 - 0.5))
+    out[out > top] = top
+    out[out > maximum] = maximum
+    out[out < minimum] = minimum
+    out = (out - minimum) / max(1, (maximum - minimum))
+    return out * 2 - 1
