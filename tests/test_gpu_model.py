@@ -258,6 +258,25 @@ def test_eval_driver_end_to_end():
     assert few["Liver"] == [r for r in ref["Liver"][9]]          # output == refinement[T-1]
 
 
+def test_eval_driver_over_nrrd_volumes(tmp_path):
+    """the same loop fed by the real readers: NRRD volumes on disk -> FewshotVolumeReader / SliceReader ->
+    HIP registration pre-step -> RP_Net (T = 10) -> Dice per volume (SURVEY §8f rows 1, 2, 4 chained)"""
+    from dataset.few_shot_reader import FewshotRegReader
+    from rpnet_amd.utils.volume_reader import FewshotRegReader as RealReader, write_synthetic_dataset
+    from tools.eval_driver import evaluate
+    data_dir, set_name, csv_dir = write_synthetic_dataset(str(tmp_path), n_volumes=3, classes=("Liver",), shape=(14, 72, 68), seed=5)
+    cfg = load_cfg()
+    cfg.update(n_iter_refinement=cfg["n_test_iter_refinement"], class_csv_dir=csv_dir, eval_classes=["Liver"], crop_size=[64, 64],
+               k=4, use_registration_loss=True, do_deformable=False)
+    ds = FewshotRegReader(data_dir, set_name, cfg, mode="eval")
+    assert isinstance(ds, RealReader) and len(ds) == 3
+    net = build(cfg, False)
+    aff, few, ref = evaluate(net, ds, cfg)
+    assert len(few["Liver"]) == 3 and all(0.0 <= d <= 1.0 for d in few["Liver"])
+    assert all(d is not None and d > 0.2 for d in aff["Liver"])       # the affine-warped support label overlaps the organ
+    assert sorted(ref["Liver"].keys()) == list(range(10)) and few["Liver"] == list(ref["Liver"][9])
+
+
 def test_two_way_extension_vs_composed_oracle():
     """BASELINE config 5 shape class (2-way, fp32 here): no reference behaviour; oracle composed from the
     reference's own pieces, incl. gradients of the well-conditioned CRE block and the align loss."""
