@@ -308,12 +308,30 @@ int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, si
  *                            with zero iterations: an align_corners=True identity grid sampled with align_corners=False)
  * post(v) = scale * (threshold >= 0 ? (v > threshold) : v) + shift                  (few_shot_reader.py:168,172,190,196) */
 int rpnet_affine_register(const float* moving, const float* fixed, const float* xs, const float* ys, float* theta,
-                          float* loss, int B, int H, int W, int iters, float lr, float beta1, float beta2, float eps,
+                          float* loss, int B, int H, int W, int iters, double lr, double beta1, double beta2, double eps,
                           rpnet_stream_t stream);
 int rpnet_affine_warp(const float* x, const float* theta, const float* xs, const float* ys, float* out, int B, int H, int W,
                       float threshold, float scale, float shift, rpnet_stream_t stream);
 int rpnet_identity_grid_warp(const float* x, float* out, int B, int H, int W, float threshold, float scale, float shift,
                              rpnet_stream_t stream);
+
+/* Deformable ("demons") stage, do_deformable: True (few_shot_reader.py:133-180; net/registration.py:195-212 Diffeomorphic
+ * with scaling 10, :225-313 DemonsRegistration.train_registraion with the NCC loss :157-160, :106-135 GaussianRegulariser).
+ * For every slice: flow [2][H][W] from zero by `iters` x { d = scaling-and-squaring(flow / 2^10); NCC(grid_sample(moving,
+ * compute_grid() + d), fixed); Adam(lr, betas, eps) on the flow; flow <- conv2d(flow, kernel, zero padding, per channel) }.
+ * moving = the AFFINE-warped source (net/registration.py:491: affine_reg(moving).detach()), fixed [S][H][W] in [0, 1];
+ * kernel [ksize][ksize] fp32 = the reference's normalised Gaussian (sigma [2,2] -> 9x9), built by the host;
+ * out: flow [S][2][H][W] (channel 0 = x), disp [S][2][H][W] = the displacement of the final flow, loss [S] (may be NULL)
+ * = NCC at the last evaluated flow.  All slices advance together: 24 launches per step enqueued from C on `stream`, no
+ * host synchronisation.  The bilinear scatter of the backward uses fp32 atomics (run-to-run order differs, as in the
+ * reference's own CUDA grid_sampler backward).  The optimiser's scalars are doubles (python floats in the reference).
+ * rpnet_displacement_warp   out = post(grid_sample(x, compute_grid() + disp))      (:246-261; post as above) */
+size_t rpnet_demons_workspace_bytes(int S, int H, int W);
+int rpnet_demons_register(const float* moving, const float* fixed, const float* kernel, int ksize, float* flow, float* disp,
+                          float* loss, int S, int H, int W, int iters, double lr, double beta1, double beta2, double eps,
+                          void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_displacement_warp(const float* x, const float* disp, float* out, int S, int H, int W, float threshold, float scale,
+                            float shift, rpnet_stream_t stream);
 
 #ifdef __cplusplus
 }

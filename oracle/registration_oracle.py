@@ -1,5 +1,6 @@
-"""CPU restatement of the reference's per-slice registration pre-step for the shipped configuration
-(yamls/example.yml: use_registration_loss: True, do_deformable: False).  TEST INFRASTRUCTURE ONLY: imported by
+"""CPU restatement of the reference's per-slice registration pre-step: the shipped configuration
+(yamls/example.yml: use_registration_loss: True, do_deformable: False) and, at the end of the file, the demons
+stage of do_deformable: True.  TEST INFRASTRUCTURE ONLY: imported by
 tests/ and tools/bench_registration.py's cpu_baseline leg, never by the product path (rpnet_amd/registration.py,
 which has no CPU fallback).
 
@@ -19,7 +20,9 @@ Follows, line by line:
       identity grid sampled with align_corners=False (a zoom by W / (W - 1) about the corner)
 
 Pinned by tests/golden/registration.npz, produced by tests/golden/gen_golden_registration.py from the reference's
-own get_registration_field (which runs on the CPU in this configuration).
+own get_registration_field (which runs on the CPU in this configuration), and tests/golden/registration_demons.npz
+from the reference's own AffineDemonsRegistration / GaussianRegulariser classes called in the order of
+few_shot_reader.py:133-180 (that branch of the reference function hard-codes cuda:0; no GPU in the build container).
 """
 import numpy as np
 import torch
@@ -84,3 +87,84 @@ def get_registration_field(query_images, support_images, support_labels, iters=5
 def adam_constants(iters, lr=0.01, b1=0.9, b2=0.999):
     """step_size and sqrt(bias_correction2) of torch.optim.Adam's single-tensor path, as python floats per step"""
     return [(lr / (1 - b1 ** t), float(np.sqrt(1 - b2 ** t))) for t in range(1, iters + 1)]
+
+
+# ------------------------------------------------------------------------------- demons stage (do_deformable: True)
+# Follows net/registration.py:195-212 (Diffeomorphic.diffeomorphic_2D, scaling = 10), :225-261 (DemonsRegistration,
+# flow parameter [1,2,H,W], forward = grid_sample(x, grid + diffeomorphic(flow))), :291-313 (train_registraion: NCC
+# loss, Adam, then the Gaussian regulariser smooths the flow in place), :14-31,43-49,106-135 (GaussianRegulariser:
+# 9x9 kernel for sigma 2, conv2d with zero padding, groups = 2), :157-160 (NCC), :474-502 (AffineDemonsRegistration:
+# the demons stage registers the AFFINE-warped, detached moving image), few_shot_reader.py:133-161 (use_diffeomorphic,
+# Adam lr 0.01 for both stages, sigma [2, 2], iters [50, 50], regularise_displacement False).
+def ncc(moving, fixed):
+    """the centred images are formed once per use, numerator first: autograd then accumulates the four gradient
+    contributions to `moving` in the reference's order (the optimisation amplifies a 1-ulp difference to 1e-3)"""
+    num = torch.sum((fixed - torch.mean(fixed)) * (moving - torch.mean(moving)))
+    den = torch.sqrt(torch.sum((fixed - torch.mean(fixed)) ** 2) * torch.sum((moving - torch.mean(moving)) ** 2) + 1e-10)
+    return -1.0 * num / den
+
+
+def gaussian_kernel_2d(sigma=(2.0, 2.0)):
+    def k1(s):
+        n = int(2 * np.ceil(s * 2) + 1)
+        x = np.linspace(-(n - 1) // 2, (n - 1) // 2, num=n)
+        k = 1.0 / (s * np.sqrt(2 * np.pi)) * np.exp(-(x ** 2) / (2 * s ** 2))
+        return k / np.sum(k)
+    k = np.tensordot(k1(sigma[0]), k1(sigma[1]), 0)
+    return torch.tensor(k / np.sum(k), dtype=torch.float32)
+
+
+def diffeomorphic(flow, grid_t, scaling=10):
+    """scaling and squaring: d <- d + d o (id + d), `scaling` times, from d = flow / 2^scaling"""
+    d = flow / (2 ** scaling)
+    for _ in range(scaling):
+        d = d + F.grid_sample(d, d.permute(0, 2, 3, 1) + grid_t, align_corners=False)
+    return d
+
+
+def displacement_warp(x, disp, grid_t):
+    return F.grid_sample(x, grid_t + disp.permute(0, 2, 3, 1), align_corners=False)
+
+
+def demons_register(moving, fixed, iters=50, lr=0.01, sigma=(2.0, 2.0)):
+    """moving (already affine-warped) / fixed [1,1,h,w] -> flow [1,2,h,w] after `iters` x {NCC, Adam, Gaussian smoothing}"""
+    h, w = moving.shape[-2:]
+    grid_t = compute_grid(h, w).permute(0, 2, 3, 1).contiguous()
+    flow = torch.nn.Parameter(torch.zeros(1, 2, h, w))
+    opt = torch.optim.Adam([flow], lr=lr)
+    kern = gaussian_kernel_2d(sigma)
+    pad = [(kern.shape[0] - 1) // 2, (kern.shape[1] - 1) // 2]
+    kern = kern[None, None].expand(2, -1, -1, -1).contiguous()
+    for _ in range(iters):
+        opt.zero_grad()
+        loss = ncc(displacement_warp(moving, diffeomorphic(flow, grid_t), grid_t), fixed)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            flow.data = F.conv2d(flow.data, kern, padding=pad, groups=2)
+    return flow.detach()
+
+
+def get_registration_field_deformable(query_images, support_images, support_labels, iters=(50, 50)):
+    """few_shot_reader.py:109-198 with do_deformable=True (which the reference runs on cuda:0; same operators).
+    Returns (thetas [S,2,3], flows [S,2,h,w], py_reg_pred, warped_src, py_affine_reg_pred, affine_warped_src)."""
+    src_all = (support_images[0][0][:, 0] + 1) / 2.0
+    dst_all = (query_images[:, 0] + 1) / 2.0
+    lab_all = support_labels[0][0]
+    thetas, flows, reg, wsrc, areg, asrc = [], [], [], [], [], []
+    for s in range(dst_all.shape[0]):
+        src, dst, lab = src_all[s][None, None], dst_all[s][None, None], lab_all[s][None, None].float()
+        h, w = src.shape[-2:]
+        grid_t = compute_grid(h, w).permute(0, 2, 3, 1).contiguous()
+        theta = affine_register(src, dst, iters[0])
+        flow = demons_register(affine_warp(src, theta), dst, iters[1])
+        disp = diffeomorphic(flow, grid_t)
+        aw_lab, aw_src = affine_warp(lab, theta), affine_warp(src, theta)
+        thetas.append(theta[0])
+        flows.append(flow[0])
+        reg.append((displacement_warp(aw_lab, disp, grid_t)[0, 0] > 0.1).float())
+        wsrc.append(displacement_warp(aw_src, disp, grid_t)[0, 0])
+        areg.append((aw_lab[0, 0] > 0.1).float())
+        asrc.append(aw_src[0, 0])
+    return (torch.stack(thetas), torch.stack(flows), torch.stack(reg)[:, None], torch.stack(wsrc) * 2 - 1,
+            torch.stack(areg)[:, None], torch.stack(asrc) * 2 - 1)

@@ -44,8 +44,8 @@ __device__ __forceinline__ Bilinear sample_zeros(const float* __restrict__ img, 
 __global__ __launch_bounds__(1024) void affine_register_kernel(const float* __restrict__ moving, const float* __restrict__ fixed,
                                                                 const float* __restrict__ xs, const float* __restrict__ ys,
                                                                 float* __restrict__ theta_out, float* __restrict__ loss_out,
-                                                                const int H, const int W, const int iters, const float lr,
-                                                                const float beta1, const float beta2, const float eps) {
+                                                                const int H, const int W, const int iters, const double lr,
+                                                                const double beta1, const double beta2, const double eps_d) {
     __shared__ float th[6], am[6], av[6];
     __shared__ double red[16][7];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(1024) void affine_register_kernel(const float* __re
     }
     __syncthreads();
     const float invn2 = 2.f / (float)HW, hw2 = 0.5f * (float)W, hh2 = 0.5f * (float)H;
+    // the optimiser's scalars are python doubles rounded to fp32 where they meet the fp32 tensors (1 - beta as a double first)
+    const float omb1 = (float)(1.0 - beta1), b2f = (float)beta2, omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
     for (int it = 1; it <= iters; ++it) {
         const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
         double s[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -86,12 +88,12 @@ __global__ __launch_bounds__(1024) void affine_register_kernel(const float* __re
             const float g = (float)gsum;
             // torch.optim.Adam, single-tensor path: exp_avg.lerp_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2);
             // denom = exp_avg_sq.sqrt() / sqrt(1 - b2^t) + eps; param.addcdiv_(exp_avg, denom, value = -lr / (1 - b1^t))
-            const float m = am[t] + (1.f - beta1) * (g - am[t]);
-            const float v = av[t] * beta2 + (1.f - beta2) * g * g;
+            const float m = am[t] + omb1 * (g - am[t]);
+            const float v = av[t] * b2f + omb2 * g * g;
             am[t] = m;
             av[t] = v;
-            const float step = (float)((double)lr / (1.0 - pow((double)beta1, (double)it)));
-            const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)it));
+            const float step = (float)(lr / (1.0 - pow(beta1, (double)it)));
+            const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)it));
             th[t] = th[t] - step * (m / (sqrtf(v) / bc2s + eps));
         }
         if (t == 6 && loss_out && it == iters) {
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
 }  // namespace rpnet
 
 extern "C" int rpnet_affine_register(const float* moving, const float* fixed, const float* xs, const float* ys, float* theta,
-                                     float* loss, int B, int H, int W, int iters, float lr, float beta1, float beta2,
-                                     float eps, rpnet_stream_t stream) {
+                                     float* loss, int B, int H, int W, int iters, double lr, double beta1, double beta2,
+                                     double eps, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(moving && fixed && xs && ys && theta, RPNET_ERR_ARG, "affine_register: null pointer");
     RPNET_REQUIRE(B >= 0 && H >= 2 && W >= 2 && iters >= 0 && (long)H * W < (1L << 30), RPNET_ERR_SHAPE,

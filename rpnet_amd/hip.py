@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librpnet_hip.so")
 _lib = None
 
-vp, ci, cf, cs = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+vp, ci, cf, cs, cd = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
 
 
 class ConvDesc(C.Structure):
@@ -56,7 +56,10 @@ _SIGS = {
     "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
-    "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, cf, vp]),
+    "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp]),
+    "rpnet_demons_workspace_bytes": (cs, [ci, ci, ci]),
+    "rpnet_demons_register": (ci, [vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp, cs, vp]),
+    "rpnet_displacement_warp": (ci, [vp, vp, vp, ci, ci, ci, cf, cf, cf, vp]),
     "rpnet_affine_warp": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, vp]),
     "rpnet_identity_grid_warp": (ci, [vp, vp, ci, ci, ci, cf, cf, cf, vp]),
     "rpnet_mask_adjoint": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),

@@ -87,3 +87,57 @@ for tag, seed, S, size in CASES:
                 f"{tag}_aff_pred": aff_pred.numpy().astype(np.uint8), f"{tag}_aff_src": np.asarray(aff_src, np.float32)})
 np.savez_compressed(os.path.join(HERE, "registration.npz"), **out)
 print("wrote registration.npz", os.path.getsize(os.path.join(HERE, "registration.npz")) / 1e6, "MB")
+
+
+# ------------------------------------------------------------------------- do_deformable: True (the demons stage)
+# The reference's get_registration_field hard-codes device "cuda:0" for this branch (few_shot_reader.py:137-143); the
+# container has no GPU, so the same call sequence (:133-180) is made here on the reference's own classes with
+# use_GPU=False — AffineDemonsRegistration(use_diffeomorphic=True), two Adam(lr 0.01), GaussianRegulariser sigma [2,2],
+# iters [50, 50] — a composed oracle in the sense of SURVEY.md §8c.
+def reference_deformable(qry, supp, lab, iters=(50, 50)):
+    src_all = (supp[0][0][:, 0].numpy() + 1) / 2.0
+    dst_all = (qry[:, 0].numpy() + 1) / 2.0
+    lab_all = lab[0][0].numpy()
+    res = {k: [] for k in ("theta", "flow", "reg", "wsrc", "areg", "asrc")}
+    for s in range(len(dst_all)):
+        src = torch.from_numpy(src_all[s])[None, None]
+        dst = torch.from_numpy(dst_all[s])[None, None]
+        src_label = torch.from_numpy(lab_all[s])[None, None]
+        size = src_all[s].shape
+        registration = refreg.AffineDemonsRegistration(size, use_diffeomorphic=True, use_GPU=False, stop_shear=False)
+        opts = [torch.optim.Adam(registration.affine_reg.parameters(), lr=0.01),
+                torch.optim.Adam(registration.demons.parameters(), lr=0.01)]
+        regulariser = refreg.GaussianRegulariser([1, 1], sigma=[2, 2], dtype=torch.float32, device="cpu")
+        registration.train_registraion(src, dst, opts, regulariser=regulariser, iters=list(iters),
+                                       regularise_displacement=False, verbose=False)
+        grid = refreg.compute_grid(size)
+        res["theta"].append(registration.affine_reg.theta.data[0].clone())
+        res["flow"].append(registration.demons.flow.data[0].clone())
+        res["reg"].append((registration(src_label, grid)[0, 0].data > 0.1).float())
+        res["wsrc"].append(registration(src, grid)[0, 0].data * 2 - 1)
+        res["areg"].append((registration.affine_reg(src_label)[0, 0].data > 0.1).float())
+        res["asrc"].append(registration.affine_reg(src)[0, 0].data * 2 - 1)
+    return {k: torch.stack(v) for k, v in res.items()}
+
+
+DCASES = [("d64", 87, 2, 64), ("d96", 88, 1, 96)]
+dout = {}
+for tag, seed, S, size in DCASES:
+    ep = synth.make_episode(seed, S, size)
+    supp = [[torch.from_numpy(ep["support_images"][0][0])]]
+    lab = [[torch.from_numpy(ep["support_fg"][0][0])]]
+    qry = torch.from_numpy(ep["query_images"])
+    ref = reference_deformable(qry, supp, lab)
+    o_th, o_fl, o_reg, o_wsrc, o_areg, o_asrc = RO.get_registration_field_deformable(qry, supp, lab)
+    e_fl = (o_fl - ref["flow"]).abs().max().item()
+    e_src = (o_wsrc - ref["wsrc"]).abs().max().item()
+    flips = int((o_reg[:, 0] != ref["reg"]).sum())
+    print(f"{tag}: oracle vs reference (demons): theta {(o_th - ref['theta']).abs().max().item():.2e}, flow {e_fl:.2e} "
+          f"(|flow| max {ref['flow'].abs().max().item():.3f}), warped source {e_src:.2e}, label flips {flips}")
+    assert e_fl < 1e-6 and e_src < 1e-5 and flips == 0, "oracle demons stage does not reproduce the reference"
+    dout.update({f"{tag}_dims": np.array([seed, S, size]), f"{tag}_theta": ref["theta"].numpy(), f"{tag}_flow": ref["flow"].numpy(),
+                 f"{tag}_base_grid": (torch.linspace(-1, 1, size) * (size - 1) / size).numpy(),
+                 f"{tag}_reg_pred": ref["reg"].numpy().astype(np.uint8), f"{tag}_warped_src": ref["wsrc"].numpy(),
+                 f"{tag}_aff_pred": ref["areg"].numpy().astype(np.uint8), f"{tag}_aff_src": ref["asrc"].numpy()})
+np.savez_compressed(os.path.join(HERE, "registration_demons.npz"), **dout)
+print("wrote registration_demons.npz", os.path.getsize(os.path.join(HERE, "registration_demons.npz")) / 1e6, "MB")
