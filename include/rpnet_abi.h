@@ -202,6 +202,10 @@ int rpnet_maxpool2_fwd(const float* z, float* out, int N, int H, int W, int C, r
 int rpnet_maxpool2_bwd(const float* z, const float* dpool, const float* skip, float* dz, int N, int H, int W,
                        int C, rpnet_stream_t stream);
 int rpnet_upsample2_bwd(const float* dyu, float* dx, int N, int H, int W, int C, rpnet_stream_t stream);
+/* out = srcs[0] + ... + srcs[n-1] (n <= 16 device pointers in a HOST array, 16-byte aligned, numel each): the gradient
+ * fan-in of a feature map with many consumers (autograd's chain of pairwise adds for the query features that feed the
+ * 2 T masked convolutions of the refinement loop, net/rp_net.py:275,281-312) in one pass. */
+int rpnet_sum_n(const float* const* srcs, int n, float* out, size_t numel, rpnet_stream_t stream);
 
 /* --------------------------------------------------------- context-correlation block
  * F.avg_pool2d(mask[:,None], scale) (net/rp_net.py:269-272,311): [B][H][W] -> [B][h][w] */

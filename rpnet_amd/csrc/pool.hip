@@ -279,3 +279,45 @@ extern "C" int rpnet_mask_avgpool(const float* mask, float* out, int B, int H, i
     hipLaunchKernelGGL(mask_avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, mask, out, B, H, W, scale);
     return check_launch("mask_avgpool");
 }
+
+// out = sum of n (<= 16) equally sized fp32 tensors: autograd's fan-in of a tensor with many consumers (the query
+// features feed 2 T convolutions, net/rp_net.py:275,283 inside the refinement loop :281-312) in ONE pass — (n + 1) x the
+// tensor in HBM traffic instead of the 3 (n - 1) x of a chain of pairwise adds.
+namespace rpnet {
+struct SumSources {
+    const float* p[16];
+};
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumSources src, const int n, float* __restrict__ out, const size_t n4,
+                                                     const size_t numel) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 acc = reinterpret_cast<const f32x4*>(src.p[0])[i];
+        for (int k = 1; k < n; ++k) acc += reinterpret_cast<const f32x4*>(src.p[k])[i];
+        reinterpret_cast<f32x4*>(out)[i] = acc;
+    }
+    if (blockIdx.x == 0) {
+        const size_t e = n4 * 4 + threadIdx.x;       // tail (< 4 elements)
+        if (e < numel) {
+            float acc = src.p[0][e];
+            for (int k = 1; k < n; ++k) acc += src.p[k][e];
+            out[e] = acc;
+        }
+    }
+}
+}  // namespace rpnet
+
+extern "C" int rpnet_sum_n(const float* const* srcs, int n, float* out, size_t numel, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(srcs && out, RPNET_ERR_ARG, "sum_n: null pointer");
+    RPNET_REQUIRE(n >= 1 && n <= 16, RPNET_ERR_SHAPE, "sum_n: n=%d (1..16)", n);
+    if (numel == 0) return RPNET_OK;
+    SumSources s;
+    for (int k = 0; k < 16; ++k) {
+        s.p[k] = srcs[k < n ? k : 0];
+        RPNET_REQUIRE(s.p[k] && ((size_t)s.p[k] & 15) == 0, RPNET_ERR_ARG, "sum_n: source %d null or not 16-byte aligned", k);
+    }
+    RPNET_REQUIRE(((size_t)out & 15) == 0, RPNET_ERR_ARG, "sum_n: output not 16-byte aligned");
+    const size_t n4 = numel / 4;
+    const int blocks = (int)(n4 / 256 < 1 ? 1 : (n4 / 256 > 8192 ? 8192 : n4 / 256));
+    hipLaunchKernelGGL(sum_n_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, n, out, n4, numel);
+    return check_launch("sum_n");
+}

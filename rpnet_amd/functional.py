@@ -487,6 +487,54 @@ class MaxPool3(Function):
         return dz, None
 
 
+# ------------------------------------------------------------------------ gradient fan-in
+def sum_n(tensors):
+    """one-pass sum of up to 16 equally shaped contiguous fp32 GPU tensors (rpnet_sum_n)"""
+    out = torch.empty_like(tensors[0])
+    for i in range(0, len(tensors), 15):
+        chunk = ([out] if i else []) + [t.contiguous() for t in tensors[i:i + 15]]
+        arr = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+        call("rpnet_sum_n", arr, len(chunk), ptr(out), out.numel())
+    return out
+
+
+class FanOut(Function):
+    """x -> n aliases of x for n consumers; the backward adds the n incoming gradients in ONE kernel (autograd's
+    own fan-in is a chain of n - 1 pairwise adds: 3 (n - 1) tensor passes instead of n + 1).  Used for the query
+    features, which feed the 2 T masked convolutions of the refinement loop (net/rp_net.py:275,281-312)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.shape = x.shape
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        live = [g for g in grads if g is not None]
+        if not live:
+            return None, None
+        return (live[0] if len(live) == 1 else sum_n(live)), None
+
+
+class SplitRows(Function):
+    """x [n0 + n1, ...] -> (x[:n0], x[n0:]) (the support and query halves of one encoder call); the backward is one
+    concatenation instead of autograd's zero-fill + copy + add per slice."""
+
+    @staticmethod
+    def forward(ctx, x, n0):
+        ctx.n = (n0, x.shape[0] - n0)
+        ctx.meta = (tuple(x.shape[1:]), x.device, x.dtype)
+        return x[:n0], x[n0:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, g1):
+        tail, dev, dt = ctx.meta
+        parts = [g if g is not None else torch.zeros((n,) + tail, device=dev, dtype=dt) for g, n in zip((g0, g1), ctx.n)]
+        return torch.cat(parts, 0), None
+
+
 # ------------------------------------------------------------------------ pooling
 class MaxPool2(Function):
     """nn.MaxPool2d(2, 2) (net/unet.py:397) on NHWC."""

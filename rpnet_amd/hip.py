@@ -57,6 +57,7 @@ _SIGS = {
     "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp]),
+    "rpnet_sum_n": (ci, [vp, ci, vp, cs, vp]),
     "rpnet_demons_workspace_bytes": (cs, [ci, ci, ci]),
     "rpnet_demons_register": (ci, [vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp, cs, vp]),
     "rpnet_displacement_warp": (ci, [vp, vp, vp, ci, ci, ci, cf, cf, cf, vp]),

@@ -8,10 +8,16 @@ children are parameter containers only — they are never called.
 
 Internal activation layout is NHWC; NCHW tensors appear only at the module boundary.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as RF
+
+# one-pass gradient fan-in for the feature maps with many consumers (RF.FanOut / RF.SplitRows); RPNET_FANIN=0 leaves
+# the fan-in to autograd's pairwise adds (A/B switch)
+_FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
 
 
 def _to_nhwc(x):
@@ -206,12 +212,14 @@ class ContextCorrelationEncoder(nn.Module):
 
     def forward_masked(self, fts, mask, cache):
         """cre(fts*mask, fts*(1-mask)) with the mask multiply fused into the conv gather
-        (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC, mask [B,h,w] or None."""
+        (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC (or a pair of aliases of it, one per convolution: RF.FanOut),
+        mask [B,h,w] or None."""
         t = self.training
+        fk, fq = fts if isinstance(fts, tuple) else (fts, fts)
         m1, m2 = (1, 2) if mask is not None else (0, 0)
         sp = self.radius == 5        # the correlation then takes the split planes of fm1 / fm2
-        fm1 = RF.conv_bn_relu(fts, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp)
-        fm2 = RF.conv_bn_relu(fts, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp)
+        fm1 = RF.conv_bn_relu(fk, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp)
+        fm2 = RF.conv_bn_relu(fq, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp)
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
@@ -287,7 +295,7 @@ class RP_Net(nn.Module):
         ns = supp.shape[0]
         if ns == B:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
-            supp_d4, qry_d4 = d4[:ns], d4[ns:]
+            supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
         else:
             supp_d4 = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
             qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
@@ -316,8 +324,11 @@ class RP_Net(nn.Module):
         qry_mask = RF.mask_avgpool(appr_query_labels.float(), self.scale)
         refinement = {}
         inter = pred = None
-        for i in range(self.num_iter):
-            inter = self.cre.forward_masked(qry_d4, qry_mask, cache)
+        # the query features feed 2 T convolutions: one-pass gradient fan-in instead of autograd's chain of adds
+        T = self.num_iter
+        qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
+        for i in range(T):
+            inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache)
             logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
             if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask
                 qry_mask = RF.SoftmaxPool.apply(logits, self.scale)
