@@ -212,25 +212,33 @@ __global__ __launch_bounds__(256) void flow_adam_kernel(const float* __restrict_
     out[e] = flow[e] - step * (m / (sqrtf(v) / bc2s + eps));
 }
 
-// flow = conv2d(tmp, K x K kernel, zero padding) per channel; d0 = flow / 2^10
+// flow = conv2d(tmp, K x K kernel, zero padding) per channel; d0 = flow / 2^10.  A block owns a 32 x 8 pixel tile and
+// stages the tile + halo and the kernel in LDS (K <= 17); the taps are accumulated in the row-major order of the
+// direct sum.
+constexpr int kSmoothTW = 32, kSmoothTH = 8, kSmoothMaxK = 17;
 __global__ __launch_bounds__(256) void smooth_kernel(const float* __restrict__ tmp, const float* __restrict__ kern, const int K,
                                                       float* __restrict__ flow, float* __restrict__ d0, const int H, const int W,
                                                       const float inv_scale) {
-    const int HW = H * W, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const int i = p / W, j = p - i * W, r = K / 2;
+    __shared__ float tile[(kSmoothTH + kSmoothMaxK - 1) * (kSmoothTW + kSmoothMaxK - 1)];
+    __shared__ float kw[kSmoothMaxK * kSmoothMaxK];
+    const int r = K / 2, span_w = kSmoothTW + 2 * r, span_h = kSmoothTH + 2 * r, t = threadIdx.x;
+    const int tiles_x = (W + kSmoothTW - 1) / kSmoothTW;
+    const int ty0 = (blockIdx.x / tiles_x) * kSmoothTH, tx0 = (blockIdx.x % tiles_x) * kSmoothTW;
+    const size_t HW = (size_t)H * W;
     const float* src = tmp + (size_t)blockIdx.y * HW;         // blockIdx.y = slice * 2 + channel
-    float acc = 0.f;
-    for (int u = 0; u < K; ++u) {
-        const int y = i + u - r;
-        if (y < 0 || y >= H) continue;
-        for (int v = 0; v < K; ++v) {
-            const int x = j + v - r;
-            if (x >= 0 && x < W) acc += kern[u * K + v] * src[y * W + x];
-        }
+    for (int e = t; e < K * K; e += 256) kw[e] = kern[e];
+    for (int e = t; e < span_w * span_h; e += 256) {
+        const int y = ty0 - r + e / span_w, x = tx0 - r + e % span_w;
+        tile[e] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
     }
-    flow[(size_t)blockIdx.y * HW + p] = acc;
-    d0[(size_t)blockIdx.y * HW + p] = acc * inv_scale;
+    __syncthreads();
+    const int ly = t / kSmoothTW, lx = t % kSmoothTW, y = ty0 + ly, x = tx0 + lx;
+    if (y >= H || x >= W) return;
+    float acc = 0.f;
+    for (int u = 0; u < K; ++u)
+        for (int v = 0; v < K; ++v) acc += kw[u * K + v] * tile[(ly + u) * span_w + lx + v];
+    flow[(size_t)blockIdx.y * HW + (size_t)y * W + x] = acc;
+    d0[(size_t)blockIdx.y * HW + (size_t)y * W + x] = acc * inv_scale;
 }
 
 // out = post(grid_sample(x, grid + d))
@@ -296,8 +304,9 @@ extern "C" int rpnet_demons_register(const float* moving, const float* fixed, co
                                      double beta2, double eps, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(moving && fixed && kernel && flow && disp && workspace, RPNET_ERR_ARG, "demons_register: null pointer");
-    RPNET_REQUIRE(S >= 0 && H >= 2 && W >= 2 && iters >= 0 && ksize >= 1 && (ksize & 1) && (long)H * W < (1L << 28),
-                  RPNET_ERR_SHAPE, "demons_register: S=%d H=%d W=%d iters=%d ksize=%d (odd)", S, H, W, iters, ksize);
+    RPNET_REQUIRE(S >= 0 && H >= 2 && W >= 2 && iters >= 0 && ksize >= 1 && (ksize & 1) && ksize <= kSmoothMaxK &&
+                      (long)H * W < (1L << 28),
+                  RPNET_ERR_SHAPE, "demons_register: S=%d H=%d W=%d iters=%d ksize=%d (odd, <= 17)", S, H, W, iters, ksize);
     if (S == 0) return RPNET_OK;
     RPNET_REQUIRE(workspace_bytes >= rpnet_demons_workspace_bytes(S, H, W), RPNET_ERR_WORKSPACE, "demons_register: workspace too small");
     Workspace w;
@@ -327,7 +336,7 @@ extern "C" int rpnet_demons_register(const float* moving, const float* fixed, co
         const float step = (float)(lr / (1.0 - pow(beta1, (double)it))), bc2s = (float)sqrt(1.0 - pow(beta2, (double)it));
         hipLaunchKernelGGL(flow_adam_kernel, dim3(cdiv((long)n, 256)), blk, 0, s, (const float*)flow, (const float*)w.g[x], w.am, w.av,
                            w.tmp, n, inv_scale, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step, bc2s, (float)eps);
-        hipLaunchKernelGGL(smooth_kernel, dim3(grid.x, S * 2), blk, 0, s, (const float*)w.tmp, kernel, ksize, flow, w.d[0], H, W, inv_scale);
+        hipLaunchKernelGGL(smooth_kernel, dim3(cdiv(H, kSmoothTH) * cdiv(W, kSmoothTW), S * 2), blk, 0, s, (const float*)w.tmp, kernel, ksize, flow, w.d[0], H, W, inv_scale);
     }
     forward();                                                 // the displacement of the final flow
     return check_launch("demons_register");
