@@ -64,17 +64,29 @@ int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int c
  * and a product x*y as the partial products of the planes, accumulated in fp32 by
  * v_mfma_f32_32x32x16_bf16:
  *   NP = 3: hh + hm + mh + hl + lh + mm   (dropped terms <= 2^-23 |x*y|: fp32 round-off level), 6 MFMAs
- *   NP = 2: hh + hm + mh                  (dropped terms <= 2^-16 |x*y|), 3 MFMAs
+ * Two planes are FP16 planes (v_mfma_f32_32x32x16_f16, same rate): x / s = h + l, h = fp16(x / s), l = fp16(x / s - h)
+ * with a power-of-two scale s (tensor scale of an activation / gradient, row scale of a weight) that maps a rigorous
+ * bound of the operand to <= 2^15 — 22 significand bits for everything within 2^-18 of the bound, an absolute floor of
+ * 2^-40 of the bound below — and a product is hh + hl + lh (dropped term <= 2^-22 |x*y|), 3 MFMAs; the accumulator is
+ * multiplied by the scales in the epilogue (exact).  Used where such a bound exists (every 3x3 convolution of the
+ * training step: BatchNorm outputs, BatchNorm gradients, weights); three bf16 planes everywhere else.
  * rpnet_split_bf16: x [rows][C] fp32 (optionally times a per-row factor s or 1-s: x*mask of
- * net/rp_net.py:275,283) -> out [planes][rows][C] bf16.  C % 8 == 0.
+ * net/rp_net.py:275,283) -> out [3][rows][C] bf16.  C % 8 == 0.
+ * rpnet_split_f16: the same into two fp16 planes of x f(mask) / s, s = max(*s_a, *s_b) (device scalars: the tensor
+ * scale(s) the producer(s) published — rpnet_bn_relu; s_b NULL or the second source of a concatenation), *s_out = s.
+ * rpnet_pack_conv_weight_split with planes == 2 also writes the row scales row_scale_wp [Cout] and row_scale_wd
+ * [cin_pad] (preset the padding rows to 1) = rpnet_conv_desc.acc_scale_col of the forward / dgrad launch.
  * rpnet_pack_conv_weight_split: as rpnet_pack_conv_weight, into
  *   wp [planes][taps][Cin_pad/32][Cout][32]   (k = input channel, contiguous per output channel)
  *   wd [planes][taps][Cout/32][Cin_pad][32]   (dgrad: k = output channel, taps flipped); wd may be NULL.
  * cin, cin_off0, cin_split, cin_off1 multiples of 8; cin_pad, cout multiples of 32. */
 int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
                      rpnet_stream_t stream);
+int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
+                    void* out, size_t rows, int C, rpnet_stream_t stream);
 int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
-                                 int cin_split, int cin_off1, int cin_pad, int planes, rpnet_stream_t stream);
+                                 int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
+                                 float* row_scale_wd, rpnet_stream_t stream);
 
 /* ------------------------------------------------------------- conv (implicit GEMM)
  * Replaces nn.Conv2d(k=3,s=1,p=1,bias=True) / nn.Conv2d(k=1) forward and its
@@ -119,6 +131,11 @@ typedef struct rpnet_conv_desc {
     void* y_split;                     /* optional (single destination, Co1 == 0): the final output also as split-bf16
                                           planes [split_out_planes][N*H*W][Cout] — what the next convolution reads */
     int split_out_planes;              /* 2 or 3 when y_split is set */
+    /* power-of-two scales of fp16 split operands (split_planes == 2; all NULL otherwise): the accumulator is
+       multiplied by acc_scale_col[column] * *acc_scale_x before the bias (column = output channel: the per-row scale of
+       the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
+       rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
+    const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
@@ -176,12 +193,22 @@ int rpnet_bn_stats_from_partial(const double* partial, int nblk, int N, int HW, 
 int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, int C,
                          rpnet_stream_t stream);
+/* Split outputs: planes == 3 -> bf16 planes of the value itself.  planes == 2 -> fp16 planes of value / s with a
+ * power-of-two TENSOR scale s written to *split_scale (device scalar), chosen from a rigorous bound of the output so
+ * that fp16 cannot overflow whatever the data: rpnet_bn_relu  |z| <= max_c(|gamma_c| sqrt(n) + |beta_c|) (needs gamma,
+ * beta; |xhat| <= sqrt(n) for any batch), rpnet_bn_bwd  |dy_c| <= |scale_c| (max|dz m| + |s1|/n + |s2|/sqrt(n)) with the
+ * maxima gathered by the reduction pass; s = pow2ceil(bound) 2^-15.  The consumer multiplies its accumulator by s
+ * (rpnet_conv_desc.acc_scale_x / acc_scale_dy). */
 int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
-                  int N, int HW, int C, int groups, rpnet_stream_t stream);
+                  const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
+                  rpnet_stream_t stream);
+/* the fp16 tensor scale of a BatchNorm + ReLU output alone (same value rpnet_bn_relu writes with planes == 2) */
+int rpnet_bn_act_scale(const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
+                       rpnet_stream_t stream);
 int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
-                 const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* dgamma, float* dbeta,
-                 int N, int HW, int C, int groups, int accumulate, void* workspace, size_t workspace_bytes,
-                 rpnet_stream_t stream);
+                 const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
+                 float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
+                 size_t workspace_bytes, rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:
  * dy = dz * [z > 0] (z may be NULL: no ReLU behind the conv) and db[c] = sum_pixels dy[p][c] */

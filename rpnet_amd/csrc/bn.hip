@@ -117,11 +117,45 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ 
 }
 
 // same, 8 channels per thread, plus the split-bf16 planes of z (the operand format of the next convolution)
+// NP = 2 (fp16 planes): the planes hold z / s with the power-of-two tensor scale s derived from a RIGOROUS bound of the
+// output, |z| = |gamma xhat + beta| <= |gamma| sqrt(n) + |beta| (|xhat_i| <= sqrt(n) for any data: (x_i - mean)^2 <= n var):
+// s = pow2ceil(max_c bound) 2^-15, so |z / s| <= 2^15 < 65504 whatever the input; typical values (|xhat| ~ 1) land at
+// 2^15 / sqrt(n) ~ 8 .. 300.  Every block recomputes s from the C channel parameters; block 0 publishes it in *s_out.
+__device__ __forceinline__ float block_max256(float m, float* red4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+}
+
+// the scale alone (see bn_relu_split_kernel): for outputs whose consumers split the fp32 tensor themselves
+__global__ __launch_bounds__(256) void bn_act_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const int C, const float sqrt_n, float* __restrict__ s_out) {
+    __shared__ float red4[4];
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
+    m = block_max256(m, red4);
+    if (threadIdx.x == 0) *s_out = pow2_scale(m);
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ z,
                                                              unsigned short* __restrict__ zs, size_t total8, int C8,
-                                                             size_t group8, size_t plane_elems) {
+                                                             size_t group8, size_t plane_elems, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float sqrt_n,
+                                                             float* __restrict__ s_out) {
+    float inv_s = 1.f;
+    if (NP == 2) {
+        __shared__ float red4[4];
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C8 * 8; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
+        const float sc = pow2_scale(block_max256(m, red4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
+        inv_s = 1.f / sc;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
         const int c8 = (int)(i % C8);
         const int g = (int)(i / group8);
@@ -137,6 +171,10 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
             for (int k = 0; k < 4; ++k) { o[k] = fmaxf(a[k] * s4[k] + h4[k], 0.f); v[hh * 4 + k] = o[k]; }
             reinterpret_cast<f32x4*>(z)[i * 2 + hh] = o;
         }
+        if (NP == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= inv_s;
+        }
         u32x4 pl[NP];
         split8<NP>(v, pl);
 #pragma unroll
@@ -144,12 +182,15 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
     }
 }
 
-// partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat
+// partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat; pmax[(g*nblk + blk)][C] = max |dz*m| (optional)
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const float* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       double* __restrict__ partial, long R, int C, BnGeom gm) {
+                                                       double* __restrict__ partial, float* __restrict__ pmax, long R, int C,
+                                                       BnGeom gm) {
     __shared__ double red[256 * 8];
+    __shared__ float redm[256 * 4];
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
     const int t = threadIdx.x;
     const int tc = t % gm.C4, tr = t / gm.C4;
     const int g = blockIdx.y, blk = blockIdx.x;
@@ -170,40 +211,61 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                 const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
                 s1[k] += dm;
                 s2[k] += (double)dm * ((v[k] - mu[k]) * is[k]);
+                mx[k] = fmaxf(mx[k], fabsf(dm));
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; }
+    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; redm[t * 4 + k] = mx[k]; }
     __syncthreads();
     if (tr == 0) {
         for (int rr = 1; rr < gm.rows_it; ++rr)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { s1[k] += red[(rr * gm.C4 + tc) * 8 + k]; s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k]; }
+            for (int k = 0; k < 4; ++k) {
+                s1[k] += red[(rr * gm.C4 + tc) * 8 + k];
+                s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k];
+                mx[k] = fmaxf(mx[k], redm[(rr * gm.C4 + tc) * 4 + k]);
+            }
         double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k * 2] = s1[k]; o[k * 2 + 1] = s2[k]; }
+        if (pmax) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pmax[(size_t)(g * gm.nblk + blk) * C + tc * 4 + k] = mx[k];
+        }
     }
 }
 
 // coef[g][C][2] floats = (s1/R, s2/R); dgamma/dbeta summed over groups
+// bound[c] (optional, with pmax): a rigorous bound of |dy| of channel c over all groups,
+//   |dy| = |scale| |dz m - s1/R - xhat s2/R| <= |scale| (max |dz m| + |s1|/R + sqrt(R) |s2|/R)
 __global__ __launch_bounds__(64) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
-                                float* coef, float* dgamma, float* dbeta, int accumulate) {
+                                float* coef, float* dgamma, float* dbeta, int accumulate, const float* __restrict__ pmax,
+                                const float* __restrict__ scale, float* __restrict__ bound) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
+    float bnd = 0.f;
     for (int g = 0; g < G; ++g) {
         double s1 = 0, s2 = 0;
+        float mx = 0.f;
         for (int b = lane; b < nblk; b += 64) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
+            if (pmax) mx = fmaxf(mx, pmax[(size_t)(g * nblk + b) * C + c]);
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (pmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            bnd = fmaxf(bnd, fabsf(scale[g * C + c]) * (mx + (float)(fabs(s1) / (double)R) + (float)(fabs(s2) / sqrt((double)R))));
+        }
         if (lane == 0) {
             coef[(g * C + c) * 2] = (float)(s1 / (double)R);
             coef[(g * C + c) * 2 + 1] = (float)(s2 / (double)R);
         }
         tb += s1; tg += s2;
     }
+    if (pmax && lane == 0) bound[c] = bnd * 1.0001f;
     if (lane == 0) {
         if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
         else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
@@ -244,8 +306,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restric
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dy,
                                                            unsigned short* __restrict__ dys, size_t total8, int C,
-                                                           size_t group8, size_t plane_elems) {
+                                                           size_t group8, size_t plane_elems, const float* __restrict__ bound,
+                                                           float* __restrict__ s_out) {
     const int C8 = C / 8;
+    float inv_s = 1.f;
+    if (NP == 2) {     // fp16 planes of dy / s, s = pow2ceil(max_c bound[c]) 2^-15 (see bn_bwd_finalize)
+        __shared__ float red4[4];
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, bound[c]);
+        const float sc = pow2_scale(block_max256(m, red4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
+        inv_s = 1.f / sc;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
         const int c8 = (int)(i % C8);
         const int g = (int)(i / group8);
@@ -269,6 +341,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restric
             }
             if (dy) reinterpret_cast<f32x4*>(dy)[i * 2 + hh] = q;
         }
+        if (NP == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] *= inv_s;
+        }
         u32x4 pl[NP];
         split8<NP>(r, pl);
 #pragma unroll
@@ -284,7 +360,9 @@ static int elt_grid(size_t total4) {
 }  // namespace rpnet
 
 extern "C" size_t rpnet_bn_workspace_bytes(int C, int groups) {
-    return (size_t)groups * 256 * C * 2 * sizeof(double) + (size_t)groups * C * 2 * sizeof(float);
+    // partial sums (fp64), coefficients, per-block maxima and per-channel bounds (the last two for fp16 split outputs)
+    return (size_t)groups * 256 * C * 2 * sizeof(double) + (size_t)groups * C * 2 * sizeof(float) +
+           (size_t)groups * 256 * C * sizeof(float) + (size_t)C * sizeof(float);
 }
 
 static int bn_check(const char* who, int N, int HW, int C, int groups) {
@@ -338,7 +416,8 @@ extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const
 }
 
 extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
-                             int N, int HW, int C, int groups, rpnet_stream_t stream) {
+                             const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
+                             rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && scale && shift && z, RPNET_ERR_ARG, "bn_relu: null pointer");
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
@@ -346,12 +425,15 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
     if (z_split) {
         RPNET_REQUIRE((planes == 2 || planes == 3) && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
+        RPNET_REQUIRE(planes == 3 || (gamma && beta && split_scale), RPNET_ERR_ARG,
+                      "bn_relu: two planes (fp16) need gamma, beta and the scale output");
+        const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
         if (planes == 3)
             hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
-                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe);
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         else
             hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
-                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe);
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         return check_launch("bn_relu_split");
     }
     hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z,
@@ -359,9 +441,18 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
     return check_launch("bn_relu");
 }
 
+extern "C" int rpnet_bn_act_scale(const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
+                                  rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(gamma && beta && split_scale && groups >= 1 && C > 0, RPNET_ERR_ARG, "bn_act_scale: bad argument");
+    hipLaunchKernelGGL(bn_act_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gamma, beta, C,
+                       sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f, split_scale);
+    return check_launch("bn_act_scale");
+}
+
 extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
-                            const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* dgamma,
-                            float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
+                            const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
+                            float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
                             size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
@@ -376,19 +467,25 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     hipStream_t s = (hipStream_t)stream;
     double* partial = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)groups * 256 * C * 2 * sizeof(double));
+    const bool f16 = dy_split && planes == 2;
+    RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: two planes (fp16) need the scale output");
+    float* pmax = f16 ? coef + (size_t)groups * C * 2 : nullptr;
+    float* bound = f16 ? pmax + (size_t)groups * 256 * C : nullptr;
     hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
-                       R, C, gm);
+                       pmax, R, C, gm);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(64), 0, s, (const double*)partial, gm.nblk, R, C, groups,
-                       coef, dgamma, dbeta, accumulate);
+                       coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (dy_split) {
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
         if (planes == 3)
             hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
-                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe);
+                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
+                               split_scale);
         else
             hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
-                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe);
+                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
+                               split_scale);
         return check_launch("bn_bwd");
     }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,

@@ -32,6 +32,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
                                               const int wm, const int wn, const int li, const int h, void* lds) {
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
+    const float xs = d.acc_scale_x ? *d.acc_scale_x : 1.f;     // fp16 split operands: power-of-two tensor / row scales
     if (d.stats_partial) {
         // train-mode BatchNorm statistics of y = acc + bias, fused: this wave's 32*WM rows of each of
         // its columns -> one (sum, sum of squares) pair per column (the two lane halves hold the same
@@ -45,13 +46,14 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn * WN * 32 + j * 32 + li;
             const float bv = d.bias ? d.bias[col] : 0.f;
+            const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
             float sm = 0.f, sq = 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    const float v = row >= 0 ? acc[i][j][r] + bv : 0.f;
+                    const float v = row >= 0 ? acc[i][j][r] * as + bv : 0.f;
                     sm += v;
                     sq += v * v;
                 }
@@ -75,6 +77,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn * WN * 32 + j * 32 + li;
         const float bv = d.bias ? d.bias[col] : 0.f;
+        const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
         float* dst; int Cd, cd;
         if (col < d.Co0) { dst = d.y0; Cd = d.Co0; cd = col; } else { dst = d.y1; Cd = d.Co1; cd = col - d.Co0; }
 #pragma unroll
@@ -83,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             for (int r = 0; r < 16; ++r) {
                 const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
                 if (row >= 0) {
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] * as + bv;
                     if (d.ep_scale) {
                         const int g = row / per_group;
                         v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];

@@ -41,11 +41,68 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     }
 }
 
+// fp16 planes of x * f(mask) / s with the tensor scale s = max(*s_a, *s_b) (device scalars; s_b optional): the operand
+// of a convolution whose input is a BatchNorm output (scale from rpnet_bn_relu), pooled / masked / concatenated
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, const float* __restrict__ mask, const int mode,
+                                                         const float* __restrict__ s_a, const float* __restrict__ s_b,
+                                                         float* __restrict__ s_out, unsigned short* __restrict__ out,
+                                                         const size_t n8, const int C8, const size_t plane_elems) {
+    const float sc = fmaxf(*s_a, s_b ? *s_b : 0.f);
+    if (s_out && blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
+    const float inv = 1.f / sc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (mode) {      // x * f(mask) rounded to fp32 as the reference does, then the exact power-of-two scale
+            float f = mask[i / C8];
+            if (mode == 2) f = 1.f - f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= inv;
+        u32x4 o[2];
+        split8<2>(v, o);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(out + p * plane_elems + i * 8) = o[p];
+    }
+}
+
+// power-of-two row scales of the fp16 weight planes: t[cout] over (cin, tap), u[gathered cin row] over (cout, tap)
+__global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __restrict__ w, float* __restrict__ t,
+                                                                float* __restrict__ u, int cout, int cin_w, int taps,
+                                                                int off0, int split, int off1) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float m = 0.f;
+    if (b < cout) {
+        const float* row = w + (size_t)b * cin_w * taps;
+        for (int e = tid; e < cin_w * taps; e += 256) m = fmaxf(m, fabsf(row[e]));
+    } else {
+        const int cin = b - cout;
+        for (int e = tid; e < cout * taps; e += 256) m = fmaxf(m, fabsf(w[((size_t)(e / taps) * cin_w + cin) * taps + e % taps]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (b < cout) t[b] = pow2_scale(m);
+        else {
+            const int cin = b - cout;
+            u[cin < split ? off0 + cin : off1 + (cin - split)] = pow2_scale(m);
+        }
+    }
+}
+
 // w [Cout][cin_w][taps] -> wp [plane][tap][Cin_g/32][Cout][32] (+ wd [plane][tapflip][Cout/32][Cin_g][32])
 template <int NP>
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                                                  unsigned short* __restrict__ wd, int taps, int Cin_g,
-                                                                 int Cout, int cin_w, int off0, int split, int off1) {
+                                                                 int Cout, int cin_w, int off0, int split, int off1,
+                                                                 const float* __restrict__ t_row, const float* __restrict__ u_row) {
     __shared__ float tile[9][32][33];  // [tap][cin_l][cout_l]
     const int t = threadIdx.x;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -67,6 +124,11 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __r
             float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = tile[tap][g * 8 + q][cl];
+            if (NP == 2) {
+                const float inv = 1.f / t_row[co0 + cl];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= inv;
+            }
             u32x4 o[NP];
             split8<NP>(v, o);
             const size_t dst = (((size_t)tap * (Cin_g >> 5) + (row >> 5)) * Cout + co0 + cl) * 32 + (row & 31);
@@ -84,6 +146,11 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __r
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = tile[tap][c][g * 8 + q];
+                if (NP == 2) {
+                    const float inv = 1.f / u_row[row];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= inv;
+                }
                 u32x4 o[NP];
                 split8<NP>(v, o);
                 const int tf = taps - 1 - tap;
@@ -254,7 +321,7 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<NP>(af[pa][i], bfr[pb][j], acc[i][j]);
         }
     };
 
@@ -443,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<NP>(af[pa][i], bfr[pb][j], acc[i][j]);
             }
         }
     };
@@ -633,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<NP>(af[pa][i], bfr[pb][j], acc[i][j]);
             }
         }
     };
@@ -804,33 +871,51 @@ extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mo
                                 int planes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && out && (scale_mode == 0 || scale), RPNET_ERR_ARG, "split_bf16: null pointer");
-    RPNET_REQUIRE(C > 0 && C % 8 == 0 && (planes == 2 || planes == 3) && scale_mode >= 0 && scale_mode <= 2, RPNET_ERR_SHAPE,
-                  "split_bf16: C=%d planes=%d mode=%d", C, planes, scale_mode);
+    RPNET_REQUIRE(C > 0 && C % 8 == 0 && planes == 3 && scale_mode >= 0 && scale_mode <= 2, RPNET_ERR_SHAPE,
+                  "split_bf16: C=%d planes=%d (3; two planes are fp16 with a tensor scale: rpnet_split_f16) mode=%d", C, planes, scale_mode);
     if (rows == 0) return RPNET_OK;
     const size_t n8 = rows * (size_t)(C / 8);
     const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
-    if (planes == 3)
-        hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
-    else
-        hipLaunchKernelGGL(split_bf16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
+                       (unsigned short*)out, n8, C / 8, rows * (size_t)C);
     return check_launch("split_bf16");
 }
 
+extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
+                               void* out, size_t rows, int C, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && out && s_a && (mask_mode == 0 || mask), RPNET_ERR_ARG, "split_f16: null pointer");
+    RPNET_REQUIRE(C > 0 && C % 8 == 0 && mask_mode >= 0 && mask_mode <= 2, RPNET_ERR_SHAPE, "split_f16: C=%d mode=%d", C, mask_mode);
+    if (rows == 0) return RPNET_OK;
+    const size_t n8 = rows * (size_t)(C / 8);
+    const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
+                       (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    return check_launch("split_f16");
+}
+
 extern "C" int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
-                                            int cin_split, int cin_off1, int cin_pad, int planes, rpnet_stream_t stream) {
+                                            int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
+                                            float* row_scale_wd, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(w && wp, RPNET_ERR_ARG, "pack_conv_weight_split: null pointer");
+    RPNET_REQUIRE(planes != 2 || (row_scale_wp && row_scale_wd), RPNET_ERR_ARG,
+                  "pack_conv_weight_split: two planes (fp16) need the row scale outputs");
     RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 32 == 0 && (taps == 9 || taps == 1) && (planes == 2 || planes == 3),
                   RPNET_ERR_SHAPE, "pack_conv_weight_split: cout %d cin_pad %d taps %d planes %d", cout, cin_pad, taps, planes);
     RPNET_REQUIRE(cin % 8 == 0 && cin_off0 % 8 == 0 && cin_split % 8 == 0 && cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
                   "pack_conv_weight_split: channel counts / offsets must be multiples of 8");
     if (planes == 3)
         hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1);
-    else
+                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
+                           (const float*)nullptr, (const float*)nullptr);
+    else {
+        // row_scale_wd covers the cin_pad gathered rows; the caller presets the padding rows (any non-zero value)
+        hipLaunchKernelGGL(weight_row_scale_kernel, dim3(cout + cin), dim3(256), 0, (hipStream_t)stream, w, row_scale_wp, row_scale_wd,
+                           cout, cin, taps, cin_off0, cin_split, cin_off1);
         hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1);
+                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
+                           (const float*)row_scale_wp, (const float*)row_scale_wd);
+    }
     return check_launch("pack_conv_weight_split");
 }

@@ -325,7 +325,8 @@ void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split, in
 // (8 row groups x 32 lanes read 128-byte rows of every split) and writes it transposed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                             int ksplit, int taps, int Cin_g, int Cout, int cin_w,
-                                                            int off0, int split, int off1, int accumulate) {
+                                                            int off0, int split, int off1, int accumulate,
+                                                            const float* __restrict__ sx, const float* __restrict__ sdy) {
     // one block = a 32 (cin) x 32 (cout) tile of ALL taps: the sums over the K splits land in LDS as
     // [tap][cin][cout] and leave as rows of 32 cin x taps contiguous floats per output channel — the
     // state_dict layout [Cout][Cin][taps] written with full lines instead of 4-byte pieces 36 bytes apart
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 }
                 for (; z < ksplit; ++z) s0 += p[(size_t)z * zstride];
                 s = (s0 + s1) + (s2 + s3);
+                if (sx) s *= *sx * *sdy;          // fp16 split operands: the two power-of-two tensor scales
             }
             tile[tap][rr][cl] = s;
         }
@@ -487,8 +489,11 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
             if (dy)      // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
                 if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
             if (!dw) return RPNET_OK;       // GEMM phase only: the partial sums stay in the workspace
+            RPNET_REQUIRE(d->split_planes != 2 || (d->acc_scale_x && d->acc_scale_dy), RPNET_ERR_ARG,
+                          "conv_wgrad: fp16 planes need acc_scale_x and acc_scale_dy");
             hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
-                               Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
+                               Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate,
+                               d->split_planes == 2 ? d->acc_scale_x : nullptr, d->acc_scale_dy);
             return check_launch("wgrad_reduce");
         }
 #define RPNET_W9(P2, IS, LW, LH)                                                                                   \
@@ -503,7 +508,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         int rc9 = check_launch("conv_wgrad9");
         if (rc9) return rc9;
         hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
-                           Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
+                           Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate, (const float*)nullptr, (const float*)nullptr);
         return check_launch("wgrad_reduce");
     }
     int bm, bn, ks, sps;
@@ -525,7 +530,7 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
     int rc = check_launch("conv_wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, d->taps), dim3(256), 0, s, part, dw, ks, d->taps,
-                       Cin, Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate);
+                       Cin, Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate, (const float*)nullptr, (const float*)nullptr);
     return check_launch("wgrad_reduce");
 }
 

@@ -19,13 +19,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "split_bf16.h"
 
 namespace rpnet {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 using s16x8 = __attribute__((ext_vector_type(8))) short;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
                         const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx)
-                            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa], bf[kx][pb], acc[kx], 0, 0, 0);
+                            acc[kx] = mma16<NP>(af[pa], bf[kx][pb], acc[kx]);
                     }
                 }
             } else {
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
                         const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
                         for (int tap = 0; tap < 9; ++tap)
-                            acc[tap % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap / 3][pa], bf[tap % 3][pb], acc[tap % NACC], 0, 0, 0);
+                            acc[tap % NACC] = mma16<NP>(af[tap / 3][pa], bf[tap % 3][pb], acc[tap % NACC]);
                     }
                 };
                 bf16x8 afA[3][NP], bfA[3][NP], afB[3][NP], bfB[3][NP];

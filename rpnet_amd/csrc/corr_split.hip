@@ -273,7 +273,7 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
                                           int cstride, int planes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && (planes == 2 || planes == 3), RPNET_ERR_SHAPE,
+    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && planes == 3, RPNET_ERR_SHAPE,
                   "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d", r, C, cstride, planes);
     RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_fwd: image too large");
     const int tiles = cdiv(h, 8) * cdiv(w, 8);
@@ -292,7 +292,7 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
                                           size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_split_bwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 2 || planes == 3), RPNET_ERR_SHAPE,
+    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && planes == 3, RPNET_ERR_SHAPE,
                   "local_corr_split_bwd: r=%d (5) C=%d (multiple of 128) cstride=%d planes=%d", r, C, cstride, planes);
     RPNET_REQUIRE(workspace_bytes >= rpnet_local_corr_bwd_workspace_bytes(B, h, w, cstride), RPNET_ERR_WORKSPACE,
                   "local_corr_split_bwd: workspace too small");

@@ -29,19 +29,31 @@ BN_MOMENTUM = 0.1
 # joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
 _ASYNC = {"on": False, "side": {}, "pending": set()}
 
-# Arithmetic of the 3x3 convolutions (forward, dgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
+# Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
 # v_mfma_f32_32x32x16_bf16 partial products into fp32 accumulators (dropped terms <= 2^-23 |x*y|: fp32
-# round-off level, 16/6 of the fp32 matrix rate); "bf16x2" = two planes, three products (2^-16).
-_MATH = {"planes": {"f32": 0, "bf16x3": 3, "bf16x2": 2}[os.environ.get("RPNET_CONV_MATH", "bf16x3")]}
+# round-off level, 16/6 of the fp32 matrix rate); "f16x2" = two FP16 planes of operand / (power-of-two scale) and
+# three v_mfma_f32_32x32x16_f16 products (dropped term 2^-22 |x*y|, 16/3 of the fp32 matrix rate) wherever a
+# rigorous bound of the operand gives a scale that cannot overflow fp16 — the train-mode conv + BatchNorm layers:
+# BatchNorm outputs, BatchNorm gradients, weights — and bf16x3 everywhere else (eval mode, vgg, correlation).
+_MODES = {"f32": (0, False), "bf16x3": (3, False), "f16x2": (3, True)}
+_MATH = {}
 
 
 def set_conv_math(mode):
-    _MATH["planes"] = {"f32": 0, "bf16x3": 3, "bf16x2": 2}[mode]
+    _MATH["mode"] = mode
+    _MATH["planes"], _MATH["f16"] = _MODES[mode]
+
+
+set_conv_math(os.environ.get("RPNET_CONV_MATH", "bf16x3"))
 
 
 def conv_math():
-    return {0: "f32", 3: "bf16x3", 2: "bf16x2"}[_MATH["planes"]]
+    return _MATH["mode"]
+
+
+def f16_mode():
+    return _MATH["f16"]
 
 
 def set_async_wgrad(on=True):
@@ -121,6 +133,45 @@ def _use_split(pw, x0, x1):
             and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0))
 
 
+def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True):
+    """fp16 planes of x * f(mask) / s, s = max(s_a, s_b) (device scalars) -> (planes [2, ...], s [1]) (rpnet_split_f16)"""
+    hip.require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.float16)
+    s = torch.empty(1, device=x.device, dtype=torch.float32) if want_scale else None
+    c = x.shape[-1]
+    call("rpnet_split_f16", ptr(x), ptr(mask), mode if mask is not None else 0, ptr(s_a), ptr(s_b), ptr(s), ptr(out),
+         x.numel() // c, c)
+    return out, s
+
+
+def _f16_sources(x0, x1, in_scale, in_mode, x_scales):
+    """fp16 operand planes of a convolution's source(s) with ONE tensor scale, or None when a source carries no
+    rigorous bound (then the caller falls back to three bf16 planes).  A BatchNorm output arrives with its planes
+    and scale (`_rp_split16`, written by rpnet_bn_relu); pooled / masked / concatenated sources are split here from
+    the fp32 tensor with the scale(s) of their producer(s) (`_rp_scale`, or handed in as x_scales)."""
+    s0 = x_scales[0] if x_scales else getattr(x0, "_rp_scale", None)
+    s1 = None
+    if x1 is not None:
+        s1 = (x_scales[1] if x_scales and len(x_scales) > 1 else None)
+        if s1 is None:
+            s1 = getattr(x1, "_rp_scale", None)
+        if s1 is None:
+            return None
+    if s0 is None:
+        return None
+    masked = in_scale is not None and in_mode
+    if x1 is None and not masked:
+        c = getattr(x0, "_rp_split16", None)
+        if c is not None and c[0].shape[1:] == x0.shape:
+            return c[0], None, c[1]
+    xs0, s = split_f16(x0, s0, s1, in_scale if masked else None, in_mode if masked else 0)
+    xs1 = split_f16(x1, s0, s1, want_scale=False)[0] if x1 is not None else None
+    if x1 is None and not masked:
+        x0._rp_split16 = (xs0, s)
+    return xs0, xs1, s
+
+
 # ------------------------------------------------------------------ weight packing
 class PackedWeight:
     """Packed copies of one nn.Conv2d weight (see rpnet_pack_conv_weight)."""
@@ -159,16 +210,25 @@ class PackedWeight:
         return self._wd
 
     def split_packs(self, planes):
-        """bf16 split packs of the same weight (rpnet_pack_conv_weight_split), made on first use."""
-        if self.wps is None or self.wps.shape[0] != planes:
+        """split packs of the same weight (rpnet_pack_conv_weight_split), made on first use: planes == 3 -> (wp, wd) bf16
+        planes; planes == 2 -> (wp, wd, row scale of wp [cout], row scale of wd [cin_pad]) fp16 planes of w / row scale."""
+        if self.wps is None:
+            self.wps = {}
+        pk = self.wps.get(planes)
+        if pk is None:
             n = self.taps * self.cin_pad * self.cout
             mk = torch.zeros if self.cin_pad != self.cin else torch.empty
             w = self._weight
-            self.wps = mk((planes, n), device=w.device, dtype=torch.bfloat16)
-            self.wds = mk((planes, n), device=w.device, dtype=torch.bfloat16)
-            call("rpnet_pack_conv_weight_split", ptr(w), ptr(self.wps), ptr(self.wds), self.cout, self.cin, self.taps,
-                 self.off0, self.split, self.off1, self.cin_pad, planes)
-        return self.wps, self.wds
+            dt = torch.bfloat16 if planes == 3 else torch.float16
+            wps, wds = mk((planes, n), device=w.device, dtype=dt), mk((planes, n), device=w.device, dtype=dt)
+            t = u = None
+            if planes == 2:
+                t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
+                u = torch.ones(self.cin_pad, device=w.device, dtype=torch.float32)
+            call("rpnet_pack_conv_weight_split", ptr(w), ptr(wps), ptr(wds), self.cout, self.cin, self.taps,
+                 self.off0, self.split, self.off1, self.cin_pad, planes, ptr(t), ptr(u))
+            pk = self.wps[planes] = (wps, wds) if planes == 3 else (wps, wds, t, u)
+        return pk
 
 
 class WeightCache:
@@ -218,7 +278,7 @@ class ConvBnRelu(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, in_scale, weight, bias, gamma, beta, running_mean, running_var, nbt, pw, training,
-                groups, upsample, in_mode, out_split=True):
+                groups, upsample, in_mode, out_split=True, x_scales=None):
         hip.require_gpu(x0, weight)
         N, Hs, Ws, _ = x0.shape
         H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
@@ -255,11 +315,18 @@ class ConvBnRelu(Function):
             return z
         y = _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
-        fused, xs = 0, None
+        fused, xs, sx = 0, None, None
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
-            if _use_split(pw, x0, x1):
+            f16 = _f16_sources(x0, x1, in_scale, in_mode, x_scales) if (_MATH["f16"] and _use_split(pw, x0, x1)) else None
+            if f16 is not None:      # two fp16 planes with a tensor scale; weights with row scales
+                xs, sx = (f16[0], f16[1]), f16[2]
+                wps, _, t_row, _ = pw.split_packs(2)
+                d = _desc(xs[0], xs[1], wps, bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
+                d.split_planes = 2
+                d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(sx)
+            elif _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
                 xs = (_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_))
                 d = _desc(xs[0], xs[1], pw.split_packs(np_)[0], bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
@@ -281,14 +348,27 @@ class ConvBnRelu(Function):
             call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
                  ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
                  ptr(ws), wsb)
-        np_out = _MATH["planes"] if (out_split and cout % 32 == 0) else 0
-        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
-        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, N, H * W, cout, groups)
-        if zs is not None:
-            z._rp_split = zs      # the next convolution's operand, produced here instead of by a separate pass
+        # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution (fp16 planes with
+        # the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), False = none
+        want16 = _MATH["f16"] and cout % 32 == 0
+        np_out = 0
+        if out_split and cout % 32 == 0 and _MATH["planes"]:
+            np_out = 2 if (want16 and out_split != "corr") else _MATH["planes"]
+        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out == 2 else torch.bfloat16) if np_out else None
+        sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
+        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
+             ptr(sz) if np_out == 2 else None, N, H * W, cout, groups)
+        if np_out == 2:
+            z._rp_split16 = (zs, sz)      # the next convolution's operand, produced here instead of by a separate pass
+        elif zs is not None:
+            z._rp_split = zs
+        if want16:
+            if np_out != 2:               # the scale alone (pooled / concatenated / masked consumers split the fp32 tensor)
+                call("rpnet_bn_act_scale", ptr(gamma), ptr(beta), ptr(sz), N, H * W, cout, groups)
+            z._rp_scale = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
-        ctx.bias, ctx.beta, ctx.xs = bias, beta, xs
+        ctx.bias, ctx.beta, ctx.xs, ctx.sx = bias, beta, xs, sx
         return z
 
     @staticmethod
@@ -311,11 +391,12 @@ class ConvBnRelu(Function):
         wsplit = bool(np_) and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
         dsplit = bool(np_) and cout % 32 == 0 and need_d
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
+        sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ == 2) else None   # fp16: tensor scale
         dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
-             ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(gamma.grad if direct else dgamma),
+             ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
              ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(ws), wsb)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
@@ -330,6 +411,8 @@ class ConvBnRelu(Function):
                 d = _desc(ctx.xs[0], ctx.xs[1], None, None, None, 0, None, None, N, H, W, pw.taps, upsample,
                           co_split=(cout, 0))
                 d.split_planes = np_
+                if np_ == 2:
+                    d.acc_scale_x, d.acc_scale_dy = ptr(ctx.sx), ptr(sdy)
             else:
                 dyp = dy
                 d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
@@ -352,7 +435,7 @@ class ConvBnRelu(Function):
                     else:
                         call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                              ptr(ws2), wb)
-                for tns in (x0, x1, in_scale, dy, dyp) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
+                for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
                     if tns is not None:
                         tns.record_stream(side)
                 if not _ASYNC["pending"]:
@@ -371,9 +454,12 @@ class ConvBnRelu(Function):
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
                 need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
                 if dsplit:
-                    dd = _desc(dys, None, pw.split_packs(np_)[1], None, None, 0, g0, g1, N, H, W,
+                    pk = pw.split_packs(np_)
+                    dd = _desc(dys, None, pk[1], None, None, 0, g0, g1, N, H, W,
                                pw.taps, 0, out_scale=None if need_s else in_scale, out_mode=in_mode)
                     dd.split_planes = np_
+                    if np_ == 2:
+                        dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
@@ -391,17 +477,19 @@ class ConvBnRelu(Function):
                 dx1 = g1 if need1 else None
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = None if _direct(bias) else torch.zeros_like(gamma)
-        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
-                 out_split=True):
-    """out_split: also write the output as split-bf16 planes (when the split arithmetic is on): pass False
-    when the consumer is not a 3x3 convolution."""
+                 out_split=True, x_scales=None):
+    """out_split: also write the output as the split planes of its consumer (when the split arithmetic is on): True = a
+    3x3 convolution reads it as is, "corr" = the local correlation, False = neither (pooled / concatenated / 1x1
+    consumers).  x_scales: the fp16 tensor scales of the sources when they do not travel on the tensors themselves
+    (`_rp_scale` is lost by slicing / reshaping)."""
     pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
     return ConvBnRelu.apply(x0, x1, in_scale, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                             bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
-                            1 if upsample else 0, in_mode, out_split)
+                            1 if upsample else 0, in_mode, out_split, x_scales)
 
 
 class ConvRelu(Function):
@@ -545,6 +633,9 @@ class MaxPool2(Function):
         out = _empty((N, H // 2, W // 2, Cc), z)
         call("rpnet_maxpool2_fwd", ptr(z), ptr(out), N, H, W, Cc)
         ctx.save_for_backward(z)
+        sc = getattr(z, "_rp_scale", None)
+        if sc is not None:
+            out._rp_scale = sc            # a subset of the source's values: its fp16 tensor scale still bounds them
         return out
 
     @staticmethod

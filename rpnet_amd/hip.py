@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("x0", vp), ("x1", vp), ("C0", ci), ("C1", ci), ("w", vp), ("bias", vp), ("in_scale", vp),
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
-                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci)]
+                ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
+                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp)]
 
 
 _SIGS = {
@@ -29,7 +30,8 @@ _SIGS = {
     "rpnet_last_error_string": (C.c_char_p, []),
     "rpnet_pack_conv_weight": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_split_bf16": (ci, [vp, vp, ci, vp, cs, ci, ci, vp]),
-    "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_split_f16": (ci, [vp, vp, ci, vp, vp, vp, vp, cs, ci, vp]),
+    "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
@@ -41,8 +43,9 @@ _SIGS = {
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
     "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
-    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
-    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_bn_act_scale": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
     "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
     "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

@@ -48,10 +48,11 @@ class conv_block(nn.Module):
             nn.Conv2d(ch_out, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
-    def forward_nhwc(self, x0, cache, x1=None, groups=1):
+    def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True):
+        """out_split: whether a 3x3 convolution reads the block's output as is (RF.conv_bn_relu)"""
         t = self.training
         x = RF.conv_bn_relu(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups)
-        return RF.conv_bn_relu(x, self.conv[3], self.conv[4], cache, t, groups=groups)
+        return RF.conv_bn_relu(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
         return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
@@ -69,8 +70,9 @@ class up_conv(nn.Module):
             nn.Conv2d(ch_in, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
-    def forward_nhwc(self, x, cache, groups=1):
-        return RF.conv_bn_relu(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True)
+    def forward_nhwc(self, x, cache, groups=1, out_split=True):
+        return RF.conv_bn_relu(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True,
+                               out_split=out_split)
 
     def forward(self, x):
         return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
@@ -119,15 +121,18 @@ class U_Net(Unet_2D):
         if x.shape[1] % 16 or x.shape[2] % 16:
             raise ValueError(f"U_Net needs H, W multiples of 16, got {tuple(x.shape[1:3])}")
         pool = RF.MaxPool2.apply
-        x1 = self.Conv1.forward_nhwc(x, cache, groups=groups)
-        x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups)
-        x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups)
-        x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups)
+        # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
+        # scale per convolution), so those producers skip their own operand planes
+        sk = not (RF.f16_mode() and self.training)
+        x1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk)
+        x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups, out_split=sk)
+        x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups, out_split=sk)
+        x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups, out_split=sk)
         x5 = self.Conv5.forward_nhwc(pool(x4), cache, groups=groups)
-        d5 = self.Up5.forward_nhwc(x5, cache, groups=groups)
+        d5 = self.Up5.forward_nhwc(x5, cache, groups=groups, out_split=sk)
         d5 = self.Up_conv5.forward_nhwc(x4, cache, x1=d5, groups=groups)      # cat((x4, d5), 1) as two sources
-        d4 = self.Up4.forward_nhwc(d5, cache, groups=groups)
-        return self.Up_conv4.forward_nhwc(x3, cache, x1=d4, groups=groups)    # cat((x3, d4), 1)
+        d4 = self.Up4.forward_nhwc(d5, cache, groups=groups, out_split=sk)
+        return self.Up_conv4.forward_nhwc(x3, cache, x1=d4, groups=groups, out_split=sk)    # cat((x3, d4), 1)
 
     def forward(self, x, mask=None, do_last_conv=True):
         n, c, h, w = x.shape
@@ -210,16 +215,17 @@ class ContextCorrelationEncoder(nn.Module):
         if (2 * self.radius + 1) ** 2 > RF.CORR_STRIDE:
             raise NotImplementedError("mask_refinement_correlation_radius > 5")
 
-    def forward_masked(self, fts, mask, cache):
+    def forward_masked(self, fts, mask, cache, fts_scale=None):
         """cre(fts*mask, fts*(1-mask)) with the mask multiply fused into the conv gather
         (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC (or a pair of aliases of it, one per convolution: RF.FanOut),
         mask [B,h,w] or None."""
         t = self.training
         fk, fq = fts if isinstance(fts, tuple) else (fts, fts)
         m1, m2 = (1, 2) if mask is not None else (0, 0)
-        sp = self.radius == 5        # the correlation then takes the split planes of fm1 / fm2
-        fm1 = RF.conv_bn_relu(fk, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp)
-        fm2 = RF.conv_bn_relu(fq, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp)
+        sp = "corr" if self.radius == 5 else False       # the correlation then takes the split planes of fm1 / fm2
+        xs = (fts_scale,) if fts_scale is not None else None
+        fm1 = RF.conv_bn_relu(fk, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp, x_scales=xs)
+        fm2 = RF.conv_bn_relu(fq, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp, x_scales=xs)
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
@@ -231,8 +237,9 @@ class ContextCorrelationEncoder(nn.Module):
     def forward(self, fm1, fm2):
         cache = RF.WeightCache()
         t = self.training
-        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=self.radius == 5)
-        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=self.radius == 5)
+        sp = "corr" if self.radius == 5 else False
+        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=sp)
+        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=sp)
         return _to_nchw(self._tail(a, b, cache))
 
 
@@ -295,16 +302,18 @@ class RP_Net(nn.Module):
         ns = supp.shape[0]
         if ns == B:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
+            s_supp = s_qry = getattr(d4, "_rp_scale", None)   # fp16 tensor scale of the features (f16x2 training)
             supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
         else:
             supp_d4 = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
             qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
+            s_supp, s_qry = getattr(supp_d4, "_rp_scale", None), getattr(qry_d4, "_rp_scale", None)
         supp_d4 = supp_d4.reshape(n_ways, n_shots, B, h, w, -1)
 
         # ---- support relation features, per (way, shot) with that shot's own mask (:269-275)
         fore = [[m.float().contiguous() for m in way] for way in fore_mask]
         back = [[m.float().contiguous() for m in way] for way in back_mask]
-        supp_fts = [[self.cre.forward_masked(supp_d4[wa, s], RF.mask_avgpool(fore[wa][s], self.scale), cache)
+        supp_fts = [[self.cre.forward_masked(supp_d4[wa, s], RF.mask_avgpool(fore[wa][s], self.scale), cache, s_supp)
                      for s in range(n_shots)] for wa in range(n_ways)]
 
         # ---- prototypes: constant across iterations, computed once (:288-300)
@@ -328,7 +337,7 @@ class RP_Net(nn.Module):
         T = self.num_iter
         qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
         for i in range(T):
-            inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache)
+            inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
             logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
             if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask
                 qry_mask = RF.SoftmaxPool.apply(logits, self.scale)

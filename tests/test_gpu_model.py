@@ -61,7 +61,7 @@ def test_unet_and_cre_vs_oracle():
             assert int(sd["encoder.Conv3.conv.1.num_batches_tracked"]) == 2 and int(sd["cre.w_k.1.num_batches_tracked"]) == 1
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["bf16x3", "f16x2", "f32"])
 def conv_math(request):
     """default arithmetic of the 3x3 convolutions (3-plane split-bf16, fp32-equivalent) and the fp32-MFMA kernels"""
     from rpnet_amd import functional as RF

