@@ -45,7 +45,7 @@ def set_conv_math(mode):
     _MATH["planes"], _MATH["f16"] = _MODES[mode]
 
 
-set_conv_math(os.environ.get("RPNET_CONV_MATH", "bf16x3"))
+set_conv_math(os.environ.get("RPNET_CONV_MATH", "f16x2"))
 
 
 def conv_math():
