@@ -307,6 +307,40 @@ def test_f16x2_chain_accuracy(RF):
         assert errs["bf16x3"][k] <= 1.5 * errs["f32"][k] + 2e-6, (k, errs)
 
 
+def test_f16x2_gradient_dynamic_range(RF):
+    """The fp16 planes of a BatchNorm gradient share ONE tensor scale.  With upstream gradients whose channel magnitudes
+    span six decades, the weight-gradient rows of the small channels must still be fp32-accurate: within 1.5x the
+    fp32 kernel's error (+2e-6) for channels down to 1e-4 of the largest, within 2e-5 at 1e-6 (measured 6.6e-6 there,
+    1.0e-6 at 1e-4.5; fp32 kernels 1.1e-6)."""
+    import copy
+    N, H, W, c = 4, 32, 32, 128
+    conv0, bn0 = _mk_layer(c, c, 3, 72)
+    conv1, bn1 = _mk_layer(c, c, 3, 71)
+    x = rnd(73, N, c, H, W)
+    decades = torch.arange(c).float() / (c / 6.0)
+    go = rnd(74, N, c, H, W) * (10.0 ** -decades)[None, :, None, None]
+    c0, b0, c1, b1 = [copy.deepcopy(m).double() for m in (conv0, bn0, conv1, bn1)]
+    xd = x.double().requires_grad_(True)
+    F.relu(b1.train()(c1(F.relu(b0.train()(c0(xd)))))).backward(go.double())
+    rw = c1.weight.grad
+    rows = {}
+    for math in ("f32", "f16x2"):
+        RF.set_conv_math(math)
+        try:
+            g0, gb0, g1, gb1 = [copy.deepcopy(m).to(DEV).train() for m in (conv0, bn0, conv1, bn1)]
+            cache = RF.WeightCache()
+            xg = nhwc(x).to(DEV).requires_grad_(True)
+            z = RF.conv_bn_relu(RF.conv_bn_relu(xg, g0, gb0, cache, True), g1, gb1, cache, True, out_split=False)
+            z.backward(nhwc(go).to(DEV))
+            gw = g1.weight.grad.double().cpu()
+            rows[math] = (gw - rw).abs().amax(dim=(1, 2, 3)) / rw.abs().amax(dim=(1, 2, 3))
+            assert rel_err(nchw(xg.grad), xd.grad) < 5e-6
+        finally:
+            RF.set_conv_math("f32")
+    assert (rows["f16x2"][decades <= 4.0] <= 1.5 * rows["f32"][decades <= 4.0].max() + 2e-6).all(), rows
+    assert rows["f16x2"].max() < 2e-5, rows
+
+
 def test_conv_masked_inputs(RF, conv_math):
     """w_k(x*m) and w_q(x*(1-m)) with the mask multiply fused into the gather (net/rp_net.py:275)."""
     N, H, W, Cc = 2, 8, 8, 64
