@@ -1,5 +1,5 @@
 """Per-launch table of the convolution calls of one profiled step (streams serialised): shape, duration, TFLOP/s
-of algorithmic fp32 FLOPs.  Usage: python tools/layer_tf.py [--conv-math f32|bf16x3|bf16x2]"""
+of algorithmic fp32 FLOPs.  Usage: python tools/layer_tf.py [--conv-math f16x2|bf16x3|f32]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, yaml
