@@ -348,12 +348,13 @@ class ConvBnRelu(Function):
             call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
                  ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
                  ptr(ws), wsb)
-        # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution (fp16 planes with
-        # the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), False = none
-        want16 = _MATH["f16"] and cout % 32 == 0
+        # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution reads it as is (fp16
+        # planes with the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), "scale" = no planes
+        # but the fp16 tensor scale (pooled / concatenated / masked 3x3 consumers split the fp32 tensor), False = none
+        want16 = _MATH["f16"] and cout % 32 == 0 and out_split in (True, "scale")
         np_out = 0
-        if out_split and cout % 32 == 0 and _MATH["planes"]:
-            np_out = 2 if (want16 and out_split != "corr") else _MATH["planes"]
+        if out_split in (True, "corr") and cout % 32 == 0 and _MATH["planes"]:
+            np_out = 2 if want16 else _MATH["planes"]
         zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out == 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
@@ -363,7 +364,7 @@ class ConvBnRelu(Function):
         elif zs is not None:
             z._rp_split = zs
         if want16:
-            if np_out != 2:               # the scale alone (pooled / concatenated / masked consumers split the fp32 tensor)
+            if np_out != 2:
                 call("rpnet_bn_act_scale", ptr(gamma), ptr(beta), ptr(sz), N, H * W, cout, groups)
             z._rp_scale = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
@@ -483,8 +484,8 @@ class ConvBnRelu(Function):
 def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
                  out_split=True, x_scales=None):
     """out_split: also write the output as the split planes of its consumer (when the split arithmetic is on): True = a
-    3x3 convolution reads it as is, "corr" = the local correlation, False = neither (pooled / concatenated / 1x1
-    consumers).  x_scales: the fp16 tensor scales of the sources when they do not travel on the tensors themselves
+    3x3 convolution reads it as is, "corr" = the local correlation, "scale" = no planes, only the fp16 tensor scale (a
+    pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers).  x_scales: the fp16 tensor scales of the sources when they do not travel on the tensors themselves
     (`_rp_scale` is lost by slicing / reshaping)."""
     pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
     return ConvBnRelu.apply(x0, x1, in_scale, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,

@@ -123,7 +123,7 @@ class U_Net(Unet_2D):
         pool = RF.MaxPool2.apply
         # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
         # scale per convolution), so those producers skip their own operand planes
-        sk = not (RF.f16_mode() and self.training)
+        sk = "scale" if (RF.f16_mode() and self.training) else True
         x1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk)
         x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups, out_split=sk)
         x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups, out_split=sk)

@@ -291,7 +291,7 @@ def test_f16x2_chain_accuracy(RF):
             ls = [(copy.deepcopy(cv).to(DEV), copy.deepcopy(b).to(DEV).train()) for cv, b in layers]
             cache = RF.WeightCache()
             xg = nhwc(x).to(DEV).requires_grad_(True)
-            z1 = RF.conv_bn_relu(xg, ls[0][0], ls[0][1], cache, True, out_split=False)
+            z1 = RF.conv_bn_relu(xg, ls[0][0], ls[0][1], cache, True, out_split="scale")
             sk = nhwc(F.relu(skip)).to(DEV)
             if RF.f16_mode():
                 sk._rp_scale = torch.tensor([2.0 ** -10], device=DEV)     # a bound handed in by the caller: |skip| < 8 = 2^-10 * 2^13
