@@ -341,7 +341,7 @@ def main():
                           "f16x2": "fp32 operands as 2 fp16 planes of operand / (power-of-two scale from a rigorous bound: "
                                    "BatchNorm outputs and gradients, weights), 3 v_mfma_f32_32x32x16_f16 partial products, "
                                    "fp32 accumulate (dropped term <= 2^-22 |x*y|; measured error vs fp64 = the fp32 matrix "
-                                   "instruction's); operands without a bound (eval mode, correlation) on 3 bf16 planes"}[math],
+                                   "instruction's); the local correlation the same way (block-local scale for its window gradients); operands without a bound (eval mode) on 3 bf16 planes"}[math],
             "config": {"workload": f"1-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
                                    f"(BASELINE configs[{(1 if world == 1 else 3) if args.shots == 1 else 2}]), train mode, align loss on, "
                                    "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",

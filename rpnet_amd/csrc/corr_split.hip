@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                                                                       const unsigned short* __restrict__ f2s,
                                                                       float* __restrict__ corr, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
-                                                                      const float inv_sqrt_c) {
+                                                                      const float inv_sqrt_c_in, const float* __restrict__ s1,
+                                                                      const float* __restrict__ s2) {
+    // NP = 2: fp16 planes of f / s with the producers' tensor scales (rpnet_bn_relu); the scores are multiplied by s1 s2
+    const float inv_sqrt_c = NP == 2 ? inv_sqrt_c_in * (*s1 * *s2) : inv_sqrt_c_in;
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NT_N = (NQ + 31) / 32, NQP = NT_N * 32;
     constexpr int A_BYTES = 64 * 64, B_BYTES = NQP * 64;            // one plane: [row][32 channels]
     constexpr int BJ = (NQ * 4 + 255) / 256;                        // halo pieces per thread and plane
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                     if (wv + 4 * j < NT_N) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mma16<NP>(af[pa][i], bfr[pb][j], acc[i][j]);
                     }
             }
         }
@@ -157,7 +160,7 @@ template <int R, int NP, int SIGN>
 __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float* __restrict__ g, const unsigned short* __restrict__ fos,
                                                                       float* __restrict__ df, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
-                                                                      const float inv_sqrt_c) {
+                                                                      const float inv_sqrt_c, const float* __restrict__ s_fo) {
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NCH = (NQ + 31) / 32, GS = (KK + 3) & ~3;
     constexpr int BN = 128, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
     constexpr int A_BYTES = 64 * 64, B_BYTES = 32 * RSB;
@@ -183,6 +186,22 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         const int p = e / GS, o = e - p * GS;
         const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
         gs[e] = (o < KK && y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] * inv_sqrt_c : 0.f;
+    }
+    // NP = 2: the window gradients have no a-priori bound, but the tile is right here: a block-local power-of-two scale
+    // from its own maximum (exact), the fo planes carry their producer's tensor scale; the result takes both back
+    float g_inv = 1.f, out_scale = 1.f;
+    if (NP == 2) {
+        __shared__ float red4[4];
+        __syncthreads();
+        float m = 0.f;
+        for (int e = t; e < 64 * GS; e += 256) m = fmaxf(m, fabsf(gs[e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) red4[wv] = m;
+        __syncthreads();
+        const float sg = pow2_scale(fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3])));
+        g_inv = 1.f / sg;
+        out_scale = sg * *s_fo;
     }
     // G slab piece of this thread: pixel row ap = t >> 2 (py, px), k-group t & 3
     const int ap = t >> 2, apy = ap >> 3, apx = ap & 7, akg = t & 3;
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
                 const int c = SIGN > 0 ? qy - apy : apy + 2 * R - qy;
                 const int a = SIGN > 0 ? qx - apx : apx + 2 * R - qx;
                 const bool in = q < NQ && c >= 0 && c < K && a >= 0 && a < K;
-                v[i] = in ? gs[ap * GS + a * K + c] : 0.f;
+                v[i] = in ? gs[ap * GS + a * K + c] * g_inv : 0.f;
             }
             u32x4 o[NP];
             split8<NP>(v, o);
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
             for (int q = 0; q < NPROD; ++q) {
                 const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb], acc[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[i] = mma16<NP>(af[pa][i], bfr[pb], acc[i]);
             }
         }
     }
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         for (int r = 0; r < 16; ++r) {
             const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
-            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = acc[i][r];
+            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = NP == 2 ? acc[i][r] * out_scale : acc[i][r];
         }
 }
 
@@ -270,29 +289,33 @@ int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, i
 }  // namespace rpnet
 
 extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, float* corr, int B, int h, int w, int C, int r,
-                                          int cstride, int planes, rpnet_stream_t stream) {
+                                          int cstride, int planes, const float* scale1, const float* scale2,
+                                          rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && planes == 3, RPNET_ERR_SHAPE,
-                  "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d", r, C, cstride, planes);
+    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && (planes == 3 || (planes == 2 && scale1 && scale2)),
+                  RPNET_ERR_SHAPE, "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d (2 = fp16 planes + their scales)", r, C,
+                  cstride, planes);
     RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_fwd: image too large");
     const int tiles = cdiv(h, 8) * cdiv(w, 8);
     const float isc = 1.0f / sqrtf((float)C);
     const unsigned short* a = (const unsigned short*)f1s;
     const unsigned short* b2 = (const unsigned short*)f2s;
     if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc,
+                           (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
+                           cstride, isc, scale1, scale2);
     return check_launch("local_corr_split_fwd");
 }
 
 extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, const float* dcorr, float* df1, float* df2, int B,
-                                          int h, int w, int C, int r, int cstride, int planes, void* workspace,
-                                          size_t workspace_bytes, rpnet_stream_t stream) {
+                                          int h, int w, int C, int r, int cstride, int planes, const float* scale1,
+                                          const float* scale2, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_split_bwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && planes == 3, RPNET_ERR_SHAPE,
+    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 3 || (planes == 2 && scale1 && scale2)), RPNET_ERR_SHAPE,
                   "local_corr_split_bwd: r=%d (5) C=%d (multiple of 128) cstride=%d planes=%d", r, C, cstride, planes);
     RPNET_REQUIRE(workspace_bytes >= rpnet_local_corr_bwd_workspace_bytes(B, h, w, cstride), RPNET_ERR_WORKSPACE,
                   "local_corr_split_bwd: workspace too small");
@@ -305,13 +328,13 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
     const unsigned short* b2 = (const unsigned short*)f2s;
     const dim3 grid(tiles, C / 128, B);
     if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2);
     if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;
     if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1);
     return check_launch("local_corr_split_bwd");
 }

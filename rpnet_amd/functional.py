@@ -37,6 +37,7 @@ _ASYNC = {"on": False, "side": {}, "pending": set()}
 # rigorous bound of the operand gives a scale that cannot overflow fp16 — the train-mode conv + BatchNorm layers:
 # BatchNorm outputs, BatchNorm gradients, weights — and bf16x3 everywhere else (eval mode, vgg, correlation).
 _MODES = {"f32": (0, False), "bf16x3": (3, False), "f16x2": (3, True)}
+_CORR16 = os.environ.get("RPNET_CORR_F16", "1") == "1"   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
 _MATH = {}
 
 
@@ -351,7 +352,7 @@ class ConvBnRelu(Function):
         # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution reads it as is (fp16
         # planes with the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), "scale" = no planes
         # but the fp16 tensor scale (pooled / concatenated / masked 3x3 consumers split the fp32 tensor), False = none
-        want16 = _MATH["f16"] and cout % 32 == 0 and out_split in (True, "scale")
+        want16 = _MATH["f16"] and cout % 32 == 0 and out_split in ((True, "scale", "corr") if _CORR16 else (True, "scale"))
         np_out = 0
         if out_split in (True, "corr") and cout % 32 == 0 and _MATH["planes"]:
             np_out = 2 if want16 else _MATH["planes"]
@@ -670,9 +671,16 @@ class LocalCorr(Function):
         B, h, w, Cc = f1.shape
         corr = _empty((B, h, w, CORR_STRIDE), f1)
         np_ = _MATH["planes"] if (r == 5 and Cc % 128 == 0) else 0
-        if np_:
+        c1, c2 = getattr(f1, "_rp_split16", None), getattr(f2, "_rp_split16", None)
+        if np_ and c1 is not None and c2 is not None and c1[0].shape[1:] == f1.shape and c2[0].shape[1:] == f2.shape:
+            # both inputs are BatchNorm outputs that came with fp16 planes and their tensor scales
+            (f1s, s1), (f2s, s2) = c1, c2
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, 2, ptr(s1), ptr(s2))
+            ctx.save_for_backward(f1s, f2s, s1, s2)
+            np_ = 2
+        elif np_:
             f1s, f2s = _split_operand(f1, np_), _split_operand(f2, np_)
-            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_)
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None)
             ctx.save_for_backward(f1s, f2s)
         else:
             call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
@@ -683,14 +691,15 @@ class LocalCorr(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dcorr):
-        f1, f2 = ctx.saved_tensors
+        f1, f2 = ctx.saved_tensors[:2]
+        s1, s2 = ctx.saved_tensors[2:] if ctx.np_ == 2 else (None, None)
         B, h, w, Cc = ctx.shape
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
         ws = _ws(wb, dcorr)
         if ctx.np_:
             call("rpnet_local_corr_split_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc,
-                 ctx.r, CORR_STRIDE, ctx.np_, ptr(ws), wb)
+                 ctx.r, CORR_STRIDE, ctx.np_, ptr(s1), ptr(s2), ptr(ws), wb)
         else:
             call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
                  CORR_STRIDE, ptr(ws), wb)

@@ -424,6 +424,42 @@ def test_local_correlation(RF, conv_math, dims):
     assert rel_err(nchw(a.grad), g1) < tol and rel_err(nchw(bb.grad), g2) < tol
 
 
+def test_local_correlation_f16_planes(RF):
+    """f16x2: the correlation of two BatchNorm outputs runs on their fp16 planes (tensor scales from the BatchNorm
+    bound; block-local scale for the window gradients in the backward) — against the same composite in fp64."""
+    import copy
+    from oracle import rpnet_oracle as O
+    N, H, W, c, r = 2, 16, 16, 128, 5
+    (ca, ba), (cb, bb_) = _mk_layer(c, c, 3, 81), _mk_layer(c, c, 3, 82)
+    x = rnd(83, N, c, H, W)
+    go = rnd(84, N, 121, H, W)
+    ra, rba, rb, rbb = [copy.deepcopy(m).double() for m in (ca, ba, cb, bb_)]
+    xd = x.double().requires_grad_(True)
+    f1, f2 = F.relu(rba.train()(ra(xd))), F.relu(rbb.train()(rb(xd)))
+    ref = O.local_correlation(f1, f2, r)
+    ref.backward(go.double())
+    errs = {}
+    for math in ("f32", "f16x2"):
+        RF.set_conv_math(math)
+        try:
+            ga, gba, gb, gbb = [copy.deepcopy(m).to(DEV).train() for m in (ca, ba, cb, bb_)]
+            cache = RF.WeightCache()
+            xg = nhwc(x).to(DEV).requires_grad_(True)
+            a = RF.conv_bn_relu(xg, ga, gba, cache, True, out_split="corr")
+            b = RF.conv_bn_relu(xg, gb, gbb, cache, True, out_split="corr")
+            if math == "f16x2":
+                assert getattr(a, "_rp_split16", None) is not None
+            out = RF.LocalCorr.apply(a, b, r)
+            gop = torch.zeros(N, H, W, 128)
+            gop[..., :121] = go.permute(0, 2, 3, 1)
+            out.backward(gop.to(DEV))
+            errs[math] = (rel_err(nchw(out[..., :121]), ref), rel_err(nchw(xg.grad), xd.grad), rel_err(ga.weight.grad, ra.weight.grad))
+        finally:
+            RF.set_conv_math("f32")
+    for k in range(3):
+        assert errs["f16x2"][k] <= 1.5 * errs["f32"][k] + 2e-6, errs
+
+
 def test_local_correlation_golden(RF, golden):
     g = golden("ops")
     b, c, h, w, r = (int(v) for v in g["corr_r5_dims"])
