@@ -3,8 +3,9 @@
 //   x = h + m (+ l),   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (exact for NP = 3)
 // and x*y is the sum of the partial products of the planes that matter, accumulated in fp32:
 //   NP = 3:  hh + hm + mh + hl + lh + mm      6 MFMAs, dropped terms <= 2^-23 |x*y|  (fp32 round-off level)
-//   NP = 2:  hh + hm + mh                     3 MFMAs, dropped terms <= 2^-16 |x*y|
-// i.e. 16/6 = 2.7x (NP = 3) the fp32 matrix rate for the same algorithmic FLOPs.
+//   NP = 2:  FP16 planes of x / s (power-of-two scale from a rigorous bound, split_bf16.h):  hh + hl + lh
+//                                             3 MFMAs (v_mfma_f32_32x32x16_f16), dropped term <= 2^-22 |x*y|
+// i.e. 16/6 = 2.7x (NP = 3) / 16/3 = 5.3x (NP = 2) the fp32 matrix rate for the same algorithmic FLOPs.
 //
 // The split is done ONCE by whoever produces a tensor (rpnet_split_bf16; weights by
 // rpnet_pack_conv_weight_split), never inside the GEMM: the implicit-GEMM kernel below only moves

@@ -4,9 +4,10 @@ Activations are fp32 NHWC tensors [N, H, W, C]; the module-boundary tensors of t
 reference (images, masks, logits) keep their NCHW layout.  Every Function calls
 librpnet_hip.so through rpnet_amd.hip — there is no torch-operator fallback.
 
-The 3x3 convolutions (forward, input and weight gradients) and the local correlation run by default on
-"split-bf16" operands (set_conv_math / RPNET_CONV_MATH, see _MATH below): the kernel that produces a tensor also
-writes it as three bf16 planes (`x._rp_split`), which is what the next convolution's operand loads read.
+The 3x3 convolutions (forward, input and weight gradients) and the local correlation run by default on split 16-bit
+operands (set_conv_math / RPNET_CONV_MATH, see _MATH below): the kernel that produces a tensor also writes it as two
+fp16 planes of tensor / scale (`x._rp_split16` = (planes, scale); scale from a rigorous bound, `x._rp_scale`) or, where
+no bound exists, as three exact bf16 planes (`x._rp_split`), which is what the next convolution's operand loads read.
 """
 import ctypes as C
 import os
