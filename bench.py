@@ -294,6 +294,10 @@ def main():
         loss = step(net, bucket, inp, scaler)
     fence()
     el = time.perf_counter() - t0
+    if math == "f16x2" and not RF.f16_mode():
+        # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16 planes
+        math = "bf16x3"
+        products, peak = MATH[math]
     if world > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -45,6 +45,7 @@ _MATH = {}
 def set_conv_math(mode):
     _MATH["mode"] = mode
     _MATH["planes"], _MATH["f16"] = _MODES[mode]
+    _MATH["f16_on"] = True
 
 
 set_conv_math(os.environ.get("RPNET_CONV_MATH", "f16x2"))
@@ -55,7 +56,15 @@ def conv_math():
 
 
 def f16_mode():
-    return _MATH["f16"]
+    """fp16 planes in use: the mode is f16x2 and the current forward is large enough for it to pay (set_f16_active)"""
+    return _MATH["f16"] and _MATH.get("f16_on", True)
+
+
+def set_f16_active(on):
+    """Per-forward switch of the fp16 planes inside the f16x2 mode: a single small episode is launch-bound and the
+    fp16 path's extra small launches (tensor scales, split passes of pooled / concatenated inputs) cost more than its
+    matrix work saves (batch 1 at 128^2: 6.3 vs 6.9 ms per step), so small calls stay on three bf16 planes."""
+    _MATH["f16_on"] = bool(on)
 
 
 def set_async_wgrad(on=True):
@@ -321,7 +330,7 @@ class ConvBnRelu(Function):
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
-            f16 = _f16_sources(x0, x1, in_scale, in_mode, x_scales) if (_MATH["f16"] and _use_split(pw, x0, x1)) else None
+            f16 = _f16_sources(x0, x1, in_scale, in_mode, x_scales) if (f16_mode() and _use_split(pw, x0, x1)) else None
             if f16 is not None:      # two fp16 planes with a tensor scale; weights with row scales
                 xs, sx = (f16[0], f16[1]), f16[2]
                 wps, _, t_row, _ = pw.split_packs(2)
@@ -353,7 +362,7 @@ class ConvBnRelu(Function):
         # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution reads it as is (fp16
         # planes with the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), "scale" = no planes
         # but the fp16 tensor scale (pooled / concatenated / masked 3x3 consumers split the fp32 tensor), False = none
-        want16 = _MATH["f16"] and cout % 32 == 0 and out_split in ((True, "scale", "corr") if _CORR16 else (True, "scale"))
+        want16 = f16_mode() and cout % 32 == 0 and out_split in ((True, "scale", "corr") if _CORR16 else (True, "scale"))
         np_out = 0
         if out_split in (True, "corr") and cout % 32 == 0 and _MATH["planes"]:
             np_out = 2 if want16 else _MATH["planes"]

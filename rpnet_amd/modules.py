@@ -18,6 +18,9 @@ from . import functional as RF
 # one-pass gradient fan-in for the feature maps with many consumers (RF.FanOut / RF.SplitRows); RPNET_FANIN=0 leaves
 # the fan-in to autograd's pairwise adds (A/B switch)
 _FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
+# f16x2 mode: encoder input pixels per call from which the fp16 planes are used (below: three bf16 planes; see
+# RF.set_f16_active).  262144 = batch 2 at 256^2, where the two arithmetics are level.
+_F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
 
 
 def _to_nhwc(x):
@@ -300,6 +303,7 @@ class RP_Net(nn.Module):
         supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
         qry = qry_imgs[0].float()
         ns = supp.shape[0]
+        RF.set_f16_active((ns + B) * H * W >= _F16_MIN_PIXELS)      # f16x2 mode: fp16 planes only where they pay
         if ns == B:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
             s_supp = s_qry = getattr(d4, "_rp_scale", None)   # fp16 tensor scale of the features (f16x2 training)

@@ -65,9 +65,12 @@ def test_unet_and_cre_vs_oracle():
 def conv_math(request):
     """default arithmetic of the 3x3 convolutions (3-plane split-bf16, fp32-equivalent) and the fp32-MFMA kernels"""
     from rpnet_amd import functional as RF
-    old = RF.conv_math()
+    from rpnet_amd import modules as RM
+    old, old_min = RF.conv_math(), RM._F16_MIN_PIXELS
     RF.set_conv_math(request.param)
+    RM._F16_MIN_PIXELS = 0          # the fp16 planes at every size (the default keeps small calls on bf16x3)
     yield request.param
+    RM._F16_MIN_PIXELS = old_min
     RF.set_conv_math(old)
 
 
