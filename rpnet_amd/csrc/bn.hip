@@ -102,7 +102,19 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 
 __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ z,
-                                                       size_t total4, int C4, size_t group4) {
+                                                       size_t total4, int C4, size_t group4, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float sqrt_n,
+                                                       float* __restrict__ s_out) {
+    if (s_out && blockIdx.x == 0) {      // the fp16 tensor scale of this output (see bn_relu_split_kernel), no planes
+        __shared__ float red4s[4];
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C4 * 4; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) red4s[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) *s_out = pow2_scale(fmaxf(fmaxf(red4s[0], red4s[1]), fmaxf(red4s[2], red4s[3])));
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
         const int g = (int)(i / group4);
@@ -436,8 +448,9 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         return check_launch("bn_relu_split");
     }
+    RPNET_REQUIRE(!split_scale || (gamma && beta), RPNET_ERR_ARG, "bn_relu: the tensor scale needs gamma and beta");
     hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z,
-                       total4, C / 4, group4);
+                       total4, C / 4, group4, gamma, beta, sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f, split_scale);
     return check_launch("bn_relu");
 }
 

@@ -368,15 +368,14 @@ class ConvBnRelu(Function):
             np_out = 2 if want16 else _MATH["planes"]
         zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out == 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
+        # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
-             ptr(sz) if np_out == 2 else None, N, H * W, cout, groups)
+             ptr(sz) if (np_out == 2 or (want16 and np_out == 0)) else None, N, H * W, cout, groups)
         if np_out == 2:
             z._rp_split16 = (zs, sz)      # the next convolution's operand, produced here instead of by a separate pass
         elif zs is not None:
             z._rp_split = zs
         if want16:
-            if np_out != 2:
-                call("rpnet_bn_act_scale", ptr(gamma), ptr(beta), ptr(sz), N, H * W, cout, groups)
             z._rp_scale = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
