@@ -13,11 +13,14 @@ loop) + backward + the flat-bucket gradient all-reduce.  Synthet
 episodes are generated once and are resident in HBM before the timed region; weights are
 name-seeded random init (no dataset / checkpoint exists offline).
 
-Arithmetic of the 3x3 convolutions (`--conv-math`, default bf16x3): every fp32 operand is carried as three
-bf16 planes (an exact split) and multiplied on the bf16 matrix pipe with six partial products into fp32
-accumulators — fp32-level accuracy (dropped terms <= 2^-23 |x*y|; tests/test_gpu_ops.py::test_split_conv_accuracy
-measures it against fp64 next to the fp32-MFMA kernel) at 16/6 of the fp32 matrix rate.  `f32` selects the
-v_mfma_f32_32x32x2_f32 kernels; the JSON line carries that figure too (`alt_math`).
+Arithmetic of the 3x3 convolutions (`--conv-math`, default f16x2): every fp32 operand is carried as two fp16
+planes of operand / (power-of-two scale from a rigorous bound) and multiplied on the fp16 matrix pipe with three
+partial products into fp32 accumulators — fp32-level accuracy (dropped term <= 2^-22 |x*y|;
+tests/test_gpu_ops.py::test_split_conv_accuracy measures it against fp64 next to the fp32-MFMA kernel) at 16/3 of the
+fp32 matrix rate; operands without a bound run as three bf16 planes (`bf16x3`, six products).  `f32` selects the
+v_mfma_f32_32x32x2_f32 kernels; the JSON line carries those figures too (`alt_math`).  `f16` = ONE fp16 plane (plain
+fp16 operands, fp32 accumulation and BatchNorm statistics): the reduced-precision arithmetic of BASELINE configs[4]
+(`--size 512 --iters 10 --ways 2 --batch 4 --conv-math f16`), reported with dtype "f16", never the headline.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live: every C-ABI call of one extra
 step is bracketed by HIP events on the launch stream; the dominant kernel is the implicit-GEMM
@@ -44,15 +47,32 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 # MFMA partial products issued per algorithmic fp32 multiply-add, and the resulting ceiling in algorithmic FLOPs
 # (the fp16 matrix instruction v_mfma_f32_32x32x16_f16 has the bf16 one's rate)
-MATH = {"f32": (1, PEAK_F32_MFMA_TFLOPS), "bf16x3": (6, PEAK_BF16_MFMA_TFLOPS / 6), "f16x2": (3, PEAK_BF16_MFMA_TFLOPS / 3)}
+MATH = {"f32": (1, PEAK_F32_MFMA_TFLOPS), "bf16x3": (6, PEAK_BF16_MFMA_TFLOPS / 6), "f16x2": (3, PEAK_BF16_MFMA_TFLOPS / 3),
+        "f16": (1, PEAK_BF16_MFMA_TFLOPS)}
 GF_PER_PAIR = {(256, 5): 675.4, (128, 1): 138.5}  # algorithmic fwd+bwd GFLOP per pair
 
 
-def algorithmic_gf_per_pair(size, T, n_shots=1):
-    """encoder 82.22 GF/image fwd at 256^2, CRE 10.12 GF/call, backward = 2x forward."""
+def algorithmic_gf_per_pair(size, T, n_shots=1, n_ways=1):
+    """encoder 82.22 GF/image fwd at 256^2, CRE 10.12 GF/call, backward = 2x forward; a pair has
+    ways x shots support images (one encoder pass and one CRE call each) + the query image and its T CRE calls
+    (configs[4]: 3 images + 12 CRE calls at 512^2 = 4416 GF)."""
     s = (size / 256.0) ** 2
-    imgs, cre_calls = n_shots + 1, n_shots + T
+    imgs, cre_calls = n_ways * n_shots + 1, n_ways * n_shots + T
     return 3.0 * (imgs * 82.22 + cre_calls * 10.12) * s
+
+
+def baseline_config(args, world):
+    """which BASELINE.json configuration the command line is (parity-test shapes other than [1] / [3] are not headline)"""
+    key = (args.ways, args.shots, args.size, args.iters)
+    if key == (1, 1, 256, 5):
+        return "BASELINE configs[1]" if world == 1 else "BASELINE configs[3]: the same per-GPU work, gradients all-reduced"
+    if key == (1, 5, 256, 5):
+        return "BASELINE configs[2]"
+    if key == (2, 1, 512, 10):
+        return "BASELINE configs[4]"
+    if key == (1, 1, 128, 1):
+        return "BASELINE configs[0] shape"
+    return "not a BASELINE configuration"
 
 
 def build_model(cfg, dev):
@@ -64,12 +84,12 @@ def build_model(cfg, dev):
     return net
 
 
-def make_inputs(seed, B, size, dev, n_shots=1):
+def make_inputs(seed, B, size, dev, n_shots=1, n_ways=1):
     from rpnet_amd.utils.synth import make_episode
-    ep = make_episode(seed, B, size, n_shots=n_shots)
+    ep = make_episode(seed, B, size, n_shots=n_shots, n_ways=n_ways)
     t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
-    return ([[t(s) for s in ep["support_images"][0]]], [[t(s) for s in ep["support_fg"][0]]],
-            [[t(s) for s in ep["support_bg"][0]]], [t(ep["query_images"])], t(ep["query_labels"]),
+    return ([[t(s) for s in way] for way in ep["support_images"]], [[t(s) for s in way] for way in ep["support_fg"]],
+            [[t(s) for s in way] for way in ep["support_bg"]], [t(ep["query_images"])], t(ep["query_labels"]),
             t(ep["appr_query_labels"]))
 
 
@@ -130,14 +150,17 @@ def profile_step(net, bucket, inp, scaler):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
-    command, KiB units, read side doubled per the gfx950 note of MI355X_MICROARCH.md).  A PMC
-    pass cannot run inside the timed process, so this is the offline figure or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    command, KiB units, read side doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_traffic.py).
+    A PMC pass cannot run inside the timed process, so this is the offline figure (its file named in
+    `traffic_source`) or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
         return None
-    d = json.load(open(path))
+    pmc_traffic.source = os.path.basename(files[-1])
+    d = json.load(open(files[-1]))
     n = b = 0.0
     for k, v in d.items():
         if "conv_igemm" in k:
@@ -180,41 +203,68 @@ def conv_accuracy_probe(dev):
     return out
 
 
-def cpu_baseline(cfg, size, T, seconds_budget=25.0, net=None, bucket=None, dev=None):
-    """The CPU oracle in as-written mode (the reference's operator sequence: all-pairs
-    correlation + grid_sample, explicit bilinear up-sampling in getFeatures, prototypes per
-    iteration) fwd+bwd on the host cores, batch 1, same loss.  Bounded sample.  With `net` (the benched model: same
-    seeded parameters) the same episode also goes through the HIP path under the arithmetic being benched and the two
-    results are compared (`parity`) — the oracle in its checker role, at the headline image size."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps):
+    """One CPU leg: the oracle fwd+bwd (same loss as the GPU step) on a seed-1234 synthetic episode, one warm-up step,
+    then timed steps until the budget or `max_steps`; returns (leg dict, state of the last step)."""
+    import statistics
     from oracle import rpnet_oracle as O
     from rpnet_amd.utils.synth import make_episode
-    ep = make_episode(1234, 1, size)
+    cfg = dict(cfg)
+    cfg["n_iter_refinement"] = T
+    ep = make_episode(1234, B, size)
     t = torch.from_numpy
     si, fg, bg = [[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], [[t(ep["support_bg"][0][0])]]
     qi, ql, appr = [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"])
     P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True)
-
     last = {}
 
     def one():
         for p in P.values():
             p.grad = None
-        out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True, as_written=True)
+        out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True, as_written=as_written)
         loss = O.total_loss(out, ql, cfg["align_loss_scaler"])
         loss.backward()
-        last["out"], last["loss"] = out["output"].detach(), loss.item()
+        last["loss"] = loss.item()
 
     one()  # warm-up
-    n, t0 = 0, time.perf_counter()
+    times, t_all = [], time.perf_counter()
     while True:
+        t0 = time.perf_counter()
         one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 8:
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > seconds_budget or len(times) >= max_steps:
             break
-    res = {"value": n / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{n} fwd+bwd steps of batch 1 at {size}x{size}, T={T}, oracle as-written mode "
-                     f"(reference operator sequence), {el / n:.2f} s/step"}
+    med = statistics.median(times)
+    leg = {"value": round(B / med, 4), "unit": "pairs/s", "batch": B, "size": size, "T": T,
+           "mode": "as-written (the reference's operator sequence: all-pairs correlation + grid_sample, explicit "
+                   "bilinear up-sampling in getFeatures, prototypes per iteration)" if as_written else
+                   "algorithmic (local-window correlation, adjoint-mask prototypes hoisted out of the loop)",
+           "steps": len(times), "median_s_per_step": round(med, 3)}
+    return leg, (P, last, (si, fg, bg, qi, ql, appr))
+
+
+def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=None, full=False):
+    """The CPU oracle fwd+bwd on the host cores, same loss.  `value` = the as-written mode (what "the
+    reference CPU path" costs) at batch 1 of the benched size, a bounded sample; `legs` adds the algorithmic mode and
+    BASELINE configs[0] (128^2, T=1) — and with --cpu-baseline-full batch 8 in both modes, 3 + 5 steps each (minutes).
+    With `net` (the benched model: same seeded parameters) the as-written episode also goes through the HIP path under
+    the arithmetic being benched and the two results are compared (`parity`) — the oracle in its checker role, at the
+    headline image size."""
+    main_leg, (P, last, (si, fg, bg, qi, ql, appr)) = _cpu_leg(cfg, size, T, 1, True, seconds_budget, 8 if not full else 5)
+    res = {"value": main_leg["value"], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+           "nproc": os.cpu_count(), "cpu_model": _cpu_model(),
+           "sample": f"{main_leg['steps']} fwd+bwd steps (median) of batch 1 at {size}x{size}, T={T}, oracle as-written mode "
+                     f"(reference operator sequence), {main_leg['median_s_per_step']:.2f} s/step", "legs": [main_leg]}
     if net is not None:
         mv = lambda a: a.to(dev)  # noqa: E731
         loss = step(net, bucket, ([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], mv(ql), mv(appr)),
@@ -227,10 +277,17 @@ def cpu_baseline(cfg, size, T, seconds_budget=25.0, net=None, bucket=None, dev=N
             grads[name] = float((a - b).norm() / b.norm())
         res["parity"] = {"what": f"the same batch-1 {size}x{size} episode and seeded parameters through the HIP path (arithmetic of this "
                                  "run) against the CPU oracle: loss, and relative L2 error of five weight gradients (these are conditioned by "
-                                 "ReLU / max-pool / 0.5-threshold switches: the fp32-MFMA kernels measure 2e-4 .. 6e-3 on the same comparison, "
-                                 "three bf16 planes 2e-4 .. 7e-3)",
+                                 "ReLU / max-pool / 0.5-threshold switches: tests/test_gpu_model.py::test_gradients_vs_fp64_yardstick "
+                                 "holds them against an fp64 oracle)",
                          "loss_hip": round(loss.item(), 6), "loss_oracle": round(last["loss"], 6),
                          "loss_rel_err": abs(loss.item() - last["loss"]) / abs(last["loss"]), "weight_grad_rel_l2_err": grads}
+    del P
+    extra = [(size, T, 1, False, 8.0, 5), (128, 1, 1, True, 4.0, 5)]
+    if full:
+        extra = [(size, T, 1, False, 60.0, 5), (size, T, 8, True, 600.0, 5), (size, T, 8, False, 300.0, 5),
+                 (128, 1, 1, True, 30.0, 5), (128, 1, 1, False, 30.0, 5)]
+    for sz, tt, bb, aw, budget, mx in extra:
+        res["legs"].append(_cpu_leg(cfg, sz, tt, bb, aw, budget, mx)[0])
     return res
 
 
@@ -243,9 +300,14 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5, help="T refinement iterations")
     ap.add_argument("--shots", type=int, default=1, help="support shots (5 with --batch 16 = BASELINE configs[2])")
+    ap.add_argument("--ways", type=int, default=1, help="ways (2 with --size 512 --iters 10 --batch 4 --conv-math f16 = "
+                                                        "BASELINE configs[4])")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="all CPU legs of BASELINE.md §4 (as-written and algorithmic, B=1 and B=8, and configs[0]); minutes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-math", choices=sorted(MATH), default=None,
-                    help="arithmetic of the 3x3 convolutions (default: the library's, bf16x3 = fp32-equivalent split)")
+                    help="arithmetic of the 3x3 convolutions (default: the library's, f16x2 = fp32-equivalent fp16 split; "
+                         "f16 = plain fp16 operands, configs[4] only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -273,12 +335,12 @@ def main():
     RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
     if args.conv_math:
         RF.set_conv_math(args.conv_math)
-    math = RF.conv_math()
+    requested = math = RF.conv_math()
     products, peak = MATH[math]
     net = build_model(cfg, dev)
     broadcast_parameters(net)
     bucket = FlatGradBucket(net)
-    inp = make_inputs(1234 + rank, args.batch, args.size, dev, args.shots)   # resident in HBM before timing
+    inp = make_inputs(1234 + rank, args.batch, args.size, dev, args.shots, args.ways)   # resident in HBM before timing
 
     def fence():
         torch.cuda.synchronize()
@@ -294,8 +356,9 @@ def main():
         loss = step(net, bucket, inp, scaler)
     fence()
     el = time.perf_counter() - t0
-    if math == "f16x2" and not RF.f16_mode():
-        # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16 planes
+    if math in ("f16x2", "f16") and not RF.f16_mode():
+        # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
+        # planes: label the line with what ran (`requested` keeps what was asked for, for the restore below)
         math = "bf16x3"
         products, peak = MATH[math]
     if world > 1:
@@ -306,18 +369,20 @@ def main():
 
     pairs = world * args.batch * args.steps
     value = pairs / el
-    gf_pair = algorithmic_gf_per_pair(args.size, args.iters, args.shots)
+    gf_pair = algorithmic_gf_per_pair(args.size, args.iters, args.shots, args.ways)
 
     result = None
     # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
     # issued by rank 0 alone would never complete); only rank 0 reports.
+    RF.reset_arith()
     agg = profile_step(net, bucket, inp, scaler)
+    arith = RF.arith_counts()          # which arithmetic every conv / correlation launch of that step actually ran
     alt = None
     if world == 1 and not args.no_cpu_baseline:
-        # the same step under the other convolution arithmetics, for reference
+        # the same step under the other fp32-equivalent convolution arithmetics, for reference
         alt = {}
         for other in ("f32", "f16x2", "bf16x3"):
-            if other == math:
+            if other == math or (other == "f16x2" and requested == "f16x2"):    # below the fp16 threshold f16x2 IS bf16x3
                 continue
             RF.set_conv_math(other)
             for _ in range(2):
@@ -328,7 +393,7 @@ def main():
                 step(net, bucket, inp, scaler)
             fence()
             alt[other] = {"value": round(args.batch * 5 / (time.perf_counter() - t1), 3), "unit": "pairs/s", "steps": 5}
-        RF.set_conv_math(math)
+        RF.set_conv_math(requested)
     if rank == 0:
         conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
         wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
@@ -338,24 +403,32 @@ def main():
             "metric": f"support/query pairs/sec (fwd+bwd, {args.shots}-shot {args.size}x{args.size}, T={args.iters})",
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if math == "f16" else "f32", "data": "synthetic",
             "conv_math": {"f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
                           "bf16x3": "fp32 operands as 3 bf16 planes (exact split), 6 v_mfma_f32_32x32x16_bf16 partial "
                                     "products, fp32 accumulate: fp32-equivalent (dropped terms <= 2^-23 |x*y|)",
                           "f16x2": "fp32 operands as 2 fp16 planes of operand / (power-of-two scale from a rigorous bound: "
                                    "BatchNorm outputs and gradients, weights), 3 v_mfma_f32_32x32x16_f16 partial products, "
                                    "fp32 accumulate (dropped term <= 2^-22 |x*y|; measured error vs fp64 = the fp32 matrix "
-                                   "instruction's); the local correlation the same way (block-local scale for its window gradients); operands without a bound (eval mode) on 3 bf16 planes"}[math],
-            "config": {"workload": f"1-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
-                                   f"(BASELINE configs[{(1 if world == 1 else 3) if args.shots == 1 else 2}]), train mode, align loss on, "
+                                   "instruction's); the local correlation the same way (block-local scale for its window gradients); operands without a bound (eval mode) on 3 bf16 planes",
+                          "f16": "REDUCED PRECISION (BASELINE configs[4]): conv / correlation operands as ONE fp16 plane of operand / "
+                                 "(power-of-two tensor scale), v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 BatchNorm "
+                                 "statistics, fp32 master weights and gradients; tolerance vs the fp32 reference: "
+                                 "tests/test_gpu_f16.py (logits 1e-2, Dice 1e-3)"}[math],
+            "config": {"workload": f"{args.ways}-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
+                                   f"({baseline_config(args, world)}), train mode, align loss on, "
                                    "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_math": math,
+                       "conv_math_requested": requested,
+                       "launches_by_arithmetic": arith,
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
             "roofline": {"bound": "mfma", "kernel": "rpnet_conv_fwd launches (conv forward + dgrad): conv_igemm"
                                                     + ("_kernel" if math == "f32" else "_split*_kernel"),
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
+                         "traffic_source": getattr(pmc_traffic, "source", None),
                          "peak_basis": "157.3 TF dense fp32 MFMA" if math == "f32" else
+                                       "2500 TF dense fp16 MFMA" if math == "f16" else
                                        f"2500 TF dense bf16 / fp16 MFMA / {products} partial products per fp32 multiply-add "
                                        "(achieved counts ALGORITHMIC fp32 FLOPs, not issued MFMA FLOPs)",
                          "issued_mfma_tflops": round(achieved * products, 1),
@@ -377,8 +450,9 @@ def main():
             result["alt_math"] = alt
         if world == 1 and not args.no_cpu_baseline:
             result["conv_math_error_vs_fp64"] = {k: float(f"{v:.3g}") for k, v in conv_accuracy_probe(dev).items()}
-        if world == 1 and not args.no_cpu_baseline and args.shots == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters, net=net if args.shots == 1 else None, bucket=bucket, dev=dev)
+        if world == 1 and not args.no_cpu_baseline and args.shots == 1 and args.ways == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters, net=net, bucket=bucket, dev=dev,
+                                                  full=args.cpu_baseline_full)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     if world > 1:
         dist.barrier()

@@ -83,7 +83,8 @@ int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int c
 int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
                      rpnet_stream_t stream);
 int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
-                    void* out, size_t rows, int C, rpnet_stream_t stream);
+                    void* out, size_t rows, int C, int planes /* 2, or 1: plain fp16 (RPNET_CONV_MATH=f16) */,
+                    rpnet_stream_t stream);
 int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
                                  int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
                                  float* row_scale_wd, rpnet_stream_t stream);
@@ -124,18 +125,24 @@ typedef struct rpnet_conv_desc {
     double* stats_partial;             /* optional: per (M tile, channel) sum / sum-of-squares of the
                                           output, [groups * rpnet_conv_stats_blocks()][Cout][2] — the
                                           train-mode BatchNorm batch statistics fused into the epilogue */
-    int split_planes;                  /* 0: x0/x1/w are fp32 (v_mfma_f32_32x32x2_f32).  2 or 3: x0/x1/w point at
-                                          split-bf16 operands (rpnet_split_bf16 / rpnet_pack_conv_weight_split),
+    int split_planes;                  /* 0: x0/x1/w are fp32 (v_mfma_f32_32x32x2_f32).  3: x0/x1/w point at
+                                          split-bf16 operands (rpnet_split_bf16 / rpnet_pack_conv_weight_split);
+                                          2 / 1: at two / one fp16 plane(s) of operand / scale (rpnet_split_f16; 2 is
+                                          fp32-equivalent, 1 is plain fp16 operands with fp32 accumulation);
                                           plane p of a source at +p*N*Hin*Win*C elements, of w at
                                           +p*taps*Cin*Cout; in_scale must already be folded into the split */
     void* y_split;                     /* optional (single destination, Co1 == 0): the final output also as split-bf16
                                           planes [split_out_planes][N*H*W][Cout] — what the next convolution reads */
     int split_out_planes;              /* 2 or 3 when y_split is set */
-    /* power-of-two scales of fp16 split operands (split_planes == 2; all NULL otherwise): the accumulator is
+    /* power-of-two scales of fp16 split operands (split_planes == 2 or 1; all NULL otherwise): the accumulator is
        multiplied by acc_scale_col[column] * *acc_scale_x before the bias (column = output channel: the per-row scale of
        the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
        rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
     const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
+    int tune;                          /* 0: the library picks the tile variant.  Tuning / tests: v + 1 forces variant v of
+                                          the split forward kernels (where the shape allows it); 4 in rpnet_conv_wgrad: the
+                                          4-wave layout of the split weight gradient.  Carried here, not in the
+                                          environment: the library keeps no global state */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);

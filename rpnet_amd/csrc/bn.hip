@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
                                                              const float* __restrict__ beta, const float sqrt_n,
                                                              float* __restrict__ s_out) {
     float inv_s = 1.f;
-    if (NP == 2) {
+    if (NP <= 2) {
         __shared__ float red4[4];
         float m = 0.f;
         for (int c = threadIdx.x; c < C8 * 8; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
             for (int k = 0; k < 4; ++k) { o[k] = fmaxf(a[k] * s4[k] + h4[k], 0.f); v[hh * 4 + k] = o[k]; }
             reinterpret_cast<f32x4*>(z)[i * 2 + hh] = o;
         }
-        if (NP == 2) {
+        if (NP <= 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] *= inv_s;
         }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restric
                                                            float* __restrict__ s_out) {
     const int C8 = C / 8;
     float inv_s = 1.f;
-    if (NP == 2) {     // fp16 planes of dy / s, s = pow2ceil(max_c bound[c]) 2^-15 (see bn_bwd_finalize)
+    if (NP <= 2) {     // fp16 planes of dy / s, s = pow2ceil(max_c bound[c]) 2^-15 (see bn_bwd_finalize)
         __shared__ float red4[4];
         float m = 0.f;
         for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, bound[c]);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restric
             }
             if (dy) reinterpret_cast<f32x4*>(dy)[i * 2 + hh] = q;
         }
-        if (NP == 2) {
+        if (NP <= 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) r[k] *= inv_s;
         }
@@ -435,16 +435,19 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (z_split) {
-        RPNET_REQUIRE((planes == 2 || planes == 3) && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
+        RPNET_REQUIRE(planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
         RPNET_REQUIRE(planes == 3 || (gamma && beta && split_scale), RPNET_ERR_ARG,
-                      "bn_relu: two planes (fp16) need gamma, beta and the scale output");
+                      "bn_relu: fp16 planes (1 or 2) need gamma, beta and the scale output");
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
         if (planes == 3)
             hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
-        else
+        else if (planes == 2)
             hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
+        else
+            hipLaunchKernelGGL(bn_relu_split_kernel<1>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         return check_launch("bn_relu_split");
     }
@@ -471,7 +474,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     (void)gamma;
     RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && (dy || dy_split) && dgamma && dbeta && workspace,
                   RPNET_ERR_ARG, "bn_bwd: null pointer");
-    RPNET_REQUIRE(!dy_split || ((planes == 2 || planes == 3) && C % 8 == 0), RPNET_ERR_SHAPE, "bn_bwd: split planes=%d C=%d",
+    RPNET_REQUIRE(!dy_split || (planes >= 1 && planes <= 3 && C % 8 == 0), RPNET_ERR_SHAPE, "bn_bwd: split planes=%d C=%d",
                   planes, C);
     if (int rc = bn_check("bn_bwd", N, HW, C, groups)) return rc;
     RPNET_REQUIRE(workspace_bytes >= rpnet_bn_workspace_bytes(C, groups), RPNET_ERR_WORKSPACE, "bn_bwd: workspace too small");
@@ -480,8 +483,8 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     hipStream_t s = (hipStream_t)stream;
     double* partial = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)groups * 256 * C * 2 * sizeof(double));
-    const bool f16 = dy_split && planes == 2;
-    RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: two planes (fp16) need the scale output");
+    const bool f16 = dy_split && planes <= 2;
+    RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: fp16 planes (1 or 2) need the scale output");
     float* pmax = f16 ? coef + (size_t)groups * C * 2 : nullptr;
     float* bound = f16 ? pmax + (size_t)groups * 256 * C : nullptr;
     hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
@@ -495,8 +498,12 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
             hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
                                split_scale);
-        else
+        else if (planes == 2)
             hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+                               (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
+                               split_scale);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_split<1>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
                                split_scale);
         return check_launch("bn_bwd");

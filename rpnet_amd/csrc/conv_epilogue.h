@@ -47,13 +47,15 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             const int col = n0 + wn * WN * 32 + j * 32 + li;
             const float bv = d.bias ? d.bias[col] : 0.f;
             const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
-            float sm = 0.f, sq = 0.f;
+            // fp64 from the first add on: the variance is formed as E[y^2] - mean^2, and an fp32 running sum of squares
+            // would carry ~1e-7 mean^2 of error into it (channels with |mean| >> std)
+            double sm = 0.0, sq = 0.0;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    const float v = row >= 0 ? acc[i][j][r] * as + bv : 0.f;
+                    const double v = row >= 0 ? (double)(acc[i][j][r] * as + bv) : 0.0;
                     sm += v;
                     sq += v * v;
                 }
@@ -61,8 +63,8 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             sq += __shfl_xor(sq, 32, 64);
             if (h == 0) {
                 double* o = red + ((size_t)wm * BNC + wn * WN * 32 + j * 32 + li) * 2;
-                o[0] = (double)sm;
-                o[1] = (double)sq;
+                o[0] = sm;
+                o[1] = sq;
             }
         }
         __syncthreads();

@@ -270,10 +270,10 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     const int M = d->N * d->H * d->W;
     hipStream_t s = (hipStream_t)stream;
     if (d->split_planes) {
-        RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
-                      "conv_fwd: split operands take 2 or 3 planes and no in_scale (fold it into rpnet_split_bf16)");
-        RPNET_REQUIRE(d->split_planes != 2 || (d->acc_scale_col && d->acc_scale_x), RPNET_ERR_ARG,
-                      "conv_fwd: two planes are fp16 planes of operand / scale: acc_scale_col and acc_scale_x are required");
+        RPNET_REQUIRE(d->split_planes >= 1 && d->split_planes <= 3 && d->in_scale_mode == 0, RPNET_ERR_ARG,
+                      "conv_fwd: split operands take 1 to 3 planes and no in_scale (fold it into rpnet_split_bf16 / _f16)");
+        RPNET_REQUIRE(d->split_planes == 3 || (d->acc_scale_col && d->acc_scale_x), RPNET_ERR_ARG,
+                      "conv_fwd: one / two planes are fp16 planes of operand / scale: acc_scale_col and acc_scale_x are required");
         return conv_fwd_split(d, M, Cin, Cout, s);
     }
     const int best = choose_tile(d, M, Cout);

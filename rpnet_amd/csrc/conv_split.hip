@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 // fp16 planes of x * f(mask) / s with the tensor scale s = max(*s_a, *s_b) (device scalars; s_b optional): the operand
 // of a convolution whose input is a BatchNorm output (scale from rpnet_bn_relu), pooled / masked / concatenated
+template <int NP>
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, const float* __restrict__ mask, const int mode,
                                                          const float* __restrict__ s_a, const float* __restrict__ s_b,
                                                          float* __restrict__ s_out, unsigned short* __restrict__ out,
@@ -68,10 +69,10 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] *= inv;
-        u32x4 o[2];
-        split8<2>(v, o);
+        u32x4 o[NP];
+        split8<NP>(v, o);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(out + p * plane_elems + i * 8) = o[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(out + p * plane_elems + i * 8) = o[p];
     }
 }
 
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __r
             float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = tile[tap][g * 8 + q][cl];
-            if (NP == 2) {
+            if (NP <= 2) {
                 const float inv = 1.f / t_row[co0 + cl];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] *= inv;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __r
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = tile[tap][c][g * 8 + q];
-                if (NP == 2) {
+                if (NP <= 2) {
                     const float inv = 1.f / u_row[row];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] *= inv;
@@ -317,12 +318,10 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
                 bfr[p][j] = *reinterpret_cast<const bf16x8*>(st + NP * A_BYTES + p * B_BYTES + b_row + j * 2048 + koff);
         }
         // smallest partial products first
-        constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int NPROD = nprod<NP>();
 #pragma unroll
         for (int q = 0; q < NPROD; ++q) {
-            const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+            const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -506,19 +505,17 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                 for (int j = 0; j < WN; ++j)
                     bfr[p][j] = *reinterpret_cast<const bf16x8*>(bst + p * B_BYTES + b_row + j * 2048 + 16 * (kg ^ sw));
             }
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = nprod<NP>();
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
-                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = mma16<NP>(af[pa][i], bfr[pb][j], acc[i][j]);
             }
-            if (NP == 2 && IGLP) __builtin_amdgcn_iglp_opt(0);
+            if (NP <= 2 && IGLP) __builtin_amdgcn_iglp_opt(0);
         }
     };
 
@@ -697,12 +694,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
                 for (int j = 0; j < WN; ++j)
                     bfr[p][j] = *reinterpret_cast<const bf16x8*>(bst + p * B_BYTES + b_row + j * 2048 + 16 * (kg ^ sw));
             }
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = nprod<NP>();
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
-                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -746,8 +741,10 @@ static int launch_split_halo(const rpnet_conv_desc* d, int M, int Cin, int Cout,
     const int ntiles = tiles_m * tiles_n;
     if (d->split_planes == 3)
         hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 3, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
-    else
+    else if (d->split_planes == 2)
         hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 2, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_halo_kernel<TW, 1, WN>), dim3(ntiles), dim3(512), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split_halo");
 }
 
@@ -757,8 +754,10 @@ static int launch_split_halo4(const rpnet_conv_desc* d, int M, int Cin, int Cout
     const int ntiles = tiles_m * tiles_n;
     if (d->split_planes == 3)
         hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
-    else
+    else if (d->split_planes == 2)
         hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 2, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 1, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split_halo4");
 }
 
@@ -799,8 +798,11 @@ static int launch_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipS
     if (d->split_planes == 3)
         hipLaunchKernelGGL((conv_igemm_split_kernel<WGM, WM, WN, 3, DB>), dim3(ntiles), dim3(WGM * 128), 0, s, *d, M, Cin,
                            Cout, tiles_n, ntiles);
-    else
+    else if (d->split_planes == 2)
         hipLaunchKernelGGL((conv_igemm_split_kernel<WGM, WM, WN, 2, DB>), dim3(ntiles), dim3(WGM * 128), 0, s, *d, M, Cin,
+                           Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_kernel<WGM, WM, WN, 1, DB>), dim3(ntiles), dim3(WGM * 128), 0, s, *d, M, Cin,
                            Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split");
 }
@@ -815,10 +817,9 @@ static int halo4_tw(const rpnet_conv_desc* d) {
 
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
-    const char* e = getenv("RPNET_SPLIT_TILE");   // tuning override (tools/bench_conv_split.py)
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
-    if (e) {
-        const int v = atoi(e);
+    if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
+        const int v = d->tune - 1;
         if ((v == 7 && halo_tw(d, Cout)) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
         if (v >= 0 && v < 4 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
@@ -889,15 +890,20 @@ extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mo
 }
 
 extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
-                               void* out, size_t rows, int C, rpnet_stream_t stream) {
+                               void* out, size_t rows, int C, int planes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && out && s_a && (mask_mode == 0 || mask), RPNET_ERR_ARG, "split_f16: null pointer");
-    RPNET_REQUIRE(C > 0 && C % 8 == 0 && mask_mode >= 0 && mask_mode <= 2, RPNET_ERR_SHAPE, "split_f16: C=%d mode=%d", C, mask_mode);
+    RPNET_REQUIRE(C > 0 && C % 8 == 0 && mask_mode >= 0 && mask_mode <= 2 && (planes == 1 || planes == 2), RPNET_ERR_SHAPE,
+                  "split_f16: C=%d mode=%d planes=%d", C, mask_mode, planes);
     if (rows == 0) return RPNET_OK;
     const size_t n8 = rows * (size_t)(C / 8);
     const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
-    hipLaunchKernelGGL(split_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
-                       (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    if (planes == 2)
+        hipLaunchKernelGGL(split_f16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+    else
+        hipLaunchKernelGGL(split_f16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
     return check_launch("split_f16");
 }
 
@@ -906,9 +912,9 @@ extern "C" int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, 
                                             float* row_scale_wd, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(w && wp, RPNET_ERR_ARG, "pack_conv_weight_split: null pointer");
-    RPNET_REQUIRE(planes != 2 || (row_scale_wp && row_scale_wd), RPNET_ERR_ARG,
-                  "pack_conv_weight_split: two planes (fp16) need the row scale outputs");
-    RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 32 == 0 && (taps == 9 || taps == 1) && (planes == 2 || planes == 3),
+    RPNET_REQUIRE(planes == 3 || (row_scale_wp && row_scale_wd), RPNET_ERR_ARG,
+                  "pack_conv_weight_split: fp16 planes (1 or 2) need the row scale outputs");
+    RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 32 == 0 && (taps == 9 || taps == 1) && planes >= 1 && planes <= 3,
                   RPNET_ERR_SHAPE, "pack_conv_weight_split: cout %d cin_pad %d taps %d planes %d", cout, cin_pad, taps, planes);
     RPNET_REQUIRE(cin % 8 == 0 && cin_off0 % 8 == 0 && cin_split % 8 == 0 && cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
                   "pack_conv_weight_split: channel counts / offsets must be multiples of 8");
@@ -920,9 +926,14 @@ extern "C" int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, 
         // row_scale_wd covers the cin_pad gathered rows; the caller presets the padding rows (any non-zero value)
         hipLaunchKernelGGL(weight_row_scale_kernel, dim3(cout + cin), dim3(256), 0, (hipStream_t)stream, w, row_scale_wp, row_scale_wd,
                            cout, cin, taps, cin_off0, cin_split, cin_off1);
-        hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
-                           (const float*)row_scale_wp, (const float*)row_scale_wd);
+        if (planes == 2)
+            hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
+                               (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
+                               (const float*)row_scale_wp, (const float*)row_scale_wd);
+        else
+            hipLaunchKernelGGL(pack_weight_split_kernel<1>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
+                               (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
+                               (const float*)row_scale_wp, (const float*)row_scale_wd);
     }
     return check_launch("pack_conv_weight_split");
 }

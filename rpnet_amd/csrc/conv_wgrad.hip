@@ -484,16 +484,16 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         const int lw = ilog2_exact(d->W), lh = ilog2_exact(d->H);
         float* part9 = (float*)workspace;
         if (d->split_planes) {   // x0/x1 and dy are split-bf16 planes
-            RPNET_REQUIRE((d->split_planes == 2 || d->split_planes == 3) && d->in_scale_mode == 0, RPNET_ERR_ARG,
-                          "conv_wgrad: split operands take 2 or 3 planes and no in_scale");
+            RPNET_REQUIRE(d->split_planes >= 1 && d->split_planes <= 3 && d->in_scale_mode == 0, RPNET_ERR_ARG,
+                          "conv_wgrad: split operands take 1 to 3 planes and no in_scale");
             if (dy)      // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
                 if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
             if (!dw) return RPNET_OK;       // GEMM phase only: the partial sums stay in the workspace
-            RPNET_REQUIRE(d->split_planes != 2 || (d->acc_scale_x && d->acc_scale_dy), RPNET_ERR_ARG,
+            RPNET_REQUIRE(d->split_planes == 3 || (d->acc_scale_x && d->acc_scale_dy), RPNET_ERR_ARG,
                           "conv_wgrad: fp16 planes need acc_scale_x and acc_scale_dy");
             hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
                                Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate,
-                               d->split_planes == 2 ? d->acc_scale_x : nullptr, d->acc_scale_dy);
+                               d->split_planes <= 2 ? d->acc_scale_x : nullptr, d->acc_scale_dy);
             return check_launch("wgrad_reduce");
         }
 #define RPNET_W9(P2, IS, LW, LH)                                                                                   \

@@ -16,7 +16,6 @@
 // One block per CU (9 x 16 accumulator registers per lane, two LDS stages): 108 (NP = 3) MFMAs per wave per
 // 32-pixel K-step, one barrier per step, the next tile's LDS writes interleaved with the MFMAs.
 #include <algorithm>
-#include <stdlib.h>
 
 #include "common.h"
 #include "split_bf16.h"
@@ -199,9 +198,7 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
                     af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(o), tr(o + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             };
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = nprod<NP>();
             if constexpr (KYW) {
                 // this wave: one tap row (ky = wky), three kx taps of its 32x32 quadrant
 #pragma unroll
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
                     }
 #pragma unroll
                     for (int q = 0; q < NPROD; ++q) {
-                        const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                        const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx)
                             acc[kx] = mma16<NP>(af[pa], bf[kx][pb], acc[kx]);
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
                 auto mma_slice = [&](const bf16x8 (&af)[3][NP], const bf16x8 (&bf)[3][NP]) {
 #pragma unroll
                     for (int q = 0; q < NPROD; ++q) {
-                        const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                        const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                         for (int tap = 0; tap < 9; ++tap)
                             acc[tap % NACC] = mma16<NP>(af[tap / 3][pa], bf[tap % 3][pb], acc[tap % NACC]);
@@ -280,8 +277,7 @@ int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, in
     const int lw = ilog2x(d->W), lh = ilog2x(d->H);
     const bool p2 = lw >= 0 && lh >= 0;
     const unsigned short* dys = (const unsigned short*)dy;
-    const char* e = getenv("RPNET_WGRAD_WAVES");   // tuning override: 4 = one wave per quadrant, all nine taps
-    const bool kyw = !(e && atoi(e) == 4);
+    const bool kyw = d->tune != 4;       // tuning override carried by the descriptor: 4 = one wave per quadrant, all nine taps
 #define RPNET_W9S(NPL, P2)                                                                                                     \
     do {                                                                                                                       \
         if (kyw)                                                                                                               \
@@ -292,7 +288,8 @@ int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, in
                                M, Cin, Cout, tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0);                           \
     } while (0)
     if (d->split_planes == 3) { if (p2) RPNET_W9S(3, true); else RPNET_W9S(3, false); }
-    else { if (p2) RPNET_W9S(2, true); else RPNET_W9S(2, false); }
+    else if (d->split_planes == 2) { if (p2) RPNET_W9S(2, true); else RPNET_W9S(2, false); }
+    else { if (p2) RPNET_W9S(1, true); else RPNET_W9S(1, false); }
 #undef RPNET_W9S
     return check_launch("conv_wgrad9_split");
 }

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                                                                       const int w, const int C, const int cstride,
                                                                       const float inv_sqrt_c_in, const float* __restrict__ s1,
                                                                       const float* __restrict__ s2) {
-    // NP = 2: fp16 planes of f / s with the producers' tensor scales (rpnet_bn_relu); the scores are multiplied by s1 s2
-    const float inv_sqrt_c = NP == 2 ? inv_sqrt_c_in * (*s1 * *s2) : inv_sqrt_c_in;
+    // NP <= 2: fp16 planes of f / s with the producers' tensor scales (rpnet_bn_relu); the scores are multiplied by s1 s2
+    const float inv_sqrt_c = NP <= 2 ? inv_sqrt_c_in * (*s1 * *s2) : inv_sqrt_c_in;
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NT_N = (NQ + 31) / 32, NQP = NT_N * 32;
     constexpr int A_BYTES = 64 * 64, B_BYTES = NQP * 64;            // one plane: [row][32 channels]
     constexpr int BJ = (NQ * 4 + 255) / 256;                        // halo pieces per thread and plane
@@ -110,12 +110,10 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                     bfr[p][j] = *reinterpret_cast<const bf16x8*>(bsm + p * B_BYTES + ((jt < NT_N ? jt : 0) * 32 + li) * 64 + koff);
                 }
             }
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = nprod<NP>();
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
-                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                 for (int j = 0; j < JT; ++j)
                     if (wv + 4 * j < NT_N) {
@@ -187,10 +185,10 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
         gs[e] = (o < KK && y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] * inv_sqrt_c : 0.f;
     }
-    // NP = 2: the window gradients have no a-priori bound, but the tile is right here: a block-local power-of-two scale
+    // NP <= 2: the window gradients have no a-priori bound, but the tile is right here: a block-local power-of-two scale
     // from its own maximum (exact), the fo planes carry their producer's tensor scale; the result takes both back
     float g_inv = 1.f, out_scale = 1.f;
-    if (NP == 2) {
+    if (NP <= 2) {
         __shared__ float red4[4];
         __syncthreads();
         float m = 0.f;
@@ -261,12 +259,10 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(bp + 4 * RSB));
                 bfr[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
-            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = nprod<NP>();
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
-                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i] = mma16<NP>(af[pa][i], bfr[pb], acc[i]);
             }
@@ -280,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         for (int r = 0; r < 16; ++r) {
             const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
-            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = NP == 2 ? acc[i][r] * out_scale : acc[i][r];
+            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = NP <= 2 ? acc[i][r] * out_scale : acc[i][r];
         }
 }
 
@@ -293,8 +289,9 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
                                           rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 && (planes == 3 || (planes == 2 && scale1 && scale2)),
-                  RPNET_ERR_SHAPE, "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d (2 = fp16 planes + their scales)", r, C,
+    RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 &&
+                      (planes == 3 || ((planes == 2 || planes == 1) && scale1 && scale2)),
+                  RPNET_ERR_SHAPE, "local_corr_split_fwd: r=%d (5) C=%d cstride=%d planes=%d (1, 2 = fp16 planes + their scales)", r, C,
                   cstride, planes);
     RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_fwd: image too large");
     const int tiles = cdiv(h, 8) * cdiv(w, 8);
@@ -304,8 +301,11 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
     if (planes == 3)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc,
                            (const float*)nullptr, (const float*)nullptr);
-    else
+    else if (planes == 2)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
+                           cstride, isc, scale1, scale2);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 1>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
                            cstride, isc, scale1, scale2);
     return check_launch("local_corr_split_fwd");
 }
@@ -315,7 +315,7 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
                                           const float* scale2, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_split_bwd: null pointer");
-    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 3 || (planes == 2 && scale1 && scale2)), RPNET_ERR_SHAPE,
+    RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 3 || ((planes == 2 || planes == 1) && scale1 && scale2)), RPNET_ERR_SHAPE,
                   "local_corr_split_bwd: r=%d (5) C=%d (multiple of 128) cstride=%d planes=%d", r, C, cstride, planes);
     RPNET_REQUIRE(workspace_bytes >= rpnet_local_corr_bwd_workspace_bytes(B, h, w, cstride), RPNET_ERR_WORKSPACE,
                   "local_corr_split_bwd: workspace too small");
@@ -329,12 +329,16 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
     const dim3 grid(tiles, C / 128, B);
     if (planes == 3)
         hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, (const float*)nullptr);
-    else
+    else if (planes == 2)
         hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2);
     if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;
     if (planes == 3)
         hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, (const float*)nullptr);
-    else
+    else if (planes == 2)
         hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1);
+    else
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1);
     return check_launch("local_corr_split_bwd");
 }

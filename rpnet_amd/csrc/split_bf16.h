@@ -5,6 +5,9 @@
 //           tensor scale s that keeps |x / s| <= 2^15 (fp16 overflows at 65504) and puts typical values well above
 //           2^-3; the consumer multiplies the accumulator by s (exact).  NP = 2 therefore exists only where a rigorous
 //           bound of the tensor is known (BatchNorm outputs and gradients, weights); everything else uses NP = 3.
+//   NP = 1: ONE fp16 plane h = fp16(x / s) with the same tensor scales — plain fp16 operands (11 significand bits), one
+//           MFMA per multiply-add, fp32 accumulation: the reduced-precision arithmetic of BASELINE configs[4]
+//           (RPNET_CONV_MATH=f16), NOT fp32-equivalent.
 #pragma once
 #include "common.h"
 
@@ -41,9 +44,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
     unsigned hb[8], mb[8], lb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        if (NP == 2) {
+        if (NP <= 2) {
             hb[q] = f16_bits(v[q]);
-            mb[q] = f16_bits(v[q] - f16_val(hb[q]));
+            if (NP == 2) mb[q] = f16_bits(v[q] - f16_val(hb[q]));
             continue;
         }
         hb[q] = bf16_bits(v[q]);
@@ -54,16 +57,26 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NP]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         out[0][q] = hb[2 * q] | (hb[2 * q + 1] << 16);
-        out[1][q] = mb[2 * q] | (mb[2 * q + 1] << 16);
+        if (NP > 1) out[NP > 1 ? 1 : 0][q] = mb[2 * q] | (mb[2 * q + 1] << 16);
         if (NP > 2) out[NP - 1][q] = lb[2 * q] | (lb[2 * q + 1] << 16);
     }
 }
 
-// one partial product of split planes on the matrix pipe: NP = 3 -> bf16 planes, NP = 2 -> fp16 planes
+// partial products of the planes, smallest first: NP = 3: lh hl mm mh hm hh (plane 0 = h, 1 = m, 2 = l), NP = 2: lh hl hh
+// (plane 1 = l), NP = 1: hh
+template <int NP> constexpr int nprod() { return NP == 3 ? 6 : (NP == 2 ? 3 : 1); }
+template <int NP> constexpr int prod_a(int q) {
+    return NP == 3 ? (q == 0 ? 2 : ((q == 2 || q == 3) ? 1 : 0)) : (NP == 2 ? (q == 0 ? 1 : 0) : 0);
+}
+template <int NP> constexpr int prod_b(int q) {
+    return NP == 3 ? (q == 1 ? 2 : ((q == 2 || q == 4) ? 1 : 0)) : (NP == 2 ? (q == 1 ? 1 : 0) : 0);
+}
+
+// one partial product of split planes on the matrix pipe: NP = 3 -> bf16 planes, NP <= 2 -> fp16 planes
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 template <int NP>
 __device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
-    if constexpr (NP == 2)
+    if constexpr (NP <= 2)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

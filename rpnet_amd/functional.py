@@ -9,6 +9,7 @@ operands (set_conv_math / RPNET_CONV_MATH, see _MATH below): the kernel that pro
 fp16 planes of tensor / scale (`x._rp_split16` = (planes, scale); scale from a rigorous bound, `x._rp_scale`) or, where
 no bound exists, as three exact bf16 planes (`x._rp_split`), which is what the next convolution's operand loads read.
 """
+import collections
 import ctypes as C
 import os
 
@@ -28,7 +29,7 @@ BN_MOMENTUM = 0.1
 # into the parameter's existing .grad buffer (the flat bucket) instead of being returned to
 # autograd; the backward pass's HBM-bound kernels then run beside MFMA work.  The two streams are
 # joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
-_ASYNC = {"on": False, "side": {}, "pending": set()}
+_ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False}
 
 # Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
@@ -37,14 +38,16 @@ _ASYNC = {"on": False, "side": {}, "pending": set()}
 # three v_mfma_f32_32x32x16_f16 products (dropped term 2^-22 |x*y|, 16/3 of the fp32 matrix rate) wherever a
 # rigorous bound of the operand gives a scale that cannot overflow fp16 — the train-mode conv + BatchNorm layers:
 # BatchNorm outputs, BatchNorm gradients, weights — and bf16x3 everywhere else (eval mode, vgg, correlation).
-_MODES = {"f32": (0, False), "bf16x3": (3, False), "f16x2": (3, True)}
+# "f16" = ONE fp16 plane of operand / scale (plain fp16 operands, fp32 accumulation, fp32 BatchNorm statistics): the
+# reduced-precision arithmetic of BASELINE configs[4]; NOT fp32-equivalent (tolerances: DESIGN.md §6).
+_MODES = {"f32": (0, False, 0), "bf16x3": (3, False, 0), "f16x2": (3, True, 2), "f16": (3, True, 1)}
 _CORR16 = os.environ.get("RPNET_CORR_F16", "1") == "1"   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
 _MATH = {}
 
 
 def set_conv_math(mode):
     _MATH["mode"] = mode
-    _MATH["planes"], _MATH["f16"] = _MODES[mode]
+    _MATH["planes"], _MATH["f16"], _MATH["f16_planes"] = _MODES[mode]
     _MATH["f16_on"] = True
 
 
@@ -104,6 +107,45 @@ def join_side_streams():
         if red is not None:
             torch.cuda.current_stream(dev).wait_stream(red)
     _ASYNC["pending"].clear()
+    _ASYNC["queued"] = False
+
+
+def reset_async():
+    """Start of a forward pass / of a gradient-bucket operation: join whatever a previous backward left on the side
+    streams (a backward that raised never ran its engine callback) and allow the next backward to queue its own join."""
+    if _ASYNC["pending"]:
+        join_side_streams()
+    _ASYNC["queued"] = False
+
+
+# ---------------------------------------------------------------- which arithmetic actually ran
+# Every convolution / correlation launch is counted by kind and by the arithmetic of its operands, so that a layer that
+# quietly left the requested arithmetic (no operand bound, unsupported channel count) shows up: bench.py prints the
+# counts of one step, tests assert them (reset_arith / arith_counts).
+ARITH = collections.Counter()
+_PLANE_NAME = {0: "f32", 1: "f16", 2: "f16x2", 3: "bf16x3"}
+
+
+def reset_arith():
+    ARITH.clear()
+
+
+def arith_counts():
+    """{kind: {arithmetic: launches}} since reset_arith(); kinds: conv3x3 (forward + input gradient), wgrad3x3,
+    conv1x1, wgrad1x1, corr (forward), corr_bwd"""
+    out = {}
+    for (kind, arith), n in sorted(ARITH.items()):
+        out.setdefault(kind, {})[arith] = n
+    return out
+
+
+def _cconv(name, d, *rest):
+    """rpnet_conv_fwd / rpnet_conv_wgrad with the launch counted (the reduce-only phase of a two-phase weight
+    gradient is not a second launch of the GEMM)"""
+    wg = name == "rpnet_conv_wgrad"
+    if not wg or rest[0] is not None:
+        ARITH[(("wgrad" if wg else "conv") + ("3x3" if d.taps == 9 else "1x1"), _PLANE_NAME[d.split_planes])] += 1
+    call(name, C.byref(d), *rest)
 
 
 def _empty(shape, like, dtype=torch.float32):
@@ -144,15 +186,16 @@ def _use_split(pw, x0, x1):
             and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0))
 
 
-def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True):
-    """fp16 planes of x * f(mask) / s, s = max(s_a, s_b) (device scalars) -> (planes [2, ...], s [1]) (rpnet_split_f16)"""
+def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None):
+    """fp16 planes of x * f(mask) / s, s = max(s_a, s_b) (device scalars) -> (planes [2 or 1, ...], s [1]) (rpnet_split_f16)"""
     hip.require_gpu(x)
     x = x.contiguous()
-    out = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.float16)
+    planes = planes or _MATH["f16_planes"] or 2
+    out = torch.empty((planes,) + tuple(x.shape), device=x.device, dtype=torch.float16)
     s = torch.empty(1, device=x.device, dtype=torch.float32) if want_scale else None
     c = x.shape[-1]
     call("rpnet_split_f16", ptr(x), ptr(mask), mode if mask is not None else 0, ptr(s_a), ptr(s_b), ptr(s), ptr(out),
-         x.numel() // c, c)
+         x.numel() // c, c, planes)
     return out, s
 
 
@@ -174,7 +217,7 @@ def _f16_sources(x0, x1, in_scale, in_mode, x_scales):
     masked = in_scale is not None and in_mode
     if x1 is None and not masked:
         c = getattr(x0, "_rp_split16", None)
-        if c is not None and c[0].shape[1:] == x0.shape:
+        if c is not None and c[0].shape[1:] == x0.shape and c[0].shape[0] == _MATH["f16_planes"]:
             return c[0], None, c[1]
     xs0, s = split_f16(x0, s0, s1, in_scale if masked else None, in_mode if masked else 0)
     xs1 = split_f16(x1, s0, s1, want_scale=False)[0] if x1 is not None else None
@@ -222,7 +265,7 @@ class PackedWeight:
 
     def split_packs(self, planes):
         """split packs of the same weight (rpnet_pack_conv_weight_split), made on first use: planes == 3 -> (wp, wd) bf16
-        planes; planes == 2 -> (wp, wd, row scale of wp [cout], row scale of wd [cin_pad]) fp16 planes of w / row scale."""
+        planes; planes == 2 / 1 -> (wp, wd, row scale of wp [cout], row scale of wd [cin_pad]) fp16 planes of w / row scale."""
         if self.wps is None:
             self.wps = {}
         pk = self.wps.get(planes)
@@ -233,7 +276,7 @@ class PackedWeight:
             dt = torch.bfloat16 if planes == 3 else torch.float16
             wps, wds = mk((planes, n), device=w.device, dtype=dt), mk((planes, n), device=w.device, dtype=dt)
             t = u = None
-            if planes == 2:
+            if planes <= 2:
                 t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
                 u = torch.ones(self.cin_pad, device=w.device, dtype=torch.float32)
             call("rpnet_pack_conv_weight_split", ptr(w), ptr(wps), ptr(wds), self.cout, self.cin, self.taps,
@@ -261,6 +304,11 @@ class WeightCache:
         return pw
 
 
+# tuning / test override of the kernel variant, carried by every descriptor (rpnet_conv_desc.tune): 0 = the library's
+# choice, v + 1 = tile variant v of the split forward kernels, 4 (weight gradient) = the 4-wave layout
+TUNE = {"tile": 0}
+
+
 def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups=1, ep_scale=None, ep_shift=None,
           ep_relu=0, out_scale=None, out_mode=0, accumulate=0, co_split=None):
     d = ConvDesc()
@@ -275,6 +323,7 @@ def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups
     d.ep_scale, d.ep_shift, d.ep_relu = ptr(ep_scale), ptr(ep_shift), ep_relu
     d.out_scale, d.out_scale_mode, d.accumulate = ptr(out_scale), out_mode if out_scale is not None else 0, accumulate
     d.N, d.H, d.W, d.taps, d.upsample, d.groups = N, H, W, taps, ups, groups
+    d.tune = TUNE["tile"]
     return d
 
 
@@ -315,11 +364,11 @@ class ConvBnRelu(Function):
                           pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                 d.split_planes = np_
                 d.y_split, d.split_out_planes = ptr(zs), np_out
-                call("rpnet_conv_fwd", C.byref(d))
+                _cconv("rpnet_conv_fwd", d)
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                 d.y_split, d.split_out_planes = ptr(zs), np_out
-                call("rpnet_conv_fwd", C.byref(d))
+                _cconv("rpnet_conv_fwd", d)
             if zs is not None:
                 z._rp_split = zs      # written by the conv epilogue: no separate split pass in eval mode
             ctx.eval_mode = True
@@ -331,11 +380,12 @@ class ConvBnRelu(Function):
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
         else:
             f16 = _f16_sources(x0, x1, in_scale, in_mode, x_scales) if (f16_mode() and _use_split(pw, x0, x1)) else None
-            if f16 is not None:      # two fp16 planes with a tensor scale; weights with row scales
+            if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
                 xs, sx = (f16[0], f16[1]), f16[2]
-                wps, _, t_row, _ = pw.split_packs(2)
+                fp = _MATH["f16_planes"]
+                wps, _, t_row, _ = pw.split_packs(fp)
                 d = _desc(xs[0], xs[1], wps, bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
-                d.split_planes = 2
+                d.split_planes = fp
                 d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(sx)
             elif _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
@@ -348,7 +398,7 @@ class ConvBnRelu(Function):
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
-            call("rpnet_conv_fwd", C.byref(d))
+            _cconv("rpnet_conv_fwd", d)
         if fused:
             call("rpnet_bn_stats_from_partial", ptr(part), fused, N, H * W, cout, groups, ptr(gamma), ptr(beta),
                  ptr(running_mean), ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]),
@@ -365,13 +415,13 @@ class ConvBnRelu(Function):
         want16 = f16_mode() and cout % 32 == 0 and out_split in ((True, "scale", "corr") if _CORR16 else (True, "scale"))
         np_out = 0
         if out_split in (True, "corr") and cout % 32 == 0 and _MATH["planes"]:
-            np_out = 2 if want16 else _MATH["planes"]
-        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out == 2 else torch.bfloat16) if np_out else None
+            np_out = _MATH["f16_planes"] if want16 else _MATH["planes"]
+        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out <= 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
         # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
-             ptr(sz) if (np_out == 2 or (want16 and np_out == 0)) else None, N, H * W, cout, groups)
-        if np_out == 2:
+             ptr(sz) if want16 else None, N, H * W, cout, groups)
+        if want16 and np_out:
             z._rp_split16 = (zs, sz)      # the next convolution's operand, produced here instead of by a separate pass
         elif zs is not None:
             z._rp_split = zs
@@ -402,7 +452,7 @@ class ConvBnRelu(Function):
         wsplit = bool(np_) and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
         dsplit = bool(np_) and cout % 32 == 0 and need_d
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
-        sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ == 2) else None   # fp16: tensor scale
+        sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ <= 2) else None   # fp16: tensor scale
         dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
@@ -422,7 +472,7 @@ class ConvBnRelu(Function):
                 d = _desc(ctx.xs[0], ctx.xs[1], None, None, None, 0, None, None, N, H, W, pw.taps, upsample,
                           co_split=(cout, 0))
                 d.split_planes = np_
-                if np_ == 2:
+                if np_ <= 2:
                     d.acc_scale_x, d.acc_scale_dy = ptr(ctx.sx), ptr(sdy)
             else:
                 dyp = dy
@@ -436,26 +486,29 @@ class ConvBnRelu(Function):
                 with torch.cuda.stream(side):
                     ws2 = _ws(wb, y)
                     if wsplit:   # GEMM on the side stream, its HBM-bound reduce on a third one under the next layer's GEMM
-                        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                        _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
                         red = _reduce_stream(dev)
                         red.wait_stream(side)
-                        ws2.record_stream(red)
+                        for tns in (ws2, ctx.sx, sdy):           # read by the reduce (partials, the two operand scales)
+                            if tns is not None:
+                                tns.record_stream(red)
                         with torch.cuda.stream(red):
-                            call("rpnet_conv_wgrad", C.byref(d), None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                            _cconv("rpnet_conv_wgrad", d, None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                                  ptr(ws2), wb)
                     else:
-                        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                        _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                              ptr(ws2), wb)
                 for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
                     if tns is not None:
                         tns.record_stream(side)
-                if not _ASYNC["pending"]:
+                if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
                     torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+                    _ASYNC["queued"] = True
                 _ASYNC["pending"].add(dev)
                 dw = None
             else:
                 ws2 = _ws(wb, y)
-                call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
             need0 = ctx.needs_input_grad[0]
             need1 = x1 is not None and ctx.needs_input_grad[1]
             if need0 or need1:
@@ -469,12 +522,12 @@ class ConvBnRelu(Function):
                     dd = _desc(dys, None, pk[1], None, None, 0, g0, g1, N, H, W,
                                pw.taps, 0, out_scale=None if need_s else in_scale, out_mode=in_mode)
                     dd.split_planes = np_
-                    if np_ == 2:
+                    if np_ <= 2:
                         dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
-                call("rpnet_conv_fwd", C.byref(dd))
+                _cconv("rpnet_conv_fwd", dd)
                 if need_s:   # d(x*f(s)) -> dx = g*f(s), ds = +-<g, x>
                     gx, dscale = torch.empty_like(g0), torch.empty_like(in_scale)
                     call("rpnet_rowdot_scale", ptr(g0), ptr(x0), ptr(in_scale), ptr(gx), ptr(dscale), N * H * W, c0,
@@ -522,7 +575,7 @@ class ConvRelu(Function):
         else:
             d = _desc(x, None, pw.wp, bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
         d.dilation = dilation
-        call("rpnet_conv_fwd", C.byref(d))
+        _cconv("rpnet_conv_fwd", d)
         ctx.save_for_backward(x, weight, z)
         ctx.pw, ctx.cfg, ctx.xs = pw, (relu, dilation), xs
         return z
@@ -550,7 +603,7 @@ class ConvRelu(Function):
         d.Co0, d.dilation = cout, dilation
         wb2 = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
         ws2 = _ws(wb2, z)
-        call("rpnet_conv_wgrad", C.byref(d), ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
+        _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb2)
         dx = None
         if ctx.needs_input_grad[0] and pw.has_wd:
             dx = _empty(x.shape, z)
@@ -560,7 +613,7 @@ class ConvRelu(Function):
             else:
                 dd = _desc(dy, None, pw.wd, None, None, 0, dx, None, N, H, W, pw.taps, 0)
             dd.dilation = dilation
-            call("rpnet_conv_fwd", C.byref(dd))
+            _cconv("rpnet_conv_fwd", dd)
         return dx, dw, db, None, None, None
 
 
@@ -684,14 +737,17 @@ class LocalCorr(Function):
         if np_ and c1 is not None and c2 is not None and c1[0].shape[1:] == f1.shape and c2[0].shape[1:] == f2.shape:
             # both inputs are BatchNorm outputs that came with fp16 planes and their tensor scales
             (f1s, s1), (f2s, s2) = c1, c2
-            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, 2, ptr(s1), ptr(s2))
+            np_ = f1s.shape[0]          # 2, or 1 in "f16" mode
+            ARITH[("corr", _PLANE_NAME[np_])] += 1
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, ptr(s1), ptr(s2))
             ctx.save_for_backward(f1s, f2s, s1, s2)
-            np_ = 2
         elif np_:
             f1s, f2s = _split_operand(f1, np_), _split_operand(f2, np_)
+            ARITH[("corr", _PLANE_NAME[np_])] += 1
             call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None)
             ctx.save_for_backward(f1s, f2s)
         else:
+            ARITH[("corr", "f32")] += 1
             call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
             ctx.save_for_backward(f1, f2)
         ctx.r, ctx.np_, ctx.shape = r, np_, tuple(f1.shape)
@@ -701,11 +757,12 @@ class LocalCorr(Function):
     @once_differentiable
     def backward(ctx, dcorr):
         f1, f2 = ctx.saved_tensors[:2]
-        s1, s2 = ctx.saved_tensors[2:] if ctx.np_ == 2 else (None, None)
+        s1, s2 = ctx.saved_tensors[2:] if ctx.np_ in (1, 2) else (None, None)
         B, h, w, Cc = ctx.shape
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
         ws = _ws(wb, dcorr)
+        ARITH[("corr_bwd", _PLANE_NAME[ctx.np_])] += 1
         if ctx.np_:
             call("rpnet_local_corr_split_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc,
                  ctx.r, CORR_STRIDE, ctx.np_, ptr(s1), ptr(s2), ptr(ws), wb)

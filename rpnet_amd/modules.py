@@ -296,6 +296,7 @@ class RP_Net(nn.Module):
         H, W = qry_imgs[0].shape[-2:]
         h, w = H // self.scale, W // self.scale
         cache = self._cache
+        RF.reset_async()
         if self.training or not self.freeze_packs:
             cache.clear()  # packed weights live for one forward only (never reused across optimizer steps)
 

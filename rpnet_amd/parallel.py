@@ -88,16 +88,18 @@ class FlatGradBucket:
             self._launcher(len(self.bounds) - 2)()
 
     def zero(self):
+        from .functional import reset_async
+        reset_async()                # no side-stream accumulation may still be in flight into the buffer
         self._work = {}
         self._tail_work = None
         self.flat.zero_()
 
     def allreduce(self, async_op=False):
         """sum over ranks, then 1/world (mean gradient).  No-op without a process group."""
+        from .functional import join_side_streams
+        join_side_streams()          # also in single-process runs: the optimizer step reads the bucket next
         if not self._active():
             return None
-        from .functional import join_side_streams
-        join_side_streams()
         for s in range(len(self.bounds) - 1):             # whatever has not been launched during backward
             if s not in self._work:
                 dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM)

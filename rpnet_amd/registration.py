@@ -89,7 +89,7 @@ def displacement_warp(x, disp, threshold=-1.0, scale=1.0, shift=0.0):
     return out
 
 
-def get_registration_field(query_images, support_images, support_labels, do_deformable=False, device="cuda:0"):
+def get_registration_field(query_images, support_images, support_labels, do_deformable=True, device="cuda:0"):
     """Signature and return tuple of dataset/few_shot_reader.py:109 (registration_field, py_reg_pred,
     warped_src_list, py_affine_reg_pred, affine_warped_src_list).  query_images [S,1,H,W] in [-1,1];
     support_images [[ [S,1,H,W] ]]; support_labels [[ [S,H,W] ]].  `registration_field` holds the per-slice affine

@@ -1,0 +1,118 @@
+"""Data-parallel path on the GPU: TWO ranks of the real RP_Net on one MI355X (both on cuda:0, gloo process group — RCCL
+refuses two ranks on one device; the collective's arithmetic is the same sum), with everything that runs in the
+multi-GPU bench switched on together: async weight gradients accumulated on side streams straight into the flat bucket,
+the three-segment exchange launched from post-accumulate hooks during backward, join_side_streams in front of every
+segment (the reference has no distributed code, test_rpnet.py:16 imports data_parallel and never uses it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZE, T, GLOBAL_B = 64, 2, 4
+
+
+def _setup_model():
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    from rpnet_amd.modules import RP_Net
+    from rpnet_amd.parallel import FlatGradBucket
+    from rpnet_amd.utils.seeding import seed_module_
+    from tests.helpers import load_cfg
+    RM._F16_MIN_PIXELS = 0
+    RF.set_conv_math("f16x2")
+    RF.set_async_wgrad(True)
+    cfg = load_cfg(T)
+    net = RP_Net(cfg={"align": True, "backbone": "UNet"}, backbone_cfg=cfg).to("cuda:0")
+    seed_module_(net)
+    net.train()
+    return net, FlatGradBucket(net), cfg
+
+
+def _shard_step(net, bucket, cfg, lo, hi):
+    from rpnet_amd.functional import dice_ce
+    from tests.helpers import episode_tensors
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(909, GLOBAL_B, SIZE, "cuda:0")
+    sl = slice(lo, hi)
+    bucket.zero()
+    out = net([[si[0][0][sl]]], [[fg[0][0][sl]]], [[bg[0][0][sl]]], [qi[0][sl]], appr_query_labels=appr[sl])
+    loss = dice_ce(out["output"], ql[sl])
+    for v in out["refinement"].values():
+        loss = loss + dice_ce(v, ql[sl])
+    loss = loss + cfg["align_loss_scaler"] * out["align_loss"]
+    loss.backward()
+    return loss
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rpnet_amd.parallel import broadcast_parameters, shard_episodes
+    net, bucket, cfg = _setup_model()
+    broadcast_parameters(net)
+    assert len(bucket.bounds) == 4 and len(bucket._hooks) == 2          # three segments, two hooks
+    lo, hi = shard_episodes(GLOBAL_B, rank, world)
+    _shard_step(net, bucket, cfg, lo, hi)
+    launched = sorted(bucket._work)          # segments that went out from the hooks while backward was still running
+    bucket.allreduce()
+    torch.cuda.synchronize()
+    q.put((rank, launched, bucket.flat.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rp_net_bucket_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, l0, f0), (_, l1, f1) = res
+    assert l0 == [1, 2] and l1 == [1, 2], (l0, l1)       # (c) decoder + cre and Conv5 segments left during backward
+    assert torch.equal(f0, f1)                           # (a) both ranks hold the same averaged gradients
+    # (b) = the mean of two single-process runs of the same shards (per-rank BatchNorm statistics, as in the exchange)
+    from rpnet_amd.parallel import shard_episodes
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    old = (RF.conv_math(), RM._F16_MIN_PIXELS, RF._ASYNC["on"])
+    try:
+        flats = []
+        for r in range(2):
+            net, bucket, cfg = _setup_model()
+            _shard_step(net, bucket, cfg, *shard_episodes(GLOBAL_B, r, 2))
+            bucket.allreduce()                           # no process group: joins the side streams only
+            torch.cuda.synchronize()
+            flats.append(bucket.flat.cpu().double())
+    finally:
+        RF.set_conv_math(old[0])
+        RM._F16_MIN_PIXELS = old[1]
+        RF.set_async_wgrad(old[2])
+    want = (flats[0] + flats[1]) / 2
+    err = float((f0.double() - want).abs().max() / want.abs().max())
+    assert err <= 1e-6, err
+    assert float(want.abs().max()) > 0
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 code path end to end (rendezvous, sharded seeds, barrier-fenced timing, max over ranks, every
+    rank in the profiled step's collective) with two gloo ranks on the one GPU; small shapes."""
+    env = dict(os.environ, RPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(35500 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "2", "--size", "128", "--iters", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"

@@ -141,3 +141,145 @@ def test_f16_threshold_switch(RF):
     finally:
         RM._F16_MIN_PIXELS = old
         RF.set_conv_math("f32")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# "f16": ONE fp16 plane (plain fp16 operands, fp32 accumulation, fp32 BatchNorm statistics) — BASELINE configs[4].
+# The reference is fp32-only (net/rp_net.py:160,166-171,179), so the oracle is the fp32 reference on identical inputs
+# and the tolerance is stated here (SURVEY.md §8a "fp16 (c5)"): logits within 1e-2 of max |logit| (= 20), per-iteration
+# Dice and foreground fraction within 1e-3, loss within 1e-2 relative.
+F16_LOGIT_TOL = 1e-2
+F16_DICE_TOL = 1e-3
+
+
+@pytest.fixture
+def f16_single(RF):
+    from rpnet_amd import modules as RM
+    old, old_min = RF.conv_math(), RM._F16_MIN_PIXELS
+    RF.set_conv_math("f16")
+    RM._F16_MIN_PIXELS = 0
+    yield RF
+    RM._F16_MIN_PIXELS = old_min
+    RF.set_conv_math(old)
+
+
+def _dice(logits, ql):
+    pred = (logits.softmax(1)[:, 1] > 0.5).long()
+    return float(2.0 * (pred * ql).sum() / (pred.sum() + ql.sum() + 1e-7)), float(pred.float().mean())
+
+
+def test_f16_single_plane_layer_vs_fp32(f16_single):
+    """conv3x3 + BatchNorm + ReLU (x2, the second on a concatenation) under the one-plane arithmetic against torch fp32:
+    output, input gradient and weight gradients within a few fp16 ulps of the tensor maximum; every launch counted as f16."""
+    import copy
+    import torch.nn as nn
+    RF = f16_single
+    from tests.helpers import rel_err, rnd
+    torch.manual_seed(3)
+    c1, b1 = nn.Conv2d(64, 128, 3, padding=1), nn.BatchNorm2d(128)
+    c2, b2 = nn.Conv2d(192, 128, 3, padding=1), nn.BatchNorm2d(128)
+    x = rnd(5, 4, 64, 32, 32)
+    go = rnd(6, 4, 128, 32, 32)
+    ref_mods = [copy.deepcopy(m) for m in (c1, b1, c2, b2)]
+    xr = x.clone().requires_grad_(True)
+    a = torch.relu(ref_mods[1](ref_mods[0](xr)))
+    zr = torch.relu(ref_mods[3](ref_mods[2](torch.cat([xr, a], 1))))
+    zr.backward(go)
+    for m in (c1, b1, c2, b2):
+        m.to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    cache = RF.WeightCache()
+    RF.reset_arith()
+    # the network's first layer gets its input scale from a BatchNorm; a raw tensor carries none: hand one in
+    s_in = torch.tensor([2.0 ** (int(np.ceil(np.log2(float(x.abs().max())))) - 15)], device=DEV)
+    a = RF.conv_bn_relu(xd, c1, b1, cache, True, out_split="scale", x_scales=(s_in,))
+    z = RF.conv_bn_relu(xd, c2, b2, cache, True, x1=a, x_scales=(s_in, a._rp_scale))
+    z.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+    counts = RF.arith_counts()
+    assert counts["conv3x3"] == {"f16": 4} and counts["wgrad3x3"] == {"f16": 2}, counts       # 2 forward + 2 dgrad, 2 wgrad
+    assert rel_err(z.permute(0, 3, 1, 2), zr) < 4e-3
+    assert rel_err(xd.grad.permute(0, 3, 1, 2), xr.grad) < 4e-3
+    assert rel_err(c1.weight.grad, ref_mods[0].weight.grad) < 4e-3 and rel_err(c2.weight.grad, ref_mods[2].weight.grad) < 4e-3
+    assert rel_err(b2.weight.grad, ref_mods[3].weight.grad) < 4e-3
+
+
+@pytest.mark.parametrize("size,B,T", [(64, 2, 2), (128, 1, 2)])
+def test_f16_two_way_vs_fp32_oracle(f16_single, size, B, T):
+    """2-way 1-shot (the configs[4] shape class) under the one-plane fp16 arithmetic against the fp32 oracle composed
+    from the reference's own pieces, at the stated tolerance."""
+    from oracle import rpnet_oracle as O
+    from tests.helpers import episode_tensors, load_cfg
+    from tests.test_gpu_model import build, total_loss
+    RF = f16_single
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(66 + size, B, size, "cpu", n_shots=1, n_ways=2)
+    P = O.seeded_params()
+    with torch.no_grad():
+        ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True)
+        ref_loss = O.total_loss(ref, ql, cfg["align_loss_scaler"])
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    RF.reset_arith()
+    out = net([[mv(s) for s in w] for w in si], [[mv(s) for s in w] for w in fg], [[mv(s) for s in w] for w in bg],
+              [mv(qi[0])], appr_query_labels=mv(appr))
+    loss = total_loss(out, mv(ql), cfg["align_loss_scaler"])
+    loss.backward()
+    counts = RF.arith_counts()
+    assert set(counts["conv3x3"]) == {"f16"} and set(counts["wgrad3x3"]) == {"f16"} and set(counts["corr"]) == {"f16"}, counts
+    assert out["output"].shape == (B, 3, size, size)
+    for i in range(T):
+        got, want = out["refinement"][i].cpu(), ref["refinement"][i]
+        assert float((got - want).abs().max()) <= F16_LOGIT_TOL * float(want.abs().max()), f"logits, iteration {i}"
+        (d_g, f_g), (d_r, f_r) = _dice(got, ql), _dice(want, ql)
+        assert abs(d_g - d_r) <= F16_DICE_TOL and abs(f_g - f_r) <= F16_DICE_TOL, (i, d_g, d_r, f_g, f_r)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-2 * abs(ref_loss.item())
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+def test_config5_full_size_f16(f16_single):
+    """BASELINE configs[4] at its real size: 2-way 1-shot, 512x512, T=10, batch 4 per GPU, one fp16 plane.  The
+    reference would allocate a 1.07 GB all-pairs correlation per sample and CRE call here (net/rp_net.py:158-161); the
+    local-window kernel must not.  Size-independent properties + the same step under the fp32-equivalent arithmetic
+    (f16x2, itself held to the reference at 64^2..256^2) as the full-size yardstick of the stated fp16 tolerance."""
+    from tests.helpers import episode_tensors, load_cfg
+    from tests.test_gpu_model import build, total_loss
+    RF = f16_single
+    T, B, size = 10, 4, 512
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(555, B, size, DEV, n_shots=1, n_ways=2)
+
+    def run(math):
+        RF.set_conv_math(math)
+        torch.cuda.reset_peak_memory_stats()
+        net = build(cfg, True)
+        RF.reset_arith()
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        loss = total_loss(out, ql, cfg["align_loss_scaler"])
+        loss.backward()
+        torch.cuda.synchronize()
+        return net, out, loss, RF.arith_counts(), torch.cuda.max_memory_allocated()
+
+    net, out, loss, counts, peak = run("f16")
+    assert out["output"].shape == (B, 3, size, size) and len(out["refinement"]) == T
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert (out["output"].abs() <= 20.0 + 1e-3).all()
+    assert set(counts["conv3x3"]) == {"f16"} and set(counts["wgrad3x3"]) == {"f16"}, counts
+    assert set(counts["corr"]) == {"f16"} and set(counts["corr_bwd"]) == {"f16"}, counts
+    sd = net.state_dict()
+    assert int(sd["encoder.Conv1.conv.1.num_batches_tracked"]) == 2            # one support call (8 images) + the query call
+    assert int(sd["cre.w_k.1.num_batches_tracked"]) == 2 + T                    # one CRE call per way + T query calls
+    # 12 CRE calls x 4 samples x 1.07 GB of all-pairs scores (plus their grid_sample batches) would be > 51 GB
+    assert peak < 40e9, f"peak allocation {peak / 1e9:.1f} GB"
+    g16 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    ref_net, ref, ref_loss, _, _ = run("f16x2")
+    for i in range(T):
+        got, want = out["refinement"][i], ref["refinement"][i]
+        assert float((got - want).abs().max()) <= F16_LOGIT_TOL * float(want.abs().max()), f"logits, iteration {i}"
+        (d_g, f_g), (d_r, f_r) = _dice(got, ql), _dice(want, ql)
+        assert abs(d_g - d_r) <= F16_DICE_TOL and abs(f_g - f_r) <= F16_DICE_TOL, (i, d_g, d_r, f_g, f_r)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-2 * abs(ref_loss.item())
+    # gradients: relative L2 per parameter against the fp32-equivalent step (conditioned by the switches: loose)
+    for n, p in ref_net.named_parameters():
+        if p.grad is not None and p.grad.norm() > 1e-6 and not n.endswith("conv.0.bias") and not n.endswith("conv.3.bias"):
+            e = float((g16[n].double() - p.grad.double()).norm() / p.grad.double().norm())
+            assert e < 0.1, f"{n}: {e:.3f}"

@@ -145,7 +145,7 @@ def test_split_halo_kernel(RF, monkeypatch, tile, N, H, W, c0, c1, cout, ups):
     """The halo-resident 256x128 variant (conv_igemm_split_halo_kernel: image patches, input halo staged once per
     channel chunk) forced on small shapes: two sources, nearest x2, both patch widths (W % 32 == 0 / W % 16 == 0),
     two BatchNorm groups; forward, dgrad and the fused batch statistics against the torch reference."""
-    monkeypatch.setenv("RPNET_SPLIT_TILE", tile)
+    monkeypatch.setitem(RF.TUNE, "tile", int(tile) + 1)      # rpnet_conv_desc.tune: force tile variant `tile`
     old = RF.conv_math()
     RF.set_conv_math("bf16x3")
     try:
