@@ -261,6 +261,10 @@ class RP_Net(nn.Module):
         # calls; the caller promises not to change parameters / running statistics meanwhile (rpnet_amd.graph sets it:
         # a captured graph assumes static weights anyway).  `net._cache.clear()` drops the packs.
         self.freeze_packs = False
+        # test / diagnostic hook (off by default): teacher forcing of the refinement loop — {i: mask [B,h,w]} replaces the
+        # mask fed INTO iteration i (the loop's own thresholded prediction of iteration i-1, net/rp_net.py:308-311), so
+        # that one flipped pixel at the 0.5 threshold cannot compound across iterations when two arithmetics are compared
+        self.forced_masks = None
         self.scale = backbone_cfg.get("scale", 4)
         self.num_iter = backbone_cfg["n_iter_refinement"]
         self.use_relation_enc = backbone_cfg.get("use_relation_enc", "relation")
@@ -342,6 +346,8 @@ class RP_Net(nn.Module):
         T = self.num_iter
         qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
         for i in range(T):
+            if self.forced_masks is not None and i in self.forced_masks:
+                qry_mask = self.forced_masks[i].float().contiguous()
             inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
             logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
             if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask

@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
     launched = sorted(bucket._work)          # segments that went out from the hooks while backward was still running
     bucket.allreduce()
     torch.cuda.synchronize()
-    q.put((rank, launched, bucket.flat.cpu()))
+    q.put((rank, launched, bucket.flat.cpu().numpy()))       # by value: the worker may exit before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +78,7 @@ def test_two_rank_rp_net_bucket_on_one_gpu():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     (_, l0, f0), (_, l1, f1) = res
+    f0, f1 = torch.from_numpy(f0), torch.from_numpy(f1)
     assert l0 == [1, 2] and l1 == [1, 2], (l0, l1)       # (c) decoder + cre and Conv5 segments left during backward
     assert torch.equal(f0, f1)                           # (a) both ranks hold the same averaged gradients
     # (b) = the mean of two single-process runs of the same shards (per-rank BatchNorm statistics, as in the exchange)
