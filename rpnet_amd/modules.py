@@ -265,6 +265,9 @@ class RP_Net(nn.Module):
         # mask fed INTO iteration i (the loop's own thresholded prediction of iteration i-1, net/rp_net.py:308-311), so
         # that one flipped pixel at the 0.5 threshold cannot compound across iterations when two arithmetics are compared
         self.forced_masks = None
+        # test hook (off by default): a dict that forward fills with detached NCHW views of the stage-boundary tensors
+        # of SURVEY.md §3.2 — supp_d4, qry_d4, supp_fts[wa][s], protos, inter_i — for comparison with the golden fixtures
+        self.taps = None
         self.scale = backbone_cfg.get("scale", 4)
         self.num_iter = backbone_cfg["n_iter_refinement"]
         self.use_relation_enc = backbone_cfg.get("use_relation_enc", "relation")
@@ -318,6 +321,10 @@ class RP_Net(nn.Module):
             qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
             s_supp, s_qry = getattr(supp_d4, "_rp_scale", None), getattr(qry_d4, "_rp_scale", None)
         supp_d4 = supp_d4.reshape(n_ways, n_shots, B, h, w, -1)
+        taps = self.taps
+        if taps is not None:
+            taps["supp_d4"] = supp_d4.detach().permute(0, 1, 2, 5, 3, 4)
+            taps["qry_d4"] = _to_nchw(qry_d4.detach())
 
         # ---- support relation features, per (way, shot) with that shot's own mask (:269-275)
         fore = [[m.float().contiguous() for m in way] for way in fore_mask]
@@ -336,6 +343,9 @@ class RP_Net(nn.Module):
             fg_protos.append(fg_w / n_shots)
             bg_sum = bg_sum + bg_w / n_shots
         protos = torch.stack([bg_sum / n_ways] + fg_protos, 1).contiguous()  # [B,1+Wa,C]
+        if taps is not None:
+            taps["supp_fts"] = [[_to_nchw(f.detach()) for f in way] for way in supp_fts]
+            taps["protos"] = protos.detach()
 
         # ---- refinement loop (:281-312)
         soft = self.backbone_cfg["soft_mask"] != False  # noqa: E712 (the reference compares with ==)
@@ -350,6 +360,8 @@ class RP_Net(nn.Module):
                 qry_mask = self.forced_masks[i].float().contiguous()
             inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
             logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
+            if taps is not None:
+                taps[f"inter_{i}"] = _to_nchw(inter.detach())
             if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask
                 qry_mask = RF.SoftmaxPool.apply(logits, self.scale)
             else:

@@ -37,3 +37,32 @@ def rnd(seed, *shape):
 def rel_err(a, b):
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def rel_l2(a, b):
+    """|| a - b ||_2 / || b ||_2 — element-wise agreement in the aggregate (rel_err is max-abs over max-abs)"""
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+
+def oracle_step(cfg, inputs, dtype=torch.float32, input_scale=1.0, noise=None):
+    """One forward + backward of the CPU oracle (train mode, align loss on, the harness loss) in `dtype` on the seeded
+    parameters; `input_scale` multiplies the images, `noise` = (seed, eps) multiplies every image pixel by
+    1 + eps * u, u uniform in [-1, 1] (conditioning experiments).  Returns ({name: grad}, loss, out)."""
+    from oracle import rpnet_oracle as O
+    si, fg, bg, qi, ql, appr = inputs
+    P = {}
+    for k, v in O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True).items():
+        t = v.detach().to(dtype) if v.is_floating_point() else v.detach().clone()
+        P[k] = t.clone().requires_grad_(v.requires_grad)
+    c = lambda t: t.to(dtype)  # noqa: E731
+    if noise is not None:
+        gen = torch.Generator().manual_seed(noise[0])
+        jit = lambda t: c(t) * (1.0 + noise[1] * (2.0 * torch.rand(t.shape, generator=gen, dtype=torch.float64) - 1.0)).to(dtype)  # noqa: E731
+    else:
+        jit = lambda t: c(t) * input_scale  # noqa: E731
+    out = O.rp_net_forward(P, cfg, [[jit(s) for s in w] for w in si], [[c(s) for s in w] for w in fg],
+                           [[c(s) for s in w] for w in bg], [jit(qi[0])], c(appr), True, align=True)
+    loss = O.total_loss(out, ql, cfg["align_loss_scaler"])
+    loss.backward()
+    return {k: v.grad for k, v in P.items() if v.requires_grad and v.grad is not None}, loss.detach(), out

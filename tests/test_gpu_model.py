@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import episode_tensors, in_checksum, load_cfg, rel_err
+from tests.helpers import episode_tensors, in_checksum, load_cfg, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -84,10 +84,22 @@ def test_model_vs_golden(golden, tag, conv_math):
     assert np.allclose(in_checksum(ep), g["in_checksum"], rtol=0, atol=1e-6), "synthetic inputs drifted"
     s_out, s_d4, s_f = (int(v) for v in g["strides"])
     net = build(cfg, training)
+    net.taps = {}
     with torch.set_grad_enabled(training):
         out = net(si, fg, bg, qi, appr_query_labels=appr)
         loss = total_loss(out, ql, cfg["align_loss_scaler"])
     assert out["output"] is out["refinement"][T - 1]
+    # stage-boundary tensors of SURVEY.md §3.2 against what the reference's forward hooks captured (strided fixtures)
+    tp = net.taps
+    # both norms: max |err| / max |ref| (what the north star's "1e-3 relative" bounds) and relative L2 (which small-magnitude
+    # regions of a feature map cannot hide behind its largest value)
+    for err in (rel_err, rel_l2):
+        assert err(tp["supp_d4"][0, 0][:, ::s_d4], g["supp_d4"]) < TOL and err(tp["qry_d4"][:, ::s_d4], g["qry_d4"]) < TOL
+        assert err(tp["supp_fts"][0][0][..., ::s_f, ::s_f], g["supp_fts"]) < TOL
+        assert err(tp["protos"], g["protos"]) < TOL
+        for i in range(T):
+            assert err(tp[f"inter_{i}"][..., ::s_f, ::s_f], g[f"inter_{i}"]) < TOL, f"inter[{i}]"
+            assert err(out["refinement"][i][..., ::s_out, ::s_out], g[f"refinement_{i}"]) < TOL, f"refinement[{i}]"
     flips = 0
     for i in range(T):
         got = out["refinement"][i]
@@ -115,10 +127,11 @@ def test_model_vs_golden(golden, tag, conv_math):
             if ref < 1e-4:          # conv biases in front of train-mode BN: analytically zero
                 assert gr.abs().max() < 1e-4
                 continue
-            # Gradient tolerances follow the REFERENCE's own conditioning: ReLU / max-pool / arg-max
-            # switches make d loss / d encoder-weights move by ~1e-2 when the input images are
-            # perturbed by 2e-6 relative (measured on the CPU oracle, DESIGN.md "Parity"); the
-            # CRE block behind them is smooth and is held to 1e-3.
+            # Gradient NORMS and the first 32 elements against the reference's fixtures; the element-wise L2 comparison of
+            # every tensor with a reproducible yardstick (the fp64 oracle, err_HIP <= 3 err_fp32-oracle) is
+            # test_gradients_vs_fp64_yardstick, the conditioning behind it tests/test_oracle_conditioning.py (the fp32
+            # oracle itself sits 1e-3 from fp64 on the encoder weights and moves by 2e-3 under a 2e-6 input perturbation):
+            # the encoder bounds here are 5 x those measured movements, the smooth CRE block is held to 1e-3.
             enc = n.startswith("encoder.")
             e = abs(gr.double().norm().item() - ref) / ref
             worst = max(worst, e)
@@ -406,3 +419,123 @@ def test_graphed_eval_matches_eager():
         assert len(out["refinement"]) == 10
         assert torch.equal(out["output"], ref)
     assert len(graphed._graphs) == 1
+
+
+YARD_EPS = 4e-7      # relative input perturbation of the yardstick: moves the fp64 forward as much as the HIP path deviates
+YARD_DRAWS = 6
+_YARD_CACHE = {}     # tag -> fp64 oracle results (shared by the three arithmetics)
+
+
+@pytest.mark.parametrize("tag", ["m64_train", "m128_train"])
+def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
+    """Backward parity with a reproducible yardstick instead of a loose constant.  Reference point: the CPU oracle in
+    FLOAT64 on the same inputs.  Yardstick: how far the fp64 oracle's OWN gradients move when every image pixel is
+    perturbed by YARD_EPS = 4e-7 relative (which moves the fp64 logits by 3e-6 .. 7e-6: the size of the HIP path's forward
+    deviation from fp64 — both asserted below, so the yardstick is neither inflated nor starved) —
+    the maximum over YARD_DRAWS independent draws, per parameter tensor, relative L2.  Requirement: the HIP gradient is
+    no further from the fp64 gradient than 3 x that movement.
+    Why a perturbation and not "the fp32 oracle's distance to fp64": the distance is made of DISCRETE events — a
+    pre-activation within the forward error of zero takes the other side of its ReLU (or max-pool / arg-max) — each
+    worth ~ |dz| / ||dy|| = 1e-3 of every upstream gradient at these sizes (tools/diag_grads2.py shows one: the
+    deviation enters at a single BatchNorm beta).  Whether an implementation hits such an event on a given episode is
+    chance proportional to its forward error; the perturbation draws sample exactly that chance at the HIP path's error
+    level (tests/test_oracle_conditioning.py is the CPU-only statement of the same sensitivity)."""
+    from tests.helpers import oracle_step
+    g = golden(tag)
+    size, B, T, _, seed = (int(v) for v in g["meta"])
+    cfg = load_cfg(T)
+    cpu_inputs, _ = episode_tensors(seed, B, size)
+    if tag not in _YARD_CACHE:
+        g64, l64, o64 = oracle_step(cfg, cpu_inputs, dtype=torch.float64)
+        yard, fwd_moves = {}, []
+        for draw in range(YARD_DRAWS):
+            gp, _, op = oracle_step(cfg, cpu_inputs, dtype=torch.float64, noise=(100 + draw, YARD_EPS))
+            fwd_moves.append(rel_err(op["refinement"][0].detach(), o64["refinement"][0].detach()))
+            for n, v in gp.items():
+                nrm = float(g64[n].norm())
+                if nrm >= 1e-4:
+                    yard[n] = max(yard.get(n, 0.0), float((v - g64[n]).norm()) / nrm)
+        _YARD_CACHE[tag] = (g64, l64, o64["refinement"][0].detach(), yard, fwd_moves)
+    g64, l64, logits64, yard, fwd_moves = _YARD_CACHE[tag]
+    net = build(cfg, True)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV)
+    out = net(si, fg, bg, qi, appr_query_labels=appr)
+    loss = total_loss(out, ql, cfg["align_loss_scaler"])
+    loss.backward()
+    assert abs(loss.item() - l64.item()) < 1e-5 * abs(l64.item())
+    fwd_hip = rel_err(out["refinement"][0].detach(), logits64)
+    # the perturbation is the right size: it moves the fp64 forward (median of the draws) between a third of and three
+    # times what the HIP path deviates
+    mid = sorted(fwd_moves)[len(fwd_moves) // 2]
+    assert fwd_hip < 2e-5 and fwd_hip / 3.0 <= mid <= 3.0 * fwd_hip, (fwd_hip, fwd_moves)
+    report = []
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        ref = g64[n]
+        nrm = float(ref.norm())
+        if nrm < 1e-4:              # conv biases in front of a train-mode BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) < 1e-4, n
+            continue
+        e_hip = float((p.grad.double().cpu() - ref).norm()) / nrm
+        report.append((e_hip / yard[n], n, e_hip, yard[n]))
+    report.sort(reverse=True)
+    print(f"{tag} [{conv_math}]: forward deviation {fwd_hip:.1e} (perturbed fp64: {max(fwd_moves):.1e}); worst err_HIP / yardstick:",
+          [(round(r, 2), n, f"{a:.1e}", f"{b:.1e}") for r, n, a, b in report[:3]], "median ratio", round(report[len(report) // 2][0], 2))
+    for ratio, n, e_hip, y in report:
+        assert e_hip <= 3.0 * y, f"{n}: HIP {e_hip:.2e} from the fp64 gradient, yardstick (fp64 oracle under a {YARD_EPS} input perturbation) {y:.2e}"
+
+
+@pytest.mark.parametrize("tag", ["cb", "up"])
+def test_blocks_vs_reference_fixture(golden, tag, conv_math):
+    """conv_block / up_conv (net/modules.py:42-75) against the REFERENCE's own outputs, gradients and BatchNorm buffers
+    (tests/golden/blocks.npz: 3 -> 8 / 4 -> 8 channels, 10x12 images, two train calls + one eval call).  The HIP
+    kernels tile channels by 32 / 64, so the fixture's layer is embedded in a 64 -> 64 one whose extra weights, biases
+    and BatchNorm affines are zero: the real channels see exactly the reference's arithmetic."""
+    from rpnet_amd.modules import conv_block, up_conv
+    from rpnet_amd.utils.seeding import seeded_tensor
+    g = golden("blocks")
+    cin, cout = (3, 8) if tag == "cb" else (4, 8)
+    m = (conv_block if tag == "cb" else up_conv)(64, 64, "BatchNorm2d")
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            ref = seeded_tensor(f"blk_{tag}.{k}", torch.empty(g[f"{tag}_sd2.{k}"].shape, dtype=v.dtype))
+            if v.dim() == 0:
+                v.copy_(ref)
+                continue
+            if "running_var" not in k:
+                v.zero_()
+            idx = tuple(slice(0, s) for s in ref.shape)
+            v[idx] = ref
+    m.to(DEV).train()
+
+    def pad(x, c):
+        out = torch.zeros(x.shape[0], c, *x.shape[2:])
+        out[:, :x.shape[1]] = torch.as_tensor(x)
+        return out.to(DEV)
+
+    x1 = pad(g[f"{tag}_x1"], 64).requires_grad_(True)
+    y1 = m(x1)
+    assert rel_err(y1[:, :cout], g[f"{tag}_y1"]) < TOL and float(y1[:, cout:].abs().max()) == 0.0
+    y1.backward(pad(g[f"{tag}_go"], 64))
+    assert rel_err(x1.grad[:, :cin], g[f"{tag}_gx"]) < TOL
+    for n, p in m.named_parameters():
+        ref = torch.from_numpy(g[f"{tag}_g.{n}"])
+        got = p.grad[tuple(slice(0, s) for s in ref.shape)]
+        if n in ("conv.0.bias", "conv.3.bias", "up.1.bias"):
+            # conv bias in front of a train-mode BatchNorm: round-off in the reference (1e-5), analytically zero here
+            assert float(got.abs().max()) < 1e-5, n
+        else:
+            assert rel_err(got, ref) < TOL, n
+    y2 = m(pad(g[f"{tag}_x2"], 64))
+    assert rel_err(y2[:, :cout], g[f"{tag}_y2"]) < TOL
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_err(v[:cout], g[f"{tag}_sd2.{k}"]) < 1e-4, k
+        elif "num_batches" in k:
+            assert int(v) == int(g[f"{tag}_sd2.{k}"]) == 2
+    m.eval()
+    with torch.no_grad():
+        ye = m(pad(g[f"{tag}_x1"], 64))
+    assert rel_err(ye[:, :cout], g[f"{tag}_yeval"]) < TOL
