@@ -251,20 +251,24 @@ int rpnet_mask_avgpool(const float* mask, float* out, int B, int H, int W, int s
 int rpnet_local_corr_fwd(const float* f1, const float* f2, float* corr, int B, int h, int w, int C, int r,
                          int cstride, rpnet_stream_t stream);
 size_t rpnet_local_corr_bwd_workspace_bytes(int B, int h, int w, int cstride);
+/* df1_add (may be NULL): a second gradient of f1 that is summed into df1 by the kernel's own store — f1 also feeds the
+ * 1x1 convolution as the second source of cat([corr, fm1]) (net/rp_net.py:81); autograd would add the two in a
+ * separate pass.  df1_add may alias df1. */
 int rpnet_local_corr_bwd(const float* f1, const float* f2, const float* dcorr, float* df1, float* df2,
-                         int B, int h, int w, int C, int r, int cstride,
+                         int B, int h, int w, int C, int r, int cstride, const float* df1_add,
                          void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 /* the same on the bf16 matrix pipe with split-bf16 operands (rpnet_split_bf16 planes of f1 / f2, r = 5): the
  * 64 x 324 tile-by-halo score matrix as a GEMM over the channels, the window gathered out of it; backward as a
  * GEMM over the halo positions (C % 128 == 0).  dcorr and the outputs stay fp32.
- * planes == 3: bf16 planes.  planes == 2: fp16 planes of f1 / scale1 and f2 / scale2 (device scalars: the tensor scales
- * rpnet_bn_relu wrote with the planes); the window gradients of the backward get a block-local power-of-two scale from
- * the maximum of the tile's own values. */
+ * planes == 3: bf16 planes.  planes == 2 (or 1: plain fp16): fp16 planes of f1 / scale1 and f2 / scale2 (device scalars: the
+ * tensor scales rpnet_bn_relu wrote with the planes); the window gradients of the backward get a block-local
+ * power-of-two scale from the maximum of the tile's own values. */
 int rpnet_local_corr_split_fwd(const void* f1_split, const void* f2_split, float* corr, int B, int h, int w, int C, int r,
                                int cstride, int planes, const float* scale1, const float* scale2, rpnet_stream_t stream);
 int rpnet_local_corr_split_bwd(const void* f1_split, const void* f2_split, const float* dcorr, float* df1, float* df2,
                                int B, int h, int w, int C, int r, int cstride, int planes, const float* scale1,
-                               const float* scale2, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+                               const float* scale2, const float* df1_add, void* workspace, size_t workspace_bytes,
+                               rpnet_stream_t stream);
 
 /* ------------------------------------------------------------------------- matcher
  * getFeatures + the mask sums of net/rp_net.py:366-376 in adjoint form:

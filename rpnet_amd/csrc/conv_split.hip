@@ -552,13 +552,16 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
                                             li, h, smem);
 }
 
-template <int TW, int NP, int WN>
+// WMT = 4: the same kernel on 256-pixel patches — a 4-wave block then computes what the 8-wave kernel above does (wave
+// tile 128 x 64: 12 fragment reads per 24 MFMAs instead of 8 per 12), two such blocks per CU cover each other's staging,
+// barriers, prologue and epilogue.
+template <int TW, int NP, int WN, int WMT = 2>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
                                                                         const int tiles_n, const int ntiles) {
-    constexpr int NT = 256, BM = 128, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int NT = 256, BM = 64 * WMT, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
     constexpr int A_BYTES = HALO * 64, B_BYTES = BN * 64;
     constexpr int HJ = (HALO * 4 + NT - 1) / NT;
-    constexpr int WM = 2;
+    constexpr int WM = WMT;
     constexpr int BJ = (BN * 4 + NT - 1) / NT;                  // weight pieces per thread and plane
     __shared__ __attribute__((aligned(16))) unsigned char smem[cmax(NP * A_BYTES + NP * B_BYTES, epilogue_lds_bytes<WN, 2>())];   // one weight stage
     unsigned char* const bsm = smem + NP * A_BYTES;
@@ -723,11 +726,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
             if (t1 == 9) { t1 = 0; ++c1; }
             load_b(t1, chunk_c0(c1));
         }
-        if (tap == 0 && next_chunk) load_halo(chunk_c0(ci + 1));   // waits in registers for nine taps
+        // WMT = 2: the next chunk's halo waits in registers for nine taps.  WMT = 4 (128 accumulator registers): no room
+        // for that — it is fetched at the chunk switch, its latency covered by the CU's other block
+        if (WMT == 2 && tap == 0 && next_chunk) load_halo(chunk_c0(ci + 1));
         mma_tap(tap, 0);
         __syncthreads();
         if (more) store_b();
-        if (tap == 8 && next_chunk) store_halo();
+        if (tap == 8 && next_chunk) {
+            if (WMT != 2) load_halo(chunk_c0(ci + 1));
+            store_halo();
+        }
         __syncthreads();
         if (++tap == 9) { tap = 0; ++ci; }
     }
@@ -748,16 +756,16 @@ static int launch_split_halo(const rpnet_conv_desc* d, int M, int Cin, int Cout,
     return check_launch("conv_igemm_split_halo");
 }
 
-template <int TW, int WN>
+template <int TW, int WN, int WMT = 2>
 static int launch_split_halo4(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
-    const int tiles_m = M / 128, tiles_n = Cout / (64 * WN);
+    const int tiles_m = M / (64 * WMT), tiles_n = Cout / (64 * WN);
     const int ntiles = tiles_m * tiles_n;
     if (d->split_planes == 3)
-        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     else if (d->split_planes == 2)
-        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 2, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 2, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     else
-        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 1, WN>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 1, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     return check_launch("conv_igemm_split_halo4");
 }
 
@@ -787,6 +795,7 @@ static const SplitVariant kSplitVariants[] = {
     {4, 2, 2, 1, 256},    // 7: 256 x 128 on an image patch, input halo resident in LDS (conv_igemm_split_halo_kernel)
     {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
     {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
+    {2, 4, 2, 0, 512},    // 10: 256 x 128 on an image patch with FOUR waves (wave tile 128 x 64), two blocks per CU
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -820,13 +829,18 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = d->tune - 1;
-        if ((v == 7 && halo_tw(d, Cout)) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
+        if (((v == 7 || v == 10) && halo_tw(d, Cout) && halo_bn(d, Cout) == 128) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
         if (v >= 0 && v < 4 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
     // halo-resident patch kernels: 256 x 128 with one 8-wave block per CU when that grid fills the machine, else (and
     // for 64-wide output tiles) 128-pixel patches with two 4-wave blocks per CU
     const int hbn = halo_bn(d, Cout);
+    // one fp16 plane: a third of the MFMAs per staged byte, so the LDS fragment reads limit the 8-wave patch kernel; the
+    // 4-wave form of it (wave tile 128 x 64, two blocks per CU) reads 25 % less per MFMA: 598 vs 531 TF on 128 -> 128 at
+    // M = 262144, 767 vs 671 TF on 256 -> 256 at M = 65536 — once its grid fills both block slots of every CU
+    if (d->split_planes == 1 && hbn == 128 && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 128) >= 512)
+        return 10;
     if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224) return 7;
     if (halo4_tw(d)) {
         // 64-wide tiles (twice the blocks) win on every grid this kernel sees — 169 vs 107 TF at M = 4096, 1024 -> 512;
@@ -860,6 +874,8 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);
         case 2: return launch_split<2, 1, 2, false>(d, M, Cin, Cout, s);
         case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
+        case 10:
+            return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:
             return halo4_tw(d) == 32 ? launch_split_halo4<32, 1>(d, M, Cin, Cout, s) : launch_split_halo4<16, 1>(d, M, Cin, Cout, s);
         case 8:

@@ -138,7 +138,7 @@ constexpr int BSTR = BC + 4;    // padded feature row
 template <int R, int SIGN>
 __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __restrict__ g, const float* __restrict__ fo,
                                                               float* __restrict__ df, int h, int w, int C, int cstride,
-                                                              float inv_sqrt_c) {
+                                                              float inv_sqrt_c, const float* __restrict__ add) {
     constexpr int K = 2 * R + 1, HT = CT + 2 * R, NX = 4 + 2 * R, KA = (K + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* fs = sm;                   // [HT*HT][BSTR]
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __rest
     const float* gb = g + (size_t)b * h * w * cstride;
     const float* fb = fo + (size_t)b * h * w * C;
     float* dfb = df + (size_t)b * h * w * C;
+    const float* addb = add ? add + (size_t)b * h * w * C : nullptr;   // a second gradient of the same tensor, summed here
 
     for (int e = t; e < 64 * K * KA; e += 256) {
         const int a = e % KA, c = (e / KA) % K, p = e / (KA * K);
@@ -192,7 +193,12 @@ __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __rest
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int y = ty0 + py, x = tx0 + px0 + p;
-            if (y < h && x < w) *reinterpret_cast<f32x4*>(dfb + ((size_t)y * w + x) * C + c0 + cg * 4) = acc[p] * inv_sqrt_c;
+            if (y < h && x < w) {
+                const size_t o = ((size_t)y * w + x) * C + c0 + cg * 4;
+                f32x4 v = acc[p] * inv_sqrt_c;
+                if (addb) v += *reinterpret_cast<const f32x4*>(addb + o);
+                *reinterpret_cast<f32x4*>(dfb + o) = v;
+            }
         }
     }
 }
@@ -247,8 +253,8 @@ extern "C" size_t rpnet_local_corr_bwd_workspace_bytes(int B, int h, int w, int 
 }
 
 extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const float* dcorr, float* df1, float* df2, int B,
-                                       int h, int w, int C, int r, int cstride, void* workspace, size_t workspace_bytes,
-                                       rpnet_stream_t stream) {
+                                       int h, int w, int C, int r, int cstride, const float* df1_add, void* workspace,
+                                       size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1 && f2 && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_bwd: null pointer");
     RPNET_REQUIRE(C % CC == 0 && cstride >= (2 * r + 1) * (2 * r + 1), RPNET_ERR_SHAPE, "local_corr_bwd: C=%d cstride=%d", C, cstride);
@@ -268,9 +274,9 @@ extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const floa
         // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc, df1_add);
         hipLaunchKernelGGL((corr_transpose_kernel<RR>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc, (const float*)nullptr);
     });
     return check_launch("local_corr_bwd");
 }

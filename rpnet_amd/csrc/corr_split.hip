@@ -158,7 +158,8 @@ template <int R, int NP, int SIGN>
 __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float* __restrict__ g, const unsigned short* __restrict__ fos,
                                                                       float* __restrict__ df, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
-                                                                      const float inv_sqrt_c, const float* __restrict__ s_fo) {
+                                                                      const float inv_sqrt_c, const float* __restrict__ s_fo,
+                                                                      const float* __restrict__ add) {
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NCH = (NQ + 31) / 32, GS = (KK + 3) & ~3;
     constexpr int BN = 128, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
     constexpr int A_BYTES = 64 * 64, B_BYTES = 32 * RSB;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         }
     }
     float* dfb = df + (size_t)b * h * w * C;
+    const float* addb = add ? add + (size_t)b * h * w * C : nullptr;    // a second gradient of the same tensor, summed here
     const int col = n0 + wv * 32 + li;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -276,7 +278,11 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         for (int r = 0; r < 16; ++r) {
             const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
-            if (y < h && x < w) dfb[((size_t)y * w + x) * C + col] = NP <= 2 ? acc[i][r] * out_scale : acc[i][r];
+            if (y < h && x < w) {
+                const size_t o = ((size_t)y * w + x) * C + col;
+                const float v = NP <= 2 ? acc[i][r] * out_scale : acc[i][r];
+                dfb[o] = addb ? v + addb[o] : v;
+            }
         }
 }
 
@@ -312,7 +318,8 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
 
 extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, const float* dcorr, float* df1, float* df2, int B,
                                           int h, int w, int C, int r, int cstride, int planes, const float* scale1,
-                                          const float* scale2, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
+                                          const float* scale2, const float* df1_add, void* workspace, size_t workspace_bytes,
+                                          rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && dcorr && df1 && df2 && workspace, RPNET_ERR_ARG, "local_corr_split_bwd: null pointer");
     RPNET_REQUIRE(r == 5 && C % 128 == 0 && cstride >= 121 && (planes == 3 || ((planes == 2 || planes == 1) && scale1 && scale2)), RPNET_ERR_SHAPE,
@@ -328,17 +335,17 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
     const unsigned short* b2 = (const unsigned short*)f2s;
     const dim3 grid(tiles, C / 128, B);
     if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, (const float*)nullptr);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, (const float*)nullptr, df1_add);
     else if (planes == 2)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2, df1_add);
     else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2, df1_add);
     if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;
     if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, (const float*)nullptr);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, (const float*)nullptr, (const float*)nullptr);
     else if (planes == 2)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1);
+        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1, (const float*)nullptr);
     return check_launch("local_corr_split_bwd");
 }

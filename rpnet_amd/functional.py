@@ -278,7 +278,8 @@ class PackedWeight:
             t = u = None
             if planes <= 2:
                 t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
-                u = torch.ones(self.cin_pad, device=w.device, dtype=torch.float32)
+                # the kernel writes the scale of every real gathered row; only padding rows (none on the 3x3 layers) need a preset
+                u = (torch.ones if self.cin_pad != self.cin else torch.empty)(self.cin_pad, device=w.device, dtype=torch.float32)
             call("rpnet_pack_conv_weight_split", ptr(w), ptr(wps), ptr(wds), self.cout, self.cin, self.taps,
                  self.off0, self.split, self.off1, self.cin_pad, planes, ptr(t), ptr(u))
             pk = self.wps[planes] = (wps, wds) if planes == 3 else (wps, wds, t, u)
@@ -726,10 +727,14 @@ CORR_STRIDE = 128  # (2*5+1)^2 = 121 window channels padded to a GEMM-friendly 1
 
 class LocalCorr(Function):
     """Correlation(fm1, fm2, r) (net/rp_net.py:153-181), NHWC, output [B,h,w,128] (zero padded).  With the split
-    arithmetic on (and r = 5, C % 128 == 0) it runs on the bf16 matrix pipe from the split planes of fm1 / fm2."""
+    arithmetic on (and r = 5, C % 128 == 0) it runs on the bf16 matrix pipe from the split planes of fm1 / fm2.
+    Second output: an alias of fm1 for its other consumer (the 1x1 convolution over cat([corr, fm1]), net/rp_net.py:81),
+    so that both gradients of fm1 arrive in this backward and are summed by the kernel's own store instead of a
+    separate autograd add over the tensor."""
 
     @staticmethod
     def forward(ctx, f1, f2, r):
+        ctx.set_materialize_grads(False)
         B, h, w, Cc = f1.shape
         corr = _empty((B, h, w, CORR_STRIDE), f1)
         np_ = _MATH["planes"] if (r == 5 and Cc % 128 == 0) else 0
@@ -751,24 +756,27 @@ class LocalCorr(Function):
             call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
             ctx.save_for_backward(f1, f2)
         ctx.r, ctx.np_, ctx.shape = r, np_, tuple(f1.shape)
-        return corr
+        return corr, f1.view_as(f1)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dcorr):
+    def backward(ctx, dcorr, d_alias):
         f1, f2 = ctx.saved_tensors[:2]
         s1, s2 = ctx.saved_tensors[2:] if ctx.np_ in (1, 2) else (None, None)
         B, h, w, Cc = ctx.shape
+        if dcorr is None:
+            return d_alias, None, None
+        add = d_alias.contiguous() if d_alias is not None else None
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
         ws = _ws(wb, dcorr)
         ARITH[("corr_bwd", _PLANE_NAME[ctx.np_])] += 1
         if ctx.np_:
             call("rpnet_local_corr_split_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc,
-                 ctx.r, CORR_STRIDE, ctx.np_, ptr(s1), ptr(s2), ptr(ws), wb)
+                 ctx.r, CORR_STRIDE, ctx.np_, ptr(s1), ptr(s2), ptr(add), ptr(ws), wb)
         else:
             call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
-                 CORR_STRIDE, ptr(ws), wb)
+                 CORR_STRIDE, ptr(add), ptr(ws), wb)
         return df1, df2, None
 
 
@@ -813,6 +821,7 @@ class CosineMatchUp(Function):
 
     @staticmethod
     def forward(ctx, f, proto, H, W, scaler):
+        ctx.set_materialize_grads(False)      # `pred` is not differentiable: no zero tensor for it in backward
         B, h, w, Cc = f.shape
         K = proto.shape[1]
         proto = proto.contiguous()
@@ -828,6 +837,8 @@ class CosineMatchUp(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dlogits, _dpred):
+        if dlogits is None:
+            return None, None, None, None, None
         f, proto = ctx.saved_tensors
         H, W, scaler = ctx.cfg
         B, h, w, Cc = f.shape

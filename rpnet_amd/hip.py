@@ -56,9 +56,9 @@ _SIGS = {
     "rpnet_mask_avgpool": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
-    "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
     "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
-    "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, cs, vp]),
+    "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, cs, vp]),
     "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp]),
     "rpnet_sum_n": (ci, [vp, ci, vp, cs, vp]),
     "rpnet_demons_workspace_bytes": (cs, [ci, ci, ci]),

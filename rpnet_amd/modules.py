@@ -232,9 +232,9 @@ class ContextCorrelationEncoder(nn.Module):
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
-        corr = RF.LocalCorr.apply(fm1, fm2, self.radius)
+        corr, fm1b = RF.LocalCorr.apply(fm1, fm2, self.radius)     # fm1b: alias of fm1, gradient fan-in fused (RF.LocalCorr)
         kk = (2 * self.radius + 1) ** 2
-        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1, split=(kk, RF.CORR_STRIDE),
+        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.CORR_STRIDE),
                                out_split=False)
 
     def forward(self, fm1, fm2):
@@ -320,16 +320,18 @@ class RP_Net(nn.Module):
             supp_d4 = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
             qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
             s_supp, s_qry = getattr(supp_d4, "_rp_scale", None), getattr(qry_d4, "_rp_scale", None)
-        supp_d4 = supp_d4.reshape(n_ways, n_shots, B, h, w, -1)
         taps = self.taps
         if taps is not None:
-            taps["supp_d4"] = supp_d4.detach().permute(0, 1, 2, 5, 3, 4)
+            taps["supp_d4"] = supp_d4.detach().reshape(n_ways, n_shots, B, h, w, -1).permute(0, 1, 2, 5, 3, 4)
             taps["qry_d4"] = _to_nchw(qry_d4.detach())
+        # per (way, shot) views: unbind's backward is ONE stack (indexing [wa, s] would zero-fill and copy per slice)
+        per = (supp_d4.reshape(B, h, w, -1),) if ns == B else supp_d4.reshape(n_ways * n_shots, B, h, w, -1).unbind(0)
+        supp_d4 = [[per[wa * n_shots + s] for s in range(n_shots)] for wa in range(n_ways)]
 
         # ---- support relation features, per (way, shot) with that shot's own mask (:269-275)
         fore = [[m.float().contiguous() for m in way] for way in fore_mask]
         back = [[m.float().contiguous() for m in way] for way in back_mask]
-        supp_fts = [[self.cre.forward_masked(supp_d4[wa, s], RF.mask_avgpool(fore[wa][s], self.scale), cache, s_supp)
+        supp_fts = [[self.cre.forward_masked(supp_d4[wa][s], RF.mask_avgpool(fore[wa][s], self.scale), cache, s_supp)
                      for s in range(n_shots)] for wa in range(n_ways)]
 
         # ---- prototypes: constant across iterations, computed once (:288-300)
@@ -339,10 +341,13 @@ class RP_Net(nn.Module):
             for s in range(n_shots):
                 am, msum = RF.mask_adjoint(torch.stack([back[wa][s], fore[wa][s]], 0), h, w)
                 p = RF.MaskedPool.apply(supp_fts[wa][s], am, msum)          # [B,2,C]: bg, fg
-                bg_w, fg_w = bg_w + p[:, 0], fg_w + p[:, 1]
-            fg_protos.append(fg_w / n_shots)
-            bg_sum = bg_sum + bg_w / n_shots
-        protos = torch.stack([bg_sum / n_ways] + fg_protos, 1).contiguous()  # [B,1+Wa,C]
+                if n_ways * n_shots > 1:
+                    bg_w, fg_w = bg_w + p[:, 0], fg_w + p[:, 1]
+            if n_ways * n_shots > 1:
+                fg_protos.append(fg_w / n_shots)
+                bg_sum = bg_sum + bg_w / n_shots
+        # 1-way 1-shot: the means over one shot / one way are the pooled rows themselves ([bg, fg]): no slicing, no stack
+        protos = p if n_ways * n_shots == 1 else torch.stack([bg_sum / n_ways] + fg_protos, 1).contiguous()  # [B,1+Wa,C]
         if taps is not None:
             taps["supp_fts"] = [[_to_nchw(f.detach()) for f in way] for way in supp_fts]
             taps["protos"] = protos.detach()
@@ -385,7 +390,7 @@ class RP_Net(nn.Module):
         loss = 0
         for wa in range(n_ways):
             keep = (counts[:, wa + 1] > 0).float()                           # skip_ways (:414,421), per episode
-            protos = torch.stack([qp[:, 0], qp[:, wa + 1]], 1).contiguous()
+            protos = qp if n_ways == 1 else torch.stack([qp[:, 0], qp[:, wa + 1]], 1).contiguous()
             for s in range(n_shots):
                 logits, _ = RF.CosineMatchUp.apply(supp_fts[wa][s], protos, H, W, 20.0)   # :425-431
                 lab = RF.align_labels(fore_mask[wa][s], back_mask[wa][s])                 # :433-436

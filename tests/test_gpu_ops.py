@@ -140,7 +140,7 @@ def test_conv_two_sources_upsample_and_groups(RF, conv_math):
 
 @pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [(2, 32, 32, 128, 0, 128, False), (1, 16, 16, 64, 64, 256, False),
                                                    (2, 32, 64, 64, 0, 128, True), (3, 16, 48, 64, 64, 128, False), (2, 32, 32, 64, 0, 64, False), (1, 16, 32, 128, 0, 192, False)])
-@pytest.mark.parametrize("tile", ["7", "8"])
+@pytest.mark.parametrize("tile", ["7", "8", "10"])
 def test_split_halo_kernel(RF, monkeypatch, tile, N, H, W, c0, c1, cout, ups):
     """The halo-resident 256x128 variant (conv_igemm_split_halo_kernel: image patches, input halo staged once per
     channel chunk) forced on small shapes: two sources, nearest x2, both patch widths (W % 32 == 0 / W % 16 == 0),
@@ -414,14 +414,16 @@ def test_local_correlation(RF, conv_math, dims):
     ref = O.local_correlation(f1, f2, r)
     g1, g2 = torch.autograd.grad(ref, [f1, f2], go)
     a, bb = nhwc(f1.detach()).to(DEV).requires_grad_(True), nhwc(f2.detach()).to(DEV).requires_grad_(True)
-    out = RF.LocalCorr.apply(a, bb, r)
+    out, a_alias = RF.LocalCorr.apply(a, bb, r)
     assert out.shape[-1] == 128 and out[..., kk:].abs().max() == 0      # zero padded window channels
     gop = torch.zeros(b, h, w, 128)
     gop[..., :kk] = go.permute(0, 2, 3, 1)
-    out.backward(gop.to(DEV))
+    # the second output is an alias of f1 for its other consumer: its gradient is summed into df1 by the kernel's store
+    g_alias = rnd(14, b, h, w, c)
+    torch.autograd.backward([out, a_alias], [gop.to(DEV), g_alias.to(DEV)])
     tol = 1e-4
     assert rel_err(nchw(out[..., :kk]), ref) < tol
-    assert rel_err(nchw(a.grad), g1) < tol and rel_err(nchw(bb.grad), g2) < tol
+    assert rel_err(nchw(a.grad), g1 + nchw(g_alias)) < tol and rel_err(nchw(bb.grad), g2) < tol
 
 
 def test_local_correlation_f16_planes(RF):
@@ -449,7 +451,7 @@ def test_local_correlation_f16_planes(RF):
             b = RF.conv_bn_relu(xg, gb, gbb, cache, True, out_split="corr")
             if math == "f16x2":
                 assert getattr(a, "_rp_split16", None) is not None
-            out = RF.LocalCorr.apply(a, b, r)
+            out, _ = RF.LocalCorr.apply(a, b, r)
             gop = torch.zeros(N, H, W, 128)
             gop[..., :121] = go.permute(0, 2, 3, 1)
             out.backward(gop.to(DEV))
@@ -465,7 +467,7 @@ def test_local_correlation_golden(RF, golden):
     b, c, h, w, r = (int(v) for v in g["corr_r5_dims"])
     f1, f2, go = rnd(11, b, c, h, w), rnd(12, b, c, h, w), rnd(13, b, 121, h, w)
     a, bb = nhwc(f1).to(DEV).requires_grad_(True), nhwc(f2).to(DEV).requires_grad_(True)
-    out = RF.LocalCorr.apply(a, bb, r)
+    out, a_alias = RF.LocalCorr.apply(a, bb, r)
     gop = torch.zeros(b, h, w, 128)
     gop[..., :121] = go.permute(0, 2, 3, 1)
     out.backward(gop.to(DEV))

@@ -9,6 +9,10 @@ from rpnet_amd.functional import PackedWeight, _desc, split_bf16, split_f16
 from rpnet_amd.hip import call
 
 dev = "cuda:0"
+import rpnet_amd.functional as _RF
+if os.environ.get("TILE"):          # force tile variant TILE of the split forward kernels (rpnet_conv_desc.tune)
+    _RF.TUNE["tile"] = int(os.environ["TILE"]) + 1
+PLANES = tuple(int(v) for v in os.environ.get("PLANES", "0,3,2").split(","))
 
 
 def planes_of(x, planes):
@@ -17,7 +21,7 @@ def planes_of(x, planes):
     if planes == 3:
         return split_bf16(x, 3), None
     s_in = torch.tensor([2.0 ** (int(torch.ceil(torch.log2(x.abs().max())).item()) - 15)], device=dev)
-    return split_f16(x, s_in)
+    return split_f16(x, s_in, planes=planes)
 
 
 def conv(x, pw, co, planes, xs=None):
@@ -28,7 +32,7 @@ def conv(x, pw, co, planes, xs=None):
         xs = planes_of(x, planes) if xs is None else xs
         d = _desc(xs[0], None, pk[0], None, None, 0, y, None, N, H, W, 9, 0)
         d.split_planes = planes
-        if planes == 2:
+        if planes <= 2:
             d.acc_scale_col, d.acc_scale_x = pk[2].data_ptr(), xs[1].data_ptr()
         d._keep = (xs, pk)
     else:
@@ -60,7 +64,7 @@ for (N, H, W, ci, co) in SHAPES:
     pw = PackedWeight(w)
     fl = 2.0 * N * H * W * ci * co * 9
     line = f"M={N*H*W:8d} {ci:4d}->{co:4d}"
-    for planes in (0, 3, 2):
+    for planes in PLANES:
         xs = planes_of(x, planes) if planes else None
         _, d = conv(x, pw, co, planes, xs)
         for _ in range(3):

@@ -12,7 +12,7 @@ def run(fn, n=20):
     a.record()
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n
-tf = run(lambda: RF.LocalCorr.apply(f1, f2, r))
-out = RF.LocalCorr.apply(f1, f2, r)
+tf = run(lambda: RF.LocalCorr.apply(f1, f2, r)[0])
+out, _ = RF.LocalCorr.apply(f1, f2, r)
 tb = run(lambda: torch.autograd.grad(out, [f1, f2], go, retain_graph=True))
 print(f"corr fwd {tf*1e3:.1f} us  ({2*B*h*w*121*C/tf/1e9:.1f} TF)   bwd {tb*1e3:.1f} us")
