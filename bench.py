@@ -188,7 +188,7 @@ def conv_accuracy_probe(dev):
         y = torch.empty(2, 32, 32, 256, device=dev)
         if planes == 2:      # fp16 planes of x / s, s = a power of two with max|x| / s <= 2^15 (here from the data itself)
             s_in = torch.tensor([2.0 ** (int(torch.ceil(torch.log2(x.abs().max())).item()) - 15)], device=dev)
-            xs, sx = RF.split_f16(xd, s_in)
+            xs, sx = RF.split_f16(xd, s_in, planes=2)
             wps, _, t_row, _ = pw.split_packs(2)
             d = RF._desc(xs, None, wps, None, None, 0, y, None, 2, 32, 32, 9, 0)
             d.split_planes, d.acc_scale_col, d.acc_scale_x = 2, t_row.data_ptr(), sx.data_ptr()
@@ -203,6 +203,64 @@ def conv_accuracy_probe(dev):
     return out
 
 
+def eval_leg(net, cfg, dev, size, RF):
+    """The reference's only entry point is evaluation (test_rpnet.py:151-258: eval mode, no_grad, 2-slice batches, T = 10,
+    test_rpnet.py:51,164,189-215): forward-only latency of that call, and of the same call at batch 8 (where the eval-mode
+    fp16 planes pay, rpnet_amd.modules._F16_MIN_PIXELS_EVAL), with the conv launches' own roofline entry (HIP events on
+    the launch stream over one extra call)."""
+    was_training, old_T = net.training, net.num_iter
+    net.eval()
+    net.num_iter = cfg.get("n_test_iter_refinement", 10)
+    out = {"workload": f"eval mode, torch.no_grad, 1-way 1-shot {size}x{size}, T={net.num_iter} "
+                       "(test_rpnet.py:189-215 call shape), packs / folded BatchNorm rebuilt every call", "calls": []}
+    try:
+        for B in (2, 8):
+            si, fg, bg, qi, ql, appr = make_inputs(77, B, size, dev)
+            with torch.no_grad():
+                for _ in range(3):
+                    net(si, fg, bg, qi, appr_query_labels=appr)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 20
+                for _ in range(n):
+                    net(si, fg, bg, qi, appr_query_labels=appr)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / n * 1e3
+                # per-launch figures of the conv kernels of one more call
+                recs, orig = [], RF.call
+
+                def timed(name, *args):
+                    if name != "rpnet_conv_fwd":
+                        return orig(name, *args)
+                    d = args[0]._obj
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    orig(name, *args)
+                    b.record()
+                    recs.append((2.0 * d.N * d.H * d.W * (d.C0 + d.C1) * (d.Co0 + d.Co1) * d.taps, d.split_planes, a, b))
+                RF.call = timed
+                RF.reset_arith()
+                try:
+                    net(si, fg, bg, qi, appr_query_labels=appr)
+                    torch.cuda.synchronize()
+                finally:
+                    RF.call = orig
+            fl = sum(r[0] for r in recs)
+            tt = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
+            planes = max((r[1] for r in recs if r[0] > 1e9), default=0)
+            math = {0: "f32", 1: "f16", 2: "f16x2", 3: "bf16x3"}[planes]
+            peak = MATH[math][1]
+            out["calls"].append({"batch": B, "ms_per_call": round(ms, 3), "value": round(B / ms * 1e3, 1), "unit": "pairs/s (forward)",
+                                 "conv_math": math, "launches_by_arithmetic": RF.arith_counts(),
+                                 "roofline": {"bound": "mfma", "kernel": "rpnet_conv_fwd launches", "achieved": round(fl / tt / 1e12, 2),
+                                              "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / peak, 4),
+                                              "launches": len(recs), "conv_ms_per_call": round(tt * 1e3, 3)}})
+    finally:
+        net.num_iter = old_T
+        net.train(was_training)
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -213,9 +271,11 @@ def _cpu_model():
     return "unknown"
 
 
-def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps):
+def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps, threads=None):
     """One CPU leg: the oracle fwd+bwd (same loss as the GPU step) on a seed-1234 synthetic episode, one warm-up step,
-    then timed steps until the budget or `max_steps`; returns (leg dict, state of the last step)."""
+    then timed steps until the budget or `max_steps`; returns (leg dict, state of the last step).  `threads`: a list of
+    thread counts to try first (one step each) — the leg then runs with the fastest, so that the baseline is the host's
+    best, not its default (all hardware threads on operators this small is slower than a fraction of them)."""
     import statistics
     from oracle import rpnet_oracle as O
     from rpnet_amd.utils.synth import make_episode
@@ -237,6 +297,16 @@ def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps):
         last["loss"] = loss.item()
 
     one()  # warm-up
+    tried = {}
+    if threads:
+        default = torch.get_num_threads()
+        for n in threads:
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            one()
+            tried[n] = round(time.perf_counter() - t0, 3)
+        best = min(tried, key=tried.get)
+        torch.set_num_threads(best if tried[best] < 0.9 * tried.get(default, 1e9) else default)
     times, t_all = [], time.perf_counter()
     while True:
         t0 = time.perf_counter()
@@ -249,7 +319,9 @@ def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps):
            "mode": "as-written (the reference's operator sequence: all-pairs correlation + grid_sample, explicit "
                    "bilinear up-sampling in getFeatures, prototypes per iteration)" if as_written else
                    "algorithmic (local-window correlation, adjoint-mask prototypes hoisted out of the loop)",
-           "steps": len(times), "median_s_per_step": round(med, 3)}
+           "steps": len(times), "median_s_per_step": round(med, 3), "threads": torch.get_num_threads()}
+    if tried:
+        leg["s_per_step_by_threads"] = tried
     return leg, (P, last, (si, fg, bg, qi, ql, appr))
 
 
@@ -260,7 +332,10 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
     With `net` (the benched model: same seeded parameters) the as-written episode also goes through the HIP path under
     the arithmetic being benched and the two results are compared (`parity`) — the oracle in its checker role, at the
     headline image size."""
-    main_leg, (P, last, (si, fg, bg, qi, ql, appr)) = _cpu_leg(cfg, size, T, 1, True, seconds_budget, 8 if not full else 5)
+    default_threads = torch.get_num_threads()
+    cand = sorted({default_threads, max(default_threads // 4, 1), min(default_threads, 16)}, reverse=True)
+    main_leg, (P, last, (si, fg, bg, qi, ql, appr)) = _cpu_leg(cfg, size, T, 1, True, seconds_budget, 8 if not full else 5,
+                                                                 threads=cand)
     res = {"value": main_leg["value"], "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
            "nproc": os.cpu_count(), "cpu_model": _cpu_model(),
            "sample": f"{main_leg['steps']} fwd+bwd steps (median) of batch 1 at {size}x{size}, T={T}, oracle as-written mode "
@@ -287,7 +362,8 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
         extra = [(size, T, 1, False, 60.0, 5), (size, T, 8, True, 600.0, 5), (size, T, 8, False, 300.0, 5),
                  (128, 1, 1, True, 30.0, 5), (128, 1, 1, False, 30.0, 5)]
     for sz, tt, bb, aw, budget, mx in extra:
-        res["legs"].append(_cpu_leg(cfg, sz, tt, bb, aw, budget, mx)[0])
+        res["legs"].append(_cpu_leg(cfg, sz, tt, bb, aw, budget, mx)[0])      # with the thread count the main leg chose
+    torch.set_num_threads(default_threads)
     return res
 
 
@@ -448,6 +524,8 @@ def main():
         }
         if alt:
             result["alt_math"] = alt
+        if world == 1 and not args.no_cpu_baseline and args.ways == 1 and args.shots == 1:
+            result["eval"] = eval_leg(net, cfg, dev, args.size, RF)
         if world == 1 and not args.no_cpu_baseline:
             result["conv_math_error_vs_fp64"] = {k: float(f"{v:.3g}") for k, v in conv_accuracy_probe(dev).items()}
         if world == 1 and not args.no_cpu_baseline and args.shots == 1 and args.ways == 1:

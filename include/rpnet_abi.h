@@ -82,8 +82,12 @@ int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int c
  * cin, cin_off0, cin_split, cin_off1 multiples of 8; cin_pad, cout multiples of 32. */
 int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
                      rpnet_stream_t stream);
+/* *s_out = the power-of-two tensor scale for a tensor bounded by *bound (maps the bound to <= 2^15); see out_absmax */
+int rpnet_pow2_scale(const float* bound, float* s_out, rpnet_stream_t stream);
 int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
                     void* out, size_t rows, int C, int planes /* 2, or 1: plain fp16 (RPNET_CONV_MATH=f16) */,
+                    int a_is_bound /* 1: *s_a is a measured bound of |x| (rpnet_conv_desc.out_absmax), s = its power-of-two
+                                      scale; s_b must be NULL */,
                     rpnet_stream_t stream);
 int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
                                  int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
@@ -139,6 +143,10 @@ typedef struct rpnet_conv_desc {
        the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
        rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
     const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
+    float* out_absmax;                 /* optional: *out_absmax = max(*out_absmax, max |final output value|) (device scalar the
+                                          caller zeroed; an order-independent atomic max, so the result is deterministic):
+                                          the data-dependent bound from which an eval-mode BatchNorm output gets its fp16
+                                          tensor scale (rpnet_pow2_scale) — running statistics give no a-priori bound */
     int tune;                          /* 0: the library picks the tile variant.  Tuning / tests: v + 1 forces variant v of
                                           the split forward kernels (where the shape allows it); 4 in rpnet_conv_wgrad: the
                                           4-wave layout of the split weight gradient.  Carried here, not in the
@@ -168,7 +176,7 @@ int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int c
 /* first layer, Cin = 1 (net/unet.py:407 Conv1.conv.0): direct convolution */
 int rpnet_conv1_fwd(const float* x, const float* w /*[Cout][1][3][3]*/, const float* bias, float* y,
                     const float* ep_scale, const float* ep_shift, int N, int H, int W, int cout,
-                    rpnet_stream_t stream);
+                    float* out_absmax /* may be NULL; as rpnet_conv_desc.out_absmax */, rpnet_stream_t stream);
 size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cout);
 int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout,
                       void* workspace, size_t workspace_bytes, rpnet_stream_t stream);

@@ -75,6 +75,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             d.stats_partial[((size_t)tm * Cout + n0) * 2 + e] = sacc;
         }
     }
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn * WN * 32 + j * 32 + li;
@@ -103,9 +104,15 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
                     if (d.accumulate) v += *p;
                     *p = v;
                     acc[i][j][r] = v;
+                    amax = fmaxf(amax, fabsf(v));
                 }
             }
         }
+    }
+    if (d.out_absmax) {      // max |output| of the launch: one order-independent atomic per wave (values >= 0: uint order = float order)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(d.out_absmax), __float_as_uint(amax));
     }
     if (d.y_split) {
         // the output also as split-bf16 planes (the operand format of the next convolution; eval mode, where the

@@ -10,7 +10,8 @@ namespace rpnet {
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          const float* __restrict__ ep_scale,
-                                                         const float* __restrict__ ep_shift, int N, int H, int W, int Cout) {
+                                                         const float* __restrict__ ep_shift, int N, int H, int W, int Cout,
+                                                         float* __restrict__ out_absmax) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout]
     const int t = threadIdx.x;
     for (int i = t; i < 9 * Cout; i += 256) { const int co = i / 9, tap = i - co * 9; wl[tap * Cout + co] = w[i]; }
@@ -18,9 +19,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     __syncthreads();
     const int Q = Cout / 4, ppb = 256 / Q;
     const int q = t % Q, pl = t / Q;
-    if (pl >= ppb) return;
+    float amax = 0.f;
     const size_t M = (size_t)N * H * W;
-    for (size_t p = (size_t)blockIdx.x * ppb + pl; p < M; p += (size_t)gridDim.x * ppb) {
+    for (size_t p = (size_t)blockIdx.x * ppb + pl; pl < ppb && p < M; p += (size_t)gridDim.x * ppb) {
         const int ox = (int)(p % W), oy = (int)((p / W) % H);
         const size_t nb = p - (size_t)oy * W - ox;  // n*H*W
         f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[9 * Cout + q * 4]);
@@ -40,6 +41,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k] * sc[k] + sh[k], 0.f);
         }
         *reinterpret_cast<f32x4*>(y + p * Cout + q * 4) = acc;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+    }
+    if (out_absmax) {       // as rpnet_conv_desc.out_absmax
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out_absmax), __float_as_uint(amax));
     }
 }
 
@@ -97,7 +104,8 @@ constexpr int kConv1WgradBlocks = 1024;
 }  // namespace rpnet
 
 extern "C" int rpnet_conv1_fwd(const float* x, const float* w, const float* bias, float* y, const float* ep_scale,
-                               const float* ep_shift, int N, int H, int W, int cout, rpnet_stream_t stream) {
+                               const float* ep_shift, int N, int H, int W, int cout, float* out_absmax,
+                               rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && w && y, RPNET_ERR_ARG, "conv1_fwd: null pointer");
     RPNET_REQUIRE(cout % 4 == 0 && cout <= 1024 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_fwd: cout=%d", cout);
@@ -106,7 +114,7 @@ extern "C" int rpnet_conv1_fwd(const float* x, const float* w, const float* bias
     size_t nb = (M + ppb - 1) / ppb;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((int)nb), dim3(256), (size_t)10 * cout * sizeof(float), (hipStream_t)stream, x,
-                       w, bias, y, ep_scale, ep_shift, N, H, W, cout);
+                       w, bias, y, ep_scale, ep_shift, N, H, W, cout, out_absmax);
     return check_launch("conv1_fwd");
 }
 

@@ -53,8 +53,10 @@ template <int NP>
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, const float* __restrict__ mask, const int mode,
                                                          const float* __restrict__ s_a, const float* __restrict__ s_b,
                                                          float* __restrict__ s_out, unsigned short* __restrict__ out,
-                                                         const size_t n8, const int C8, const size_t plane_elems) {
-    const float sc = fmaxf(*s_a, s_b ? *s_b : 0.f);
+                                                         const size_t n8, const int C8, const size_t plane_elems,
+                                                         const int a_is_bound) {
+    // a_is_bound: *s_a is a bound of |x| (rpnet_conv_desc.out_absmax), not yet a scale
+    const float sc = a_is_bound ? pow2_scale(*s_a) : fmaxf(*s_a, s_b ? *s_b : 0.f);
     if (s_out && blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
     const float inv = 1.f / sc;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(out + p * plane_elems + i * 8) = o[p];
     }
 }
+
+__global__ void pow2_scale_kernel(const float* __restrict__ bound, float* __restrict__ s_out) { *s_out = pow2_scale(*bound); }
 
 // power-of-two row scales of the fp16 weight planes: t[cout] over (cin, tap), u[gathered cin row] over (cout, tap)
 __global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __restrict__ w, float* __restrict__ t,
@@ -905,8 +909,15 @@ extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mo
     return check_launch("split_bf16");
 }
 
+extern "C" int rpnet_pow2_scale(const float* bound, float* s_out, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(bound && s_out, RPNET_ERR_ARG, "pow2_scale: null pointer");
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, bound, s_out);
+    return check_launch("pow2_scale");
+}
+
 extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
-                               void* out, size_t rows, int C, int planes, rpnet_stream_t stream) {
+                               void* out, size_t rows, int C, int planes, int a_is_bound, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && out && s_a && (mask_mode == 0 || mask), RPNET_ERR_ARG, "split_f16: null pointer");
     RPNET_REQUIRE(C > 0 && C % 8 == 0 && mask_mode >= 0 && mask_mode <= 2 && (planes == 1 || planes == 2), RPNET_ERR_SHAPE,
@@ -916,10 +927,10 @@ extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode,
     const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
     if (planes == 2)
         hipLaunchKernelGGL(split_f16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C, a_is_bound);
     else
         hipLaunchKernelGGL(split_f16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+                           (unsigned short*)out, n8, C / 8, rows * (size_t)C, a_is_bound);
     return check_launch("split_f16");
 }
 

@@ -6,8 +6,9 @@ librpnet_hip.so through rpnet_amd.hip — there is no torch-operator fallback.
 
 The 3x3 convolutions (forward, input and weight gradients) and the local correlation run by default on split 16-bit
 operands (set_conv_math / RPNET_CONV_MATH, see _MATH below): the kernel that produces a tensor also writes it as two
-fp16 planes of tensor / scale (`x._rp_split16` = (planes, scale); scale from a rigorous bound, `x._rp_scale`) or, where
-no bound exists, as three exact bf16 planes (`x._rp_split`), which is what the next convolution's operand loads read.
+fp16 planes of tensor / scale (scale from a rigorous bound) or, where no bound exists, as three exact bf16 planes, which
+is what the next convolution's operand loads read.  Those forms travel between layers in an explicit `Operand` (the fp32
+tensor, its planes, its tensor scale) — never as attributes on tensors, which any view or reshape would drop silently.
 """
 import collections
 import ctypes as C
@@ -148,12 +149,64 @@ def _cconv(name, d, *rest):
     call(name, C.byref(d), *rest)
 
 
+# zeroed device scalars for rpnet_conv_desc.out_absmax (eval-mode f16 scales): one pool per device, handed out slot by slot,
+# re-zeroed with ONE fill at the start of every RP_Net.forward (reset_absmax_pool); a call outside a forward that runs
+# out of slots gets a fresh pool
+_ABSMAX = {}
+_ABSMAX_SLOTS = 256
+
+
+def reset_absmax_pool(device):
+    pool = _ABSMAX.get(device)
+    if pool is None or pool[1] > 0:
+        if pool is None:
+            _ABSMAX[device] = [torch.zeros(_ABSMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        else:
+            pool[0].zero_()
+            pool[1] = 0
+
+
+def _absmax_slot(device):
+    pool = _ABSMAX.get(device)
+    if pool is None or pool[1] >= _ABSMAX_SLOTS:
+        pool = _ABSMAX[device] = [torch.zeros(_ABSMAX_SLOTS, device=device, dtype=torch.float32), 0]
+    pool[1] += 1
+    return pool[0][pool[1] - 1:pool[1]]
+
+
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
 def _ws(nbytes, like):
     return torch.empty((max(int(nbytes), 16) + 7) // 8, device=like.device, dtype=torch.float64)
+
+
+class Operand:
+    """An NHWC fp32 activation together with the forms the operand loads of its consumers read:
+      x      the fp32 tensor (what autograd differentiates; pooled / concatenated / masked consumers split it themselves)
+      p16    fp16 planes [1 or 2, ...] of x / scale, written by the kernel that produced x (rpnet_bn_relu), or None
+      pbf    three exact bf16 planes [3, ...] of x, or None
+      scale  device scalar: the power-of-two tensor scale of the fp16 planes, from a rigorous bound of |x|
+             (train-mode BatchNorm: |gamma| sqrt(n) + |beta|), or None when no bound is known — then a consumer in
+             f16x2 / f16 mode runs on three bf16 planes, and the launch counters (arith_counts) show it.
+    A tensor derived from x whose values are a subset of x's (max-pool, a batch slice, an alias) keeps the bound:
+    `derive`."""
+    __slots__ = ("x", "p16", "pbf", "scale")
+
+    def __init__(self, x, p16=None, pbf=None, scale=None):
+        self.x, self.p16, self.pbf, self.scale = x, p16, pbf, scale
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+    def derive(self, x):
+        return Operand(x, scale=self.scale)
+
+
+def as_operand(t):
+    return t if (t is None or isinstance(t, Operand)) else Operand(t)
 
 
 def split_bf16(x, planes, scale=None, mode=0):
@@ -167,27 +220,25 @@ def split_bf16(x, planes, scale=None, mode=0):
     return out
 
 
-def _split_operand(x, planes, scale=None, mode=0):
-    """Split planes of a conv operand; an unscaled tensor remembers its split (skip connections and the
-    backward pass ask for it again)."""
+def _split_operand(op, planes, scale=None, mode=0):
+    """bf16 planes of a conv operand; an unmasked operand remembers its split (skip connections ask for it again)."""
     if scale is not None and mode:
-        return split_bf16(x, planes, scale, mode)
-    cached = getattr(x, "_rp_split", None)
-    if cached is not None and cached.shape[0] == planes and cached.shape[1:] == x.shape:
-        return cached
-    xs = split_bf16(x, planes)
-    x._rp_split = xs
-    return xs
+        return split_bf16(op.x, planes, scale, mode)
+    if op.pbf is not None and op.pbf.shape[0] == planes and op.pbf.shape[1:] == op.x.shape:
+        return op.pbf
+    op.pbf = split_bf16(op.x, planes)
+    return op.pbf
 
 
 def _use_split(pw, x0, x1):
-    """3x3 convolutions whose channel counts fit the split pack run on the bf16 pipe when enabled."""
+    """3x3 convolutions whose channel counts fit the split pack run on the 16-bit matrix pipe when enabled."""
     return (_MATH["planes"] and pw is not None and pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0
             and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0))
 
 
-def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None):
-    """fp16 planes of x * f(mask) / s, s = max(s_a, s_b) (device scalars) -> (planes [2 or 1, ...], s [1]) (rpnet_split_f16)"""
+def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None, a_is_bound=False):
+    """fp16 planes of x * f(mask) / s, s = max(s_a, s_b) (device scalars) -> (planes [2 or 1, ...], s [1]) (rpnet_split_f16);
+    a_is_bound: s_a is a measured bound of |x| instead (eval mode), s = its power-of-two scale"""
     hip.require_gpu(x)
     x = x.contiguous()
     planes = planes or _MATH["f16_planes"] or 2
@@ -195,34 +246,27 @@ def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None)
     s = torch.empty(1, device=x.device, dtype=torch.float32) if want_scale else None
     c = x.shape[-1]
     call("rpnet_split_f16", ptr(x), ptr(mask), mode if mask is not None else 0, ptr(s_a), ptr(s_b), ptr(s), ptr(out),
-         x.numel() // c, c, planes)
+         x.numel() // c, c, planes, 1 if a_is_bound else 0)
     return out, s
 
 
-def _f16_sources(x0, x1, in_scale, in_mode, x_scales):
+def _f16_sources(op0, op1, in_scale, in_mode):
     """fp16 operand planes of a convolution's source(s) with ONE tensor scale, or None when a source carries no
-    rigorous bound (then the caller falls back to three bf16 planes).  A BatchNorm output arrives with its planes
-    and scale (`_rp_split16`, written by rpnet_bn_relu); pooled / masked / concatenated sources are split here from
-    the fp32 tensor with the scale(s) of their producer(s) (`_rp_scale`, or handed in as x_scales)."""
-    s0 = x_scales[0] if x_scales else getattr(x0, "_rp_scale", None)
-    s1 = None
-    if x1 is not None:
-        s1 = (x_scales[1] if x_scales and len(x_scales) > 1 else None)
-        if s1 is None:
-            s1 = getattr(x1, "_rp_scale", None)
-        if s1 is None:
-            return None
-    if s0 is None:
+    rigorous bound (then the caller runs on three bf16 planes).  A BatchNorm output arrives with its planes and scale
+    (Operand.p16 / .scale, written by rpnet_bn_relu); pooled / masked / concatenated sources are split here from the
+    fp32 tensor with the scale(s) of their producer(s)."""
+    s0 = op0.scale
+    s1 = op1.scale if op1 is not None else None
+    if s0 is None or (op1 is not None and s1 is None):
         return None
     masked = in_scale is not None and in_mode
-    if x1 is None and not masked:
-        c = getattr(x0, "_rp_split16", None)
-        if c is not None and c[0].shape[1:] == x0.shape and c[0].shape[0] == _MATH["f16_planes"]:
-            return c[0], None, c[1]
-    xs0, s = split_f16(x0, s0, s1, in_scale if masked else None, in_mode if masked else 0)
-    xs1 = split_f16(x1, s0, s1, want_scale=False)[0] if x1 is not None else None
-    if x1 is None and not masked:
-        x0._rp_split16 = (xs0, s)
+    fp = _MATH["f16_planes"]
+    if op1 is None and not masked and op0.p16 is not None and op0.p16.shape[1:] == op0.x.shape and op0.p16.shape[0] == fp:
+        return op0.p16, None, s0
+    xs0, s = split_f16(op0.x, s0, s1, in_scale if masked else None, in_mode if masked else 0)
+    xs1 = split_f16(op1.x, s0, s1, want_scale=False)[0] if op1 is not None else None
+    if op1 is None and not masked:
+        op0.p16 = xs0            # s == s0: a later consumer of the same operand reuses the planes
     return xs0, xs1, s
 
 
@@ -339,8 +383,12 @@ class ConvBnRelu(Function):
 
     @staticmethod
     def forward(ctx, x0, x1, in_scale, weight, bias, gamma, beta, running_mean, running_var, nbt, pw, training,
-                groups, upsample, in_mode, out_split=True, x_scales=None):
+                groups, upsample, in_mode, out_split, ops, produced):
+        """ops = (Operand of x0, Operand of x1 or None): the planes / scales of the sources; `produced` (a dict) receives
+        the planes / scale this launch wrote for the output ("p16", "pbf", "scale") — conv_bn_relu_op builds the
+        output Operand from it."""
         hip.require_gpu(x0, weight)
+        op0, op1 = ops
         N, Hs, Ws, _ = x0.shape
         H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
         cout = weight.shape[0]
@@ -355,32 +403,53 @@ class ConvBnRelu(Function):
                 if pw is not None:
                     pw.eval_affine = aff
             scale, shift = aff
-            np_out = _MATH["planes"] if (out_split and cout % 32 == 0 and not first) else 0
+            # f16x2 / f16 in eval mode: running statistics give no a-priori bound of the output, so the launch measures
+            # one — max |z| through rpnet_conv_desc.out_absmax — and the fp16 tensor scale (and, for a direct 3x3 /
+            # correlation consumer, the planes) follow from it; an output that wants neither keeps the plain path.
+            want16 = f16_mode() and cout % 32 == 0 and bool(out_split) and (_CORR16 or out_split != "corr")
+            mx = _absmax_slot(x0.device) if want16 else None
+            np_out = _MATH["planes"] if (out_split in (True, "corr") and cout % 32 == 0 and not first and not want16) else 0
             zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
             if first:
-                call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout)
+                call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout, ptr(mx))
             elif _use_split(pw, x0, x1):
-                np_ = _MATH["planes"]
-                d = _desc(_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_),
-                          pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
-                d.split_planes = np_
-                d.y_split, d.split_out_planes = ptr(zs), np_out
+                f16 = _f16_sources(op0, op1, in_scale, in_mode) if f16_mode() else None
+                if f16 is not None:      # fp16 planes of the sources (their scales measured by their own launches)
+                    fp = _MATH["f16_planes"]
+                    wps, _, t_row, _ = pw.split_packs(fp)
+                    d = _desc(f16[0], f16[1], wps, bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
+                    d.split_planes = fp
+                    d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(f16[2])
+                    d._keep = f16
+                else:
+                    np_ = _MATH["planes"]
+                    d = _desc(_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_),
+                              pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
+                    d.split_planes = np_
+                d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)
                 _cconv("rpnet_conv_fwd", d)
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
-                d.y_split, d.split_out_planes = ptr(zs), np_out
+                d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)
                 _cconv("rpnet_conv_fwd", d)
             if zs is not None:
-                z._rp_split = zs      # written by the conv epilogue: no separate split pass in eval mode
+                produced["pbf"] = zs      # written by the conv epilogue: no separate split pass in eval mode
+            if want16:
+                if out_split in (True, "corr"):     # planes and scale from the measured bound in one launch
+                    produced["p16"], produced["scale"] = split_f16(z, mx, a_is_bound=True)
+                else:
+                    sz = torch.empty(1, device=x0.device, dtype=torch.float32)
+                    call("rpnet_pow2_scale", ptr(mx), ptr(sz))
+                    produced["scale"] = sz
             ctx.eval_mode = True
             return z
         y = _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
         fused, xs, sx = 0, None, None
         if first:
-            call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout)
+            call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout, None)
         else:
-            f16 = _f16_sources(x0, x1, in_scale, in_mode, x_scales) if (f16_mode() and _use_split(pw, x0, x1)) else None
+            f16 = _f16_sources(op0, op1, in_scale, in_mode) if (f16_mode() and _use_split(pw, x0, x1)) else None
             if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
                 xs, sx = (f16[0], f16[1]), f16[2]
                 fp = _MATH["f16_planes"]
@@ -390,7 +459,7 @@ class ConvBnRelu(Function):
                 d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(sx)
             elif _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
-                xs = (_split_operand(x0, np_, in_scale, in_mode), None if x1 is None else _split_operand(x1, np_))
+                xs = (_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_))
                 d = _desc(xs[0], xs[1], pw.split_packs(np_)[0], bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
                 d.split_planes = np_
             else:
@@ -423,11 +492,11 @@ class ConvBnRelu(Function):
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
              ptr(sz) if want16 else None, N, H * W, cout, groups)
         if want16 and np_out:
-            z._rp_split16 = (zs, sz)      # the next convolution's operand, produced here instead of by a separate pass
+            produced["p16"] = zs          # the next convolution's operand, produced here instead of by a separate pass
         elif zs is not None:
-            z._rp_split = zs
+            produced["pbf"] = zs
         if want16:
-            z._rp_scale = sz
+            produced["scale"] = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
         ctx.bias, ctx.beta, ctx.xs, ctx.sx = bias, beta, xs, sx
@@ -542,19 +611,27 @@ class ConvBnRelu(Function):
                 dx1 = g1 if need1 else None
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = None if _direct(bias) else torch.zeros_like(gamma)
-        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_relu(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
-                 out_split=True, x_scales=None):
-    """out_split: also write the output as the split planes of its consumer (when the split arithmetic is on): True = a
+def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
+                    out_split=True):
+    """Conv -> BatchNorm -> ReLU on Operands (tensors are wrapped: no planes, no bound); returns the output Operand.
+    out_split: also write the output as the operand planes of its consumer (when the split arithmetic is on): True = a
     3x3 convolution reads it as is, "corr" = the local correlation, "scale" = no planes, only the fp16 tensor scale (a
-    pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers).  x_scales: the fp16 tensor scales of the sources when they do not travel on the tensors themselves
-    (`_rp_scale` is lost by slicing / reshaping)."""
+    pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers)."""
+    op0, op1 = as_operand(x0), as_operand(x1)
     pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
-    return ConvBnRelu.apply(x0, x1, in_scale, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                            bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
-                            1 if upsample else 0, in_mode, out_split, x_scales)
+    produced = {}
+    z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
+                         bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
+                         1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
+    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"))
+
+
+def conv_bn_relu(x0, conv, bn, cache, training, **kw):
+    """single-layer convenience: the output TENSOR of conv_bn_relu_op (its planes and scale are dropped)"""
+    return conv_bn_relu_op(x0, conv, bn, cache, training, **kw).x
 
 
 class ConvRelu(Function):
@@ -570,7 +647,7 @@ class ConvRelu(Function):
         xs = None
         if _use_split(pw, x, None):
             np_ = _MATH["planes"]
-            xs = _split_operand(x, np_)
+            xs = split_bf16(x, np_)
             d = _desc(xs, None, pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, 0, ep_relu=1 if relu else 0)
             d.split_planes = np_
         else:
@@ -594,7 +671,7 @@ class ConvRelu(Function):
         call("rpnet_bias_relu_bwd", ptr(dz.contiguous()), ptr(z) if relu else None, ptr(dy), ptr(db), N * H * W, cout,
              ptr(ws), wb)
         dw = torch.empty_like(weight)
-        dys = _split_operand(dy, xs.shape[0]) if xs is not None and cout % 32 == 0 else None
+        dys = split_bf16(dy, xs.shape[0]) if xs is not None and cout % 32 == 0 else None
         if dys is not None and dilation <= 1 and pw.cin % 64 == 0 and cout % 64 == 0:
             d = _desc(xs, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0)
             d.split_planes, dyp = xs.shape[0], dys
@@ -698,9 +775,6 @@ class MaxPool2(Function):
         out = _empty((N, H // 2, W // 2, Cc), z)
         call("rpnet_maxpool2_fwd", ptr(z), ptr(out), N, H, W, Cc)
         ctx.save_for_backward(z)
-        sc = getattr(z, "_rp_scale", None)
-        if sc is not None:
-            out._rp_scale = sc            # a subset of the source's values: its fp16 tensor scale still bounds them
         return out
 
     @staticmethod
@@ -711,6 +785,12 @@ class MaxPool2(Function):
         dz = torch.empty_like(z)
         call("rpnet_maxpool2_bwd", ptr(z), ptr(dpool.contiguous()), None, ptr(dz), N, H, W, Cc)
         return dz
+
+
+def maxpool2(op):
+    """MaxPool2 on an Operand: the pooled values are a subset of the source's, so its fp16 tensor scale still bounds them"""
+    op = as_operand(op)
+    return op.derive(MaxPool2.apply(op.x))
 
 
 def mask_avgpool(mask, scale):
@@ -733,21 +813,22 @@ class LocalCorr(Function):
     separate autograd add over the tensor."""
 
     @staticmethod
-    def forward(ctx, f1, f2, r):
+    def forward(ctx, f1, f2, r, ops=None):
         ctx.set_materialize_grads(False)
         B, h, w, Cc = f1.shape
         corr = _empty((B, h, w, CORR_STRIDE), f1)
         np_ = _MATH["planes"] if (r == 5 and Cc % 128 == 0) else 0
-        c1, c2 = getattr(f1, "_rp_split16", None), getattr(f2, "_rp_split16", None)
-        if np_ and c1 is not None and c2 is not None and c1[0].shape[1:] == f1.shape and c2[0].shape[1:] == f2.shape:
+        o1, o2 = ops if ops is not None else (Operand(f1), Operand(f2))
+        if (np_ and o1.p16 is not None and o2.p16 is not None and o1.p16.shape[1:] == f1.shape
+                and o2.p16.shape[1:] == f2.shape and o1.p16.shape[0] == o2.p16.shape[0]):
             # both inputs are BatchNorm outputs that came with fp16 planes and their tensor scales
-            (f1s, s1), (f2s, s2) = c1, c2
+            (f1s, s1), (f2s, s2) = (o1.p16, o1.scale), (o2.p16, o2.scale)
             np_ = f1s.shape[0]          # 2, or 1 in "f16" mode
             ARITH[("corr", _PLANE_NAME[np_])] += 1
             call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, ptr(s1), ptr(s2))
             ctx.save_for_backward(f1s, f2s, s1, s2)
         elif np_:
-            f1s, f2s = _split_operand(f1, np_), _split_operand(f2, np_)
+            f1s, f2s = _split_operand(o1, np_), _split_operand(o2, np_)
             ARITH[("corr", _PLANE_NAME[np_])] += 1
             call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None)
             ctx.save_for_backward(f1s, f2s)
@@ -765,7 +846,7 @@ class LocalCorr(Function):
         s1, s2 = ctx.saved_tensors[2:] if ctx.np_ in (1, 2) else (None, None)
         B, h, w, Cc = ctx.shape
         if dcorr is None:
-            return d_alias, None, None
+            return d_alias, None, None, None
         add = d_alias.contiguous() if d_alias is not None else None
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
@@ -777,7 +858,13 @@ class LocalCorr(Function):
         else:
             call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
                  CORR_STRIDE, ptr(add), ptr(ws), wb)
-        return df1, df2, None
+        return df1, df2, None, None
+
+
+def local_corr(f1, f2, r):
+    """LocalCorr on Operands -> (corr tensor, alias of f1 for its other consumer)"""
+    o1, o2 = as_operand(f1), as_operand(f2)
+    return LocalCorr.apply(o1.x, o2.x, r, (o1, o2))
 
 
 # ------------------------------------------------------------------------ matcher

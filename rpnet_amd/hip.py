@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
-                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("tune", ci)]
+                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("out_absmax", vp), ("tune", ci)]
 
 
 _SIGS = {
@@ -30,14 +30,15 @@ _SIGS = {
     "rpnet_last_error_string": (C.c_char_p, []),
     "rpnet_pack_conv_weight": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_split_bf16": (ci, [vp, vp, ci, vp, cs, ci, ci, vp]),
-    "rpnet_split_f16": (ci, [vp, vp, ci, vp, vp, vp, vp, cs, ci, ci, vp]),
+    "rpnet_split_f16": (ci, [vp, vp, ci, vp, vp, vp, vp, cs, ci, ci, ci, vp]),
     "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
     "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),
-    "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "rpnet_pow2_scale": (ci, [vp, vp, vp]),
     "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),

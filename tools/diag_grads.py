@@ -22,7 +22,7 @@ from rpnet_amd import functional as RF
 net2 = build(cfg, True)
 with torch.no_grad():
     x = torch.cat([si[0][0], qi[0]], 0).reshape(2 * B, size, size, 1)
-    d4 = net2.encoder.forward_nhwc(x, RF.WeightCache(), groups=2)
+    d4 = net2.encoder.forward_nhwc(x, RF.WeightCache(), groups=2).x
     print("supp_d4", rel_err(d4[:B].permute(0,3,1,2), g["supp_d4"]), "qry_d4", rel_err(d4[B:].permute(0,3,1,2), g["qry_d4"]))
 
 params = dict(net.named_parameters())
