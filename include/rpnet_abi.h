@@ -190,7 +190,8 @@ int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  *                    unbiased variance, one update per group in group order;
  *                    num_batches_tracked (int64, may be NULL) += groups.
  *   rpnet_bn_relu    z = relu(y*scale + shift); z_split (may be NULL): also the split-bf16 planes of z
- *                    ([planes][N*HW][C], the operand format of the next convolution, see rpnet_split_bf16)
+ *                    ([planes][N*HW][C], the operand format of the next convolution, see rpnet_split_bf16);
+ *                    with z_split, z may be NULL: the fp32 form is not written (its only consumer reads the planes)
  *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups; accumulate != 0: added to what the
  *                    pointers hold, i.e. straight into the parameters' gradient buffers) and
  *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)), in fp32 (dy, may be

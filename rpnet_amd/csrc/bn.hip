@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { o[k] = fmaxf(a[k] * s4[k] + h4[k], 0.f); v[hh * 4 + k] = o[k]; }
-            reinterpret_cast<f32x4*>(z)[i * 2 + hh] = o;
+            if (z) reinterpret_cast<f32x4*>(z)[i * 2 + hh] = o;      // z == NULL: only the planes are wanted
         }
         if (NP <= 2) {
 #pragma unroll
@@ -431,7 +431,7 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
                              const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
                              rpnet_stream_t stream) {
     using namespace rpnet;
-    RPNET_REQUIRE(y && scale && shift && z, RPNET_ERR_ARG, "bn_relu: null pointer");
+    RPNET_REQUIRE(y && scale && shift && (z || z_split), RPNET_ERR_ARG, "bn_relu: null pointer");
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (z_split) {

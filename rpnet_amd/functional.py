@@ -192,10 +192,20 @@ class Operand:
              f16x2 / f16 mode runs on three bf16 planes, and the launch counters (arith_counts) show it.
     A tensor derived from x whose values are a subset of x's (max-pool, a batch slice, an alias) keeps the bound:
     `derive`."""
-    __slots__ = ("x", "p16", "pbf", "scale")
+    __slots__ = ("x", "p16", "pbf", "scale", "planes_only")
 
-    def __init__(self, x, p16=None, pbf=None, scale=None):
+    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False):
         self.x, self.p16, self.pbf, self.scale = x, p16, pbf, scale
+        # planes_only: x is a shape-only placeholder for autograd (a zero-storage expanded tensor) — its fp32 values were
+        # never written because the single consumer reads p16 (conv_bn_relu_op(z_unused=True)); reading x is an error
+        self.planes_only = planes_only
+
+    def values(self):
+        """the fp32 tensor, for a consumer that reads its VALUES"""
+        if self.planes_only:
+            raise RuntimeError("rpnet_amd: this operand exists as fp16 planes only (its producer was told that its single "
+                               "consumer is a 3x3 convolution on fp16 planes); a consumer asked for the fp32 values")
+        return self.x
 
     @property
     def shape(self):
@@ -223,10 +233,10 @@ def split_bf16(x, planes, scale=None, mode=0):
 def _split_operand(op, planes, scale=None, mode=0):
     """bf16 planes of a conv operand; an unmasked operand remembers its split (skip connections ask for it again)."""
     if scale is not None and mode:
-        return split_bf16(op.x, planes, scale, mode)
+        return split_bf16(op.values(), planes, scale, mode)
     if op.pbf is not None and op.pbf.shape[0] == planes and op.pbf.shape[1:] == op.x.shape:
         return op.pbf
-    op.pbf = split_bf16(op.x, planes)
+    op.pbf = split_bf16(op.values(), planes)
     return op.pbf
 
 
@@ -263,8 +273,8 @@ def _f16_sources(op0, op1, in_scale, in_mode):
     fp = _MATH["f16_planes"]
     if op1 is None and not masked and op0.p16 is not None and op0.p16.shape[1:] == op0.x.shape and op0.p16.shape[0] == fp:
         return op0.p16, None, s0
-    xs0, s = split_f16(op0.x, s0, s1, in_scale if masked else None, in_mode if masked else 0)
-    xs1 = split_f16(op1.x, s0, s1, want_scale=False)[0] if op1 is not None else None
+    xs0, s = split_f16(op0.values(), s0, s1, in_scale if masked else None, in_mode if masked else 0)
+    xs1 = split_f16(op1.values(), s0, s1, want_scale=False)[0] if op1 is not None else None
     if op1 is None and not masked:
         op0.p16 = xs0            # s == s0: a later consumer of the same operand reuses the planes
     return xs0, xs1, s
@@ -450,6 +460,9 @@ class ConvBnRelu(Function):
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout, None)
         else:
             f16 = _f16_sources(op0, op1, in_scale, in_mode) if (f16_mode() and _use_split(pw, x0, x1)) else None
+            if op0.planes_only and not (f16 is not None and op1 is None and in_scale is None and pw.cin % 64 == 0 and cout % 64 == 0):
+                raise RuntimeError("rpnet_amd: a planes-only operand (conv_bn_relu_op(z_unused=True)) reached a convolution "
+                                   "that cannot run forward AND weight gradient from its fp16 planes")
             if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
                 xs, sx = (f16[0], f16[1]), f16[2]
                 fp = _MATH["f16_planes"]
@@ -488,8 +501,14 @@ class ConvBnRelu(Function):
             np_out = _MATH["f16_planes"] if want16 else _MATH["planes"]
         zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out <= 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
+        if produced.get("z_unused") and want16 and np_out and out_split is True:
+            # the single consumer reads the fp16 planes: the fp32 form is never written, z is a zero-storage placeholder
+            # of the right shape for autograd
+            z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, H, W, cout)
+            produced["planes_only"] = True
         # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
-        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(z), ptr(zs), np_out, ptr(gamma), ptr(beta),
+        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
+             np_out, ptr(gamma), ptr(beta),
              ptr(sz) if want16 else None, N, H * W, cout, groups)
         if want16 and np_out:
             produced["p16"] = zs          # the next convolution's operand, produced here instead of by a separate pass
@@ -615,18 +634,21 @@ class ConvBnRelu(Function):
 
 
 def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
-                    out_split=True):
+                    out_split=True, z_unused=False):
     """Conv -> BatchNorm -> ReLU on Operands (tensors are wrapped: no planes, no bound); returns the output Operand.
     out_split: also write the output as the operand planes of its consumer (when the split arithmetic is on): True = a
     3x3 convolution reads it as is, "corr" = the local correlation, "scale" = no planes, only the fp16 tensor scale (a
-    pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers)."""
+    pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers).
+    z_unused: the caller guarantees that the ONLY consumer of the output is a 3x3 convolution that takes it as its single,
+    unmasked source (conv_block's first layer): in train mode on fp16 planes the fp32 form is then not written at all
+    (a third of the launch's bytes) and the returned Operand is `planes_only`."""
     op0, op1 = as_operand(x0), as_operand(x1)
     pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
-    produced = {}
+    produced = {"z_unused": bool(z_unused) and training and conv.weight.shape[0] % 64 == 0}
     z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
                          1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
-    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"))
+    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")))
 
 
 def conv_bn_relu(x0, conv, bn, cache, training, **kw):

@@ -59,7 +59,8 @@ class conv_block(nn.Module):
         """RF.Operand (or tensor) in, RF.Operand out; out_split: whether a 3x3 convolution reads the block's output as is
         (RF.conv_bn_relu_op)"""
         t = self.training
-        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups)
+        # the first layer's output feeds the second convolution and nothing else: on fp16 planes its fp32 form is not written
+        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=True)
         return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
