@@ -92,6 +92,14 @@ int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const floa
 int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
                                  int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
                                  float* row_scale_wd, rpnet_stream_t stream);
+/* the same for up to 24 layers in ONE launch per kernel (a training step repacks every layer's weights: 2 launches
+ * instead of 2 per layer).  `items` is a HOST array of n descriptors (device pointers inside), copied by value. */
+typedef struct rpnet_pack_item {
+    const float* w; void* wp; void* wd;        /* as rpnet_pack_conv_weight_split; wd may be NULL */
+    float* row_scale_wp; float* row_scale_wd;  /* planes 1 / 2: [cout] / [cin_pad] outputs; NULL for planes == 3 */
+    int cout, cin, taps, cin_off0, cin_split, cin_off1, cin_pad;
+} rpnet_pack_item;
+int rpnet_pack_conv_weights_split(const rpnet_pack_item* items, int n, int planes, rpnet_stream_t stream);
 
 /* ------------------------------------------------------------- conv (implicit GEMM)
  * Replaces nn.Conv2d(k=3,s=1,p=1,bias=True) / nn.Conv2d(k=1) forward and its

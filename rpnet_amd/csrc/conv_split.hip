@@ -16,6 +16,8 @@
 // the row XOR-swizzled with (row >> 2) & 3: both the 16-byte stores (4 lanes per row, rows consecutive)
 // and the b128 fragment reads (16-lane groups = 16 rows, one k-group) are bank-conflict free.
 // A fragment of the 32x32x16 MFMA = rows li, k-group 2*s + h (lane = li + 32 h): ONE ds_read_b128.
+#include <algorithm>
+
 #include "conv_epilogue.h"
 #include "split_bf16.h"
 
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 __global__ void pow2_scale_kernel(const float* __restrict__ bound, float* __restrict__ s_out) { *s_out = pow2_scale(*bound); }
 
 // power-of-two row scales of the fp16 weight planes: t[cout] over (cin, tap), u[gathered cin row] over (cout, tap)
-__global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __restrict__ w, float* __restrict__ t,
-                                                                float* __restrict__ u, int cout, int cin_w, int taps,
-                                                                int off0, int split, int off1) {
+__device__ __forceinline__ void weight_row_scale_block(const int b, const float* __restrict__ w, float* __restrict__ t,
+                                                       float* __restrict__ u, int cout, int cin_w, int taps, int off0, int split,
+                                                       int off1) {
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     float m = 0.f;
     if (b < cout) {
         const float* row = w + (size_t)b * cin_w * taps;
@@ -108,15 +110,27 @@ __global__ __launch_bounds__(256) void weight_row_scale_kernel(const float* __re
     }
 }
 
+// the weights of up to RPNET_PACK_MAX layers in ONE launch (blockIdx.y = layer): a training step repacks every layer
+constexpr int kPackMax = 24;
+struct PackItems {
+    rpnet_pack_item it[kPackMax];
+};
+
+__global__ __launch_bounds__(256) void weight_row_scale_kernel(const PackItems items) {
+    const rpnet_pack_item& q = items.it[blockIdx.y];
+    if ((int)blockIdx.x >= q.cout + q.cin) return;
+    weight_row_scale_block(blockIdx.x, q.w, q.row_scale_wp, q.row_scale_wd, q.cout, q.cin, q.taps, q.cin_off0, q.cin_split, q.cin_off1);
+}
+
 // w [Cout][cin_w][taps] -> wp [plane][tap][Cin_g/32][Cout][32] (+ wd [plane][tapflip][Cout/32][Cin_g][32])
 template <int NP>
-__global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
-                                                                 unsigned short* __restrict__ wd, int taps, int Cin_g,
-                                                                 int Cout, int cin_w, int off0, int split, int off1,
-                                                                 const float* __restrict__ t_row, const float* __restrict__ u_row) {
+__device__ __forceinline__ void pack_weight_split_block(const int bx, const int by, const float* __restrict__ w,
+                                                        unsigned short* __restrict__ wp, unsigned short* __restrict__ wd, int taps,
+                                                        int Cin_g, int Cout, int cin_w, int off0, int split, int off1,
+                                                        const float* __restrict__ t_row, const float* __restrict__ u_row) {
     __shared__ float tile[9][32][33];  // [tap][cin_l][cout_l]
     const int t = threadIdx.x;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ci0 = bx * 32, co0 = by * 32;
     const int ncin = min(32, cin_w - ci0);
     const int nel = ncin * taps;
     for (int e = t; e < 32 * nel; e += 256) {
@@ -171,6 +185,15 @@ __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __r
             }
         }
     }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(const PackItems items) {
+    const rpnet_pack_item& q = items.it[blockIdx.y];
+    const int tx = (q.cin + 31) / 32, ntiles = tx * (q.cout / 32);
+    if ((int)blockIdx.x >= ntiles) return;
+    pack_weight_split_block<NP>(blockIdx.x % tx, blockIdx.x / tx, q.w, (unsigned short*)q.wp, (unsigned short*)q.wd, q.taps, q.cin_pad,
+                                q.cout, q.cin, q.cin_off0, q.cin_split, q.cin_off1, q.row_scale_wp, q.row_scale_wd);
 }
 
 // WGM x 2 waves; wave tile (32 WM) x (32 WN); block tile BM = 32 WGM WM, BN = 64 WN.
@@ -764,9 +787,14 @@ template <int TW, int WN, int WMT = 2>
 static int launch_split_halo4(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
     const int tiles_m = M / (64 * WMT), tiles_n = Cout / (64 * WN);
     const int ntiles = tiles_m * tiles_n;
-    if (d->split_planes == 3)
-        hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
-    else if (d->split_planes == 2)
+    if (d->split_planes == 3) {
+        if constexpr (WMT == 2)
+            hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 3, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+        else {      // three planes need 89 KB of LDS per block: no second block on the CU, nothing to gain
+            set_error("conv_igemm_split_halo4: the 4-wave 256-pixel form exists for fp16 planes only");
+            return RPNET_ERR_ARG;
+        }
+    } else if (d->split_planes == 2)
         hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 2, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
     else
         hipLaunchKernelGGL((conv_igemm_split_halo4_kernel<TW, 1, WN, WMT>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
@@ -833,7 +861,9 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = d->tune - 1;
-        if (((v == 7 || v == 10) && halo_tw(d, Cout) && halo_bn(d, Cout) == 128) || ((v == 8 || v == 9) && halo4_tw(d))) return v;
+        if (((v == 7 || (v == 10 && d->split_planes <= 2)) && halo_tw(d, Cout) && halo_bn(d, Cout) == 128) ||
+            ((v == 8 || v == 9) && halo4_tw(d)))
+            return v;
         if (v >= 0 && v < 4 && (kSplitVariants[v].wn == 1 || n128)) return v;
     }
     // the halo-resident 256 x 128 kernel wins whenever its grid fills the machine (one block per CU)
@@ -934,33 +964,40 @@ extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode,
     return check_launch("split_f16");
 }
 
+extern "C" int rpnet_pack_conv_weights_split(const rpnet_pack_item* items, int n, int planes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(items && n >= 1 && n <= kPackMax, RPNET_ERR_ARG, "pack_conv_weights_split: %d items (1..%d)", n, kPackMax);
+    RPNET_REQUIRE(planes >= 1 && planes <= 3, RPNET_ERR_SHAPE, "pack_conv_weights_split: planes %d", planes);
+    PackItems pk;
+    int max_rows = 0, max_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const rpnet_pack_item& q = items[i];
+        RPNET_REQUIRE(q.w && q.wp, RPNET_ERR_ARG, "pack_conv_weights_split: null pointer (item %d)", i);
+        RPNET_REQUIRE(planes == 3 || (q.row_scale_wp && q.row_scale_wd), RPNET_ERR_ARG,
+                      "pack_conv_weights_split: fp16 planes (1 or 2) need the row scale outputs (item %d)", i);
+        RPNET_REQUIRE(q.cout % 32 == 0 && q.cin_pad % 32 == 0 && (q.taps == 9 || q.taps == 1), RPNET_ERR_SHAPE,
+                      "pack_conv_weights_split: cout %d cin_pad %d taps %d (item %d)", q.cout, q.cin_pad, q.taps, i);
+        RPNET_REQUIRE(q.cin % 8 == 0 && q.cin_off0 % 8 == 0 && q.cin_split % 8 == 0 && q.cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
+                      "pack_conv_weights_split: channel counts / offsets must be multiples of 8 (item %d)", i);
+        pk.it[i] = q;
+        max_rows = std::max(max_rows, q.cout + q.cin);
+        max_tiles = std::max(max_tiles, cdiv(q.cin, 32) * (q.cout / 32));
+    }
+    for (int i = n; i < kPackMax; ++i) pk.it[i] = items[0];
+    hipStream_t s = (hipStream_t)stream;
+    if (planes <= 2)    // row_scale_wd covers the cin_pad gathered rows; the caller presets the padding rows (any non-zero value)
+        hipLaunchKernelGGL(weight_row_scale_kernel, dim3(max_rows, n), dim3(256), 0, s, pk);
+    if (planes == 3) hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(max_tiles, n), dim3(256), 0, s, pk);
+    else if (planes == 2) hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(max_tiles, n), dim3(256), 0, s, pk);
+    else hipLaunchKernelGGL(pack_weight_split_kernel<1>, dim3(max_tiles, n), dim3(256), 0, s, pk);
+    return check_launch("pack_conv_weights_split");
+}
+
 extern "C" int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, int cin, int taps, int cin_off0,
                                             int cin_split, int cin_off1, int cin_pad, int planes, float* row_scale_wp,
                                             float* row_scale_wd, rpnet_stream_t stream) {
-    using namespace rpnet;
-    RPNET_REQUIRE(w && wp, RPNET_ERR_ARG, "pack_conv_weight_split: null pointer");
-    RPNET_REQUIRE(planes == 3 || (row_scale_wp && row_scale_wd), RPNET_ERR_ARG,
-                  "pack_conv_weight_split: fp16 planes (1 or 2) need the row scale outputs");
-    RPNET_REQUIRE(cout % 32 == 0 && cin_pad % 32 == 0 && (taps == 9 || taps == 1) && planes >= 1 && planes <= 3,
-                  RPNET_ERR_SHAPE, "pack_conv_weight_split: cout %d cin_pad %d taps %d planes %d", cout, cin_pad, taps, planes);
-    RPNET_REQUIRE(cin % 8 == 0 && cin_off0 % 8 == 0 && cin_split % 8 == 0 && cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
-                  "pack_conv_weight_split: channel counts / offsets must be multiples of 8");
-    if (planes == 3)
-        hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                           (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
-                           (const float*)nullptr, (const float*)nullptr);
-    else {
-        // row_scale_wd covers the cin_pad gathered rows; the caller presets the padding rows (any non-zero value)
-        hipLaunchKernelGGL(weight_row_scale_kernel, dim3(cout + cin), dim3(256), 0, (hipStream_t)stream, w, row_scale_wp, row_scale_wd,
-                           cout, cin, taps, cin_off0, cin_split, cin_off1);
-        if (planes == 2)
-            hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                               (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
-                               (const float*)row_scale_wp, (const float*)row_scale_wd);
-        else
-            hipLaunchKernelGGL(pack_weight_split_kernel<1>, dim3(cdiv(cin, 32), cout / 32), dim3(256), 0, (hipStream_t)stream, w,
-                               (unsigned short*)wp, (unsigned short*)wd, taps, cin_pad, cout, cin, cin_off0, cin_split, cin_off1,
-                               (const float*)row_scale_wp, (const float*)row_scale_wd);
-    }
-    return check_launch("pack_conv_weight_split");
+    rpnet_pack_item q;
+    q.w = w; q.wp = wp; q.wd = wd; q.row_scale_wp = row_scale_wp; q.row_scale_wd = row_scale_wd;
+    q.cout = cout; q.cin = cin; q.taps = taps; q.cin_off0 = cin_off0; q.cin_split = cin_split; q.cin_off1 = cin_off1; q.cin_pad = cin_pad;
+    return rpnet_pack_conv_weights_split(&q, 1, planes, stream);
 }

@@ -71,6 +71,13 @@ def set_f16_active(on):
     _MATH["f16_on"] = bool(on)
 
 
+def pack_planes():
+    """planes of the operand packs the current forward will ask for: 0 (fp32 kernels), 3 (bf16), 2 / 1 (fp16, when active)"""
+    if not _MATH["planes"]:
+        return 0
+    return _MATH["f16_planes"] if f16_mode() else _MATH["planes"]
+
+
 def set_async_wgrad(on=True):
     """Opt-in "bucket mode" of the backward pass: weight gradients are launched on a second HIP stream and
     every parameter gradient of a conv+BN layer is accumulated by the producing kernel straight into the
@@ -320,23 +327,32 @@ class PackedWeight:
     def split_packs(self, planes):
         """split packs of the same weight (rpnet_pack_conv_weight_split), made on first use: planes == 3 -> (wp, wd) bf16
         planes; planes == 2 / 1 -> (wp, wd, row scale of wp [cout], row scale of wd [cin_pad]) fp16 planes of w / row scale."""
+        pk = self.wps.get(planes) if self.wps else None
+        if pk is None:
+            w = self._weight
+            pk = self.alloc_split(planes)
+            call("rpnet_pack_conv_weight_split", ptr(w), ptr(pk[0]), ptr(pk[1]), self.cout, self.cin, self.taps,
+                 self.off0, self.split, self.off1, self.cin_pad, planes, ptr(pk[2]) if planes <= 2 else None,
+                 ptr(pk[3]) if planes <= 2 else None)
+        return pk
+
+    def alloc_split(self, planes):
+        """buffers of the split pack (registered as this layer's pack; the caller fills them)"""
         if self.wps is None:
             self.wps = {}
-        pk = self.wps.get(planes)
-        if pk is None:
-            n = self.taps * self.cin_pad * self.cout
-            mk = torch.zeros if self.cin_pad != self.cin else torch.empty
-            w = self._weight
-            dt = torch.bfloat16 if planes == 3 else torch.float16
-            wps, wds = mk((planes, n), device=w.device, dtype=dt), mk((planes, n), device=w.device, dtype=dt)
-            t = u = None
-            if planes <= 2:
-                t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
-                # the kernel writes the scale of every real gathered row; only padding rows (none on the 3x3 layers) need a preset
-                u = (torch.ones if self.cin_pad != self.cin else torch.empty)(self.cin_pad, device=w.device, dtype=torch.float32)
-            call("rpnet_pack_conv_weight_split", ptr(w), ptr(wps), ptr(wds), self.cout, self.cin, self.taps,
-                 self.off0, self.split, self.off1, self.cin_pad, planes, ptr(t), ptr(u))
-            pk = self.wps[planes] = (wps, wds) if planes == 3 else (wps, wds, t, u)
+        n = self.taps * self.cin_pad * self.cout
+        mk = torch.zeros if self.cin_pad != self.cin else torch.empty
+        w = self._weight
+        dt = torch.bfloat16 if planes == 3 else torch.float16
+        wps, wds = mk((planes, n), device=w.device, dtype=dt), mk((planes, n), device=w.device, dtype=dt)
+        if planes == 3:
+            pk = (wps, wds)
+        else:
+            t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
+            # the kernel writes the scale of every real gathered row; only padding rows (none on the 3x3 layers) need a preset
+            u = (torch.ones if self.cin_pad != self.cin else torch.empty)(self.cin_pad, device=w.device, dtype=torch.float32)
+            pk = (wps, wds, t, u)
+        self.wps[planes] = pk
         return pk
 
 
@@ -357,6 +373,24 @@ class WeightCache:
             pw = PackedWeight(weight.detach(), split)
             self._d[key] = pw
         return pw
+
+    def prepack(self, weights, planes):
+        """The split packs of many layers in ONE launch per kernel (rpnet_pack_conv_weights_split) instead of two
+        launches per layer on first use: RP_Net.forward hands in the 3x3 weights of the whole model right after
+        clearing the cache.  `planes`: 3 (bf16), 2 / 1 (fp16 planes with row scales)."""
+        pws = [self.get(w) for w in weights]
+        pws = [pw for pw in pws if pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0 and pw.cout % 32 == 0
+               and not (pw.wps and planes in pw.wps)]
+        for i in range(0, len(pws), hip.PACK_MAX):
+            chunk = pws[i:i + hip.PACK_MAX]
+            items = (hip.PackItem * len(chunk))()
+            for it, pw in zip(items, chunk):
+                bufs = pw.alloc_split(planes)
+                it.w, it.wp, it.wd = ptr(pw._weight), ptr(bufs[0]), ptr(bufs[1])
+                it.row_scale_wp, it.row_scale_wd = (ptr(bufs[2]), ptr(bufs[3])) if planes <= 2 else (None, None)
+                it.cout, it.cin, it.taps = pw.cout, pw.cin, pw.taps
+                it.cin_off0, it.cin_split, it.cin_off1, it.cin_pad = pw.off0, pw.split, pw.off1, pw.cin_pad
+            call("rpnet_pack_conv_weights_split", items, len(chunk), planes)
 
 
 # tuning / test override of the kernel variant, carried by every descriptor (rpnet_conv_desc.tune): 0 = the library's

@@ -25,6 +25,15 @@ class ConvDesc(C.Structure):
                 ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("out_absmax", vp), ("tune", ci)]
 
 
+PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
+
+
+class PackItem(C.Structure):
+    """struct rpnet_pack_item"""
+    _fields_ = [("w", vp), ("wp", vp), ("wd", vp), ("row_scale_wp", vp), ("row_scale_wd", vp), ("cout", ci), ("cin", ci),
+                ("taps", ci), ("cin_off0", ci), ("cin_split", ci), ("cin_off1", ci), ("cin_pad", ci)]
+
+
 _SIGS = {
     "rpnet_version": (ci, []),
     "rpnet_last_error_string": (C.c_char_p, []),
@@ -32,6 +41,7 @@ _SIGS = {
     "rpnet_split_bf16": (ci, [vp, vp, ci, vp, cs, ci, ci, vp]),
     "rpnet_split_f16": (ci, [vp, vp, ci, vp, vp, vp, vp, cs, ci, ci, ci, vp]),
     "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "rpnet_pack_conv_weights_split": (ci, [C.POINTER(PackItem), ci, ci, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),

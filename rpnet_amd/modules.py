@@ -18,6 +18,10 @@ from . import functional as RF
 # one-pass gradient fan-in for the feature maps with many consumers (RF.FanOut / RF.SplitRows); RPNET_FANIN=0 leaves
 # the fan-in to autograd's pairwise adds (A/B switch)
 _FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
+# A/B switches of two launch / traffic savings (both on by default): all operand packs of a forward in one launch, and
+# no fp32 output for conv_block's first layer when its consumer reads fp16 planes
+_PREPACK = os.environ.get("RPNET_PREPACK", "1") == "1"
+_ZSKIP = os.environ.get("RPNET_ZSKIP", "1") == "1"
 # f16x2 mode: encoder input pixels per call from which the fp16 planes are used (below: three bf16 planes; see
 # RF.set_f16_active).  262144 = batch 2 at 256^2, where the two arithmetics are level.
 _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
@@ -60,7 +64,7 @@ class conv_block(nn.Module):
         (RF.conv_bn_relu_op)"""
         t = self.training
         # the first layer's output feeds the second convolution and nothing else: on fp16 planes its fp32 form is not written
-        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=True)
+        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=_ZSKIP)
         return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
@@ -323,6 +327,10 @@ class RP_Net(nn.Module):
         RF.set_f16_active((ns + B) * H * W >= thr)      # f16x2 mode: fp16 planes only where they pay
         if not self.training and RF.f16_mode():
             RF.reset_absmax_pool(supp.device)                        # eval-mode fp16 scales are measured (one fill per forward)
+        planes = RF.pack_planes()
+        if _PREPACK and planes and (self.training or not self.freeze_packs):
+            # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
+            cache.prepack(self._pack_weights(), planes)
         if ns == B:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
             s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it
@@ -391,6 +399,15 @@ class RP_Net(nn.Module):
         if self.config["align"] and self.training:
             align_loss = self.alignLoss(inter, pred, supp_fts, fore, back)
         return {"output": output, "align_loss": align_loss, "refinement": refinement}
+
+    def _pack_weights(self):
+        ws = getattr(self, "_pack_list", None)
+        if ws is None:
+            enc = self.encoder
+            convs = [m for blk in (enc.Conv1, enc.Conv2, enc.Conv3, enc.Conv4, enc.Conv5, enc.Up_conv5, enc.Up_conv4)
+                     for m in (blk.conv[0], blk.conv[3])] + [enc.Up5.up[1], enc.Up4.up[1], self.cre.w_k[0], self.cre.w_q[0]]
+            ws = self._pack_list = [m.weight for m in convs if m.weight.shape[1] >= 32]
+        return ws
 
     def alignLoss(self, qry_fts, pred, supp_fts, fore_mask, back_mask):
         """net/rp_net.py:394-440, all B episodes at once; returns sum_epi(loss_epi) / B (:349).
