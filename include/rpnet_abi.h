@@ -79,7 +79,8 @@ int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int c
  * rpnet_pack_conv_weight_split: as rpnet_pack_conv_weight, into
  *   wp [planes][taps][Cin_pad/32][Cout][32]   (k = input channel, contiguous per output channel)
  *   wd [planes][taps][Cout/32][Cin_pad][32]   (dgrad: k = output channel, taps flipped); wd may be NULL.
- * cin, cin_off0, cin_split, cin_off1 multiples of 8; cin_pad, cout multiples of 32. */
+ * cin_pad, cout multiples of 32; channel ranges that are not multiples of 8 (the 377 = 121 + 256 channels of the 1x1
+ * convolution, packed as 128 + 256) take a gathering form of the kernel. */
 int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
                      rpnet_stream_t stream);
 /* *s_out = the power-of-two tensor scale for a tensor bounded by *bound (maps the bound to <= 2^15); see out_absmax */
@@ -151,6 +152,10 @@ typedef struct rpnet_conv_desc {
        the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
        rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
     const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
+    const float* acc_scale_x1;         /* optional (fp16 planes, two sources, rpnet_conv_fwd with taps == 1 and rpnet_conv_wgrad with
+                                          taps == 1 only): the tensor scale of source x1 when it differs from source x0's
+                                          (*acc_scale_x) — cat([corr, fm1]) of net/rp_net.py:81: the correlation's scale is
+                                          measured per call, fm1's comes from its BatchNorm bound.  NULL: one joint scale */
     float* out_absmax;                 /* optional: *out_absmax = max(*out_absmax, max |final output value|) (device scalar the
                                           caller zeroed; an order-independent atomic max, so the result is deterministic):
                                           the data-dependent bound from which an eval-mode BatchNorm output gets its fp16
@@ -281,7 +286,10 @@ int rpnet_local_corr_bwd(const float* f1, const float* f2, const float* dcorr, f
  * tensor scales rpnet_bn_relu wrote with the planes); the window gradients of the backward get a block-local
  * power-of-two scale from the maximum of the tile's own values. */
 int rpnet_local_corr_split_fwd(const void* f1_split, const void* f2_split, float* corr, int B, int h, int w, int C, int r,
-                               int cstride, int planes, const float* scale1, const float* scale2, rpnet_stream_t stream);
+                               int cstride, int planes, const float* scale1, const float* scale2,
+                               float* out_absmax /* may be NULL; as rpnet_conv_desc.out_absmax: the correlation's own fp16
+                                                    planes (operand of the 1x1 convolution) are scaled by this bound */,
+                               rpnet_stream_t stream);
 int rpnet_local_corr_split_bwd(const void* f1_split, const void* f2_split, const float* dcorr, float* df1, float* df2,
                                int B, int h, int w, int C, int r, int cstride, int planes, const float* scale1,
                                const float* scale2, const float* df1_add, void* workspace, size_t workspace_bytes,

@@ -123,20 +123,35 @@ __global__ __launch_bounds__(256) void weight_row_scale_kernel(const PackItems i
 }
 
 // w [Cout][cin_w][taps] -> wp [plane][tap][Cin_g/32][Cout][32] (+ wd [plane][tapflip][Cout/32][Cin_g][32])
-template <int NP>
-__device__ __forceinline__ void pack_weight_split_block(const int bx, const int by, const float* __restrict__ w,
+// GATHER: the block walks 32 PACKED rows and looks their source channel up (rows outside both ranges are zero padding) —
+// for layers whose channel ranges are not multiples of 8 (the 1x1 convolution over cat([corr(121 -> 128), fm1]));
+// otherwise it walks 32 source channels whose packed rows are contiguous in groups of 8.
+template <int NP, bool GATHER>
+__device__ __forceinline__ void pack_weight_split_block(float (*tile)[32][33], const int bx, const int by, const float* __restrict__ w,
                                                         unsigned short* __restrict__ wp, unsigned short* __restrict__ wd, int taps,
                                                         int Cin_g, int Cout, int cin_w, int off0, int split, int off1,
                                                         const float* __restrict__ t_row, const float* __restrict__ u_row) {
-    __shared__ float tile[9][32][33];  // [tap][cin_l][cout_l]
+    // tile [tap][cin_l][cout_l]
     const int t = threadIdx.x;
     const int ci0 = bx * 32, co0 = by * 32;
-    const int ncin = min(32, cin_w - ci0);
-    const int nel = ncin * taps;
-    for (int e = t; e < 32 * nel; e += 256) {
-        const int col = e / nel, r = e - col * nel;
-        const int c = r / taps, tap = r - c * taps;
-        tile[tap][c][col] = w[((size_t)(co0 + col) * cin_w + ci0) * taps + r];
+    const int ncin = GATHER ? 32 : min(32, cin_w - ci0);
+    if (GATHER) {
+        for (int e = t; e < 32 * 32 * taps; e += 256) {
+            const int col = e / (32 * taps), r = e - col * (32 * taps);
+            const int c = r / taps, tap = r - c * taps;
+            const int R = ci0 + c;
+            int src = -1;
+            if (R >= off0 && R < off0 + split) src = R - off0;
+            else if (R >= off1 && R < off1 + (cin_w - split)) src = split + (R - off1);
+            tile[tap][c][col] = src >= 0 ? w[((size_t)(co0 + col) * cin_w + src) * taps + tap] : 0.f;
+        }
+    } else {
+        const int nel = ncin * taps;
+        for (int e = t; e < 32 * nel; e += 256) {
+            const int col = e / nel, r = e - col * nel;
+            const int c = r / taps, tap = r - c * taps;
+            tile[tap][c][col] = w[((size_t)(co0 + col) * cin_w + ci0) * taps + r];
+        }
     }
     __syncthreads();
     const size_t plane = (size_t)taps * Cin_g * Cout;
@@ -145,7 +160,7 @@ __device__ __forceinline__ void pack_weight_split_block(const int bx, const int 
         const int g = e & 3, cl = (e >> 2) & 31, tap = e >> 7;
         if (g * 8 < ncin) {
             const int cin = ci0 + g * 8;
-            const int row = cin < split ? off0 + cin : off1 + (cin - split);
+            const int row = GATHER ? cin : (cin < split ? off0 + cin : off1 + (cin - split));
             float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = tile[tap][g * 8 + q][cl];
@@ -167,7 +182,7 @@ __device__ __forceinline__ void pack_weight_split_block(const int bx, const int 
             const int g = e & 3, c = (e >> 2) & 31, tap = e >> 7;
             if (c < ncin) {
                 const int cin = ci0 + c;
-                const int row = cin < split ? off0 + cin : off1 + (cin - split);
+                const int row = GATHER ? cin : (cin < split ? off0 + cin : off1 + (cin - split));
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = tile[tap][c][g * 8 + q];
@@ -187,13 +202,24 @@ __device__ __forceinline__ void pack_weight_split_block(const int bx, const int 
     }
 }
 
+// channel ranges that the 8-channel groups of the plain walk cannot express
+__host__ __device__ static inline bool pack_needs_gather(const rpnet_pack_item& q) {
+    return (q.cin % 8) || (q.cin_off0 % 8) || (q.cin_split % 8) || (q.cin_off1 % 8);
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(const PackItems items) {
+    __shared__ float tile[9][32][33];
     const rpnet_pack_item& q = items.it[blockIdx.y];
-    const int tx = (q.cin + 31) / 32, ntiles = tx * (q.cout / 32);
+    const bool gather = pack_needs_gather(q);
+    const int tx = gather ? q.cin_pad / 32 : (q.cin + 31) / 32, ntiles = tx * (q.cout / 32);
     if ((int)blockIdx.x >= ntiles) return;
-    pack_weight_split_block<NP>(blockIdx.x % tx, blockIdx.x / tx, q.w, (unsigned short*)q.wp, (unsigned short*)q.wd, q.taps, q.cin_pad,
-                                q.cout, q.cin, q.cin_off0, q.cin_split, q.cin_off1, q.row_scale_wp, q.row_scale_wd);
+    if (gather)
+        pack_weight_split_block<NP, true>(tile, blockIdx.x % tx, blockIdx.x / tx, q.w, (unsigned short*)q.wp, (unsigned short*)q.wd, q.taps,
+                                          q.cin_pad, q.cout, q.cin, q.cin_off0, q.cin_split, q.cin_off1, q.row_scale_wp, q.row_scale_wd);
+    else
+        pack_weight_split_block<NP, false>(tile, blockIdx.x % tx, blockIdx.x / tx, q.w, (unsigned short*)q.wp, (unsigned short*)q.wd, q.taps,
+                                           q.cin_pad, q.cout, q.cin, q.cin_off0, q.cin_split, q.cin_off1, q.row_scale_wp, q.row_scale_wd);
 }
 
 // WGM x 2 waves; wave tile (32 WM) x (32 WN); block tile BM = 32 WGM WM, BN = 64 WN.
@@ -357,12 +383,35 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
         }
     };
 
+    // two sources with DIFFERENT fp16 tensor scales (acc_scale_x1: the 1x1 convolution over cat([corr, fm1])): the
+    // accumulator is kept in units of the source of the tile being multiplied — an exact power-of-two rescale whenever
+    // the chunk sequence crosses from one source to the other — and ends in units of source 0 (acc_scale_x)
+    const bool two_scales = d.acc_scale_x1 != nullptr && d.C1 > 0;
+    const float r01 = two_scales ? *d.acc_scale_x / *d.acc_scale_x1 : 1.f;      // units of s0 -> units of s1
+    int cur_src = 0;
+    auto enter_tile = [&](int ks) {
+        if (!two_scales) return;
+        int c = rot + ks;
+        c -= (c / kchunks) * kchunks;
+        const int src = (c << 5) < d.C0 ? 0 : 1;
+        if (src != cur_src) {
+            const float f = src ? r01 : 1.f / r01;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+            cur_src = src;
+        }
+    };
     if (DB) {
         load_tile();
         store_tile(smem);
         if (nsteps > 1) load_tile();
         __syncthreads();
         for (int ks = 0; ks < nsteps; ++ks) {
+            enter_tile(ks);
             unsigned char* cur = smem + (ks & 1) * STAGE;
             unsigned char* nxt = smem + ((ks + 1) & 1) * STAGE;
             if (ks + 1 < nsteps) {
@@ -378,6 +427,7 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
         store_tile(smem);
         __syncthreads();
         for (int ks = 0; ks < nsteps; ++ks) {
+            enter_tile(ks);
             const bool more = ks + 1 < nsteps;
             if (more) load_tile();
             mma_slice(smem, 0);
@@ -386,6 +436,15 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
             if (more) store_tile(smem);
             __syncthreads();
         }
+    }
+    if (two_scales && cur_src) {
+        const float f = 1.f / r01;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
     }
     conv_epilogue<WM, WN, WGM>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h, smem);
 }
@@ -977,11 +1036,11 @@ extern "C" int rpnet_pack_conv_weights_split(const rpnet_pack_item* items, int n
                       "pack_conv_weights_split: fp16 planes (1 or 2) need the row scale outputs (item %d)", i);
         RPNET_REQUIRE(q.cout % 32 == 0 && q.cin_pad % 32 == 0 && (q.taps == 9 || q.taps == 1), RPNET_ERR_SHAPE,
                       "pack_conv_weights_split: cout %d cin_pad %d taps %d (item %d)", q.cout, q.cin_pad, q.taps, i);
-        RPNET_REQUIRE(q.cin % 8 == 0 && q.cin_off0 % 8 == 0 && q.cin_split % 8 == 0 && q.cin_off1 % 8 == 0, RPNET_ERR_SHAPE,
-                      "pack_conv_weights_split: channel counts / offsets must be multiples of 8 (item %d)", i);
+        RPNET_REQUIRE(q.cin_off0 + q.cin_split <= q.cin_pad && q.cin_off1 + (q.cin - q.cin_split) <= q.cin_pad, RPNET_ERR_SHAPE,
+                      "pack_conv_weights_split: channel ranges exceed cin_pad (item %d)", i);
         pk.it[i] = q;
         max_rows = std::max(max_rows, q.cout + q.cin);
-        max_tiles = std::max(max_tiles, cdiv(q.cin, 32) * (q.cout / 32));
+        max_tiles = std::max(max_tiles, (pack_needs_gather(q) ? q.cin_pad / 32 : cdiv(q.cin, 32)) * (q.cout / 32));
     }
     for (int i = n; i < kPackMax; ++i) pk.it[i] = items[0];
     hipStream_t s = (hipStream_t)stream;

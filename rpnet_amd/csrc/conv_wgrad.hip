@@ -326,7 +326,8 @@ void wgrad9_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split, in
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                             int ksplit, int taps, int Cin_g, int Cout, int cin_w,
                                                             int off0, int split, int off1, int accumulate,
-                                                            const float* __restrict__ sx, const float* __restrict__ sdy) {
+                                                            const float* __restrict__ sx, const float* __restrict__ sdy,
+                                                            const float* __restrict__ sx1 = nullptr, const int c0_rows = 0) {
     // one block = a 32 (cin) x 32 (cout) tile of ALL taps: the sums over the K splits land in LDS as
     // [tap][cin][cout] and leave as rows of 32 cin x taps contiguous floats per output channel — the
     // state_dict layout [Cout][Cin][taps] written with full lines instead of 4-byte pieces 36 bytes apart
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 }
                 for (; z < ksplit; ++z) s0 += p[(size_t)z * zstride];
                 s = (s0 + s1) + (s2 + s3);
-                if (sx) s *= *sx * *sdy;          // fp16 split operands: the two power-of-two tensor scales
+                // fp16 split operands: the two power-of-two tensor scales (gathered rows of the second source: its own scale)
+                if (sx) s *= ((sx1 && row >= c0_rows) ? *sx1 : *sx) * *sdy;
             }
             tile[tap][rr][cl] = s;
         }
@@ -442,6 +444,8 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
 // split-bf16 operands (conv_wgrad_split.hip)
 int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                       hipStream_t s);
+void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split);
+int conv_wgrad1_split(const rpnet_conv_desc* d, const void* dy, float* part, int M, int Cin, int Cout, int ks, int sps, hipStream_t s);
 
 }  // namespace rpnet
 
@@ -462,12 +466,12 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
                                 rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(d && d->x0 && workspace && (dy || dw), RPNET_ERR_ARG, "conv_wgrad: null pointer");
-    RPNET_REQUIRE((dy && dw) || (d->split_planes && d->taps == 9 && d->dilation <= 1), RPNET_ERR_ARG,
-                  "conv_wgrad: the two-phase form (dy or dw NULL) exists for the split 3x3 kernel only");
+    RPNET_REQUIRE((dy && dw) || (d->split_planes && d->dilation <= 1), RPNET_ERR_ARG,
+                  "conv_wgrad: the two-phase form (dy or dw NULL) exists for the split kernels only");
     const int Cin = d->C0 + d->C1, Cout = d->Co0 + d->Co1;
     RPNET_REQUIRE(d->taps == 9 || d->taps == 1, RPNET_ERR_ARG, "conv_wgrad: taps must be 9 or 1");
-    RPNET_REQUIRE(!d->split_planes || (d->taps == 9 && d->dilation <= 1), RPNET_ERR_ARG,
-                  "conv_wgrad: split operands are implemented for dense 3x3 taps only");
+    RPNET_REQUIRE(!d->split_planes || d->dilation <= 1, RPNET_ERR_ARG,
+                  "conv_wgrad: split operands are implemented for dense 3x3 and 1x1 taps only");
     RPNET_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, RPNET_ERR_SHAPE, "conv_wgrad: Cin %d / Cout %d not multiples of 64", Cin, Cout);
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_wgrad: too many pixels");
     const int M = d->N * d->H * d->W;
@@ -509,6 +513,25 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         if (rc9) return rc9;
         hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 9), dim3(256), 0, s, part9, dw, ks9, 9, Cin,
                            Cout, cin_w, cin_off0, cin_split, cin_off1, d->accumulate, (const float*)nullptr, (const float*)nullptr);
+        return check_launch("wgrad_reduce");
+    }
+    if (d->split_planes && d->taps == 1) {      // x0/x1 and dy are split planes: the single-tap split kernel
+        RPNET_REQUIRE(d->split_planes >= 1 && d->split_planes <= 3 && d->in_scale_mode == 0 && d->upsample == 0, RPNET_ERR_ARG,
+                      "conv_wgrad: split 1x1 operands take 1 to 3 planes, no in_scale, no upsampling");
+        RPNET_REQUIRE(d->C1 == 0 || (d->C0 % 64 == 0 && d->x1), RPNET_ERR_SHAPE, "conv_wgrad: source split %d not aligned to 64", d->C0);
+        int ks1, sps1;
+        wgrad1_split_plan(M, Cin, Cout, &ks1, &sps1);
+        const size_t need1 = (size_t)ks1 * Cin * Cout * sizeof(float);
+        RPNET_REQUIRE(workspace_bytes >= need1, RPNET_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", workspace_bytes, need1);
+        float* part1 = (float*)workspace;
+        if (dy)
+            if (int rc = conv_wgrad1_split(d, dy, part1, M, Cin, Cout, ks1, sps1, s)) return rc;
+        if (!dw) return RPNET_OK;
+        RPNET_REQUIRE(d->split_planes == 3 || (d->acc_scale_x && d->acc_scale_dy), RPNET_ERR_ARG,
+                      "conv_wgrad: fp16 planes need acc_scale_x and acc_scale_dy");
+        hipLaunchKernelGGL(wgrad_reduce_kernel, reduce_grid(cin_w, Cout, 1), dim3(256), 0, s, part1, dw, ks1, 1, Cin, Cout, cin_w,
+                           cin_off0, cin_split, cin_off1, d->accumulate, d->split_planes <= 2 ? d->acc_scale_x : nullptr,
+                           d->acc_scale_dy, d->split_planes <= 2 ? d->acc_scale_x1 : nullptr, d->C0);
         return check_launch("wgrad_reduce");
     }
     int bm, bn, ks, sps;

@@ -264,6 +264,133 @@ __global__ __launch_bounds__(KYW ? 768 : 256, 1) void conv_wgrad9_split_kernel(c
     }
 }
 
+// Single-tap form (the 1x1 convolution): dW[cin][cout] = sum_p x[p][cin] dy[p][cout] — the centre tap of the kernel above
+// without the strips, shifts and border rows.  64 x 64 tile, 4 waves (32 x 32 quadrants), two LDS stages of a 32-pixel
+// K-step; the work is 9x smaller than a 3x3 layer's, so the kernel is bound by streaming x and dy once (HBM / L2), not by
+// the matrix pipe.  Sources x0 | x1 as in the forward gather (a tile lies in one source).
+template <int NP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad1_split_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
+                                                                   float* __restrict__ partial, const int M, const int Cin,
+                                                                   const int Cout, const int tiles, const int tiles_n,
+                                                                   const int steps_per_split) {
+    constexpr int BK = 32, RS = 192;
+    constexpr int A_PLANE = BK * RS, B_PLANE = BK * RS;
+    constexpr int STAGE = NP * (A_PLANE + B_PLANE);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int z = blockIdx.x / tiles, tile = blockIdx.x - z * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int cm0 = tm * 64, n0 = tn * 64;
+
+    const unsigned short* src; int Cs, cc;
+    if (cm0 < d.C0) { src = reinterpret_cast<const unsigned short*>(d.x0); Cs = d.C0; cc = cm0; }
+    else { src = reinterpret_cast<const unsigned short*>(d.x1); Cs = d.C1; cc = cm0 - d.C0; }
+    const size_t planex = (size_t)M * Cs, planey = (size_t)M * Cout;
+    const int total_steps = (M + BK - 1) / BK;
+    const int s_begin = z * steps_per_split;
+    const int s_end = min(s_begin + steps_per_split, total_steps);
+
+    __amdgpu_buffer_rsrc_t rsx[NP], rsy[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        rsx[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src + p * planex), (short)0, (int)(planex * 2), 0x00020000);
+        rsy[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dy + p * planey), (short)0, (int)(planey * 2), 0x00020000);
+    }
+    // one 16-byte piece of the x tile and one of the dy tile per thread and plane: row t >> 3, column piece t & 7
+    const int row = t >> 3, c16 = (t & 7) * 16;
+    const int dst = row * RS + c16;
+    u32x4 ra[NP], rb[NP];
+    auto load_tile = [&](int st) {
+        const int pix = st * BK + row;             // rows past M lie beyond num_records: zeros
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ra[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx[p], pix * (Cs * 2) + c16, cc * 2, 0));
+            rb[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy[p], pix * (Cout * 2) + c16, n0 * 2, 0));
+        }
+    };
+    auto store_tile = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<u32x4*>(smem + stage + p * A_PLANE + dst) = ra[p];
+            *reinterpret_cast<u32x4*>(smem + stage + NP * A_PLANE + p * B_PLANE + dst) = rb[p];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // transposing-read geometry as in the nine-tap kernel
+    const int g = lane >> 4, L = lane & 15;
+    const int krow = 8 * (g >> 1) + (L >> 2);
+    const int a_base0 = krow * RS + (wm * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
+    const int b_base0 = NP * A_PLANE + krow * RS + (wn * 32 + 16 * (g & 1) + 4 * (L & 3)) * 2;
+    auto tr = [&](int byte_off) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + byte_off));
+    };
+    if (s_begin < s_end) {
+        load_tile(s_begin);
+        store_tile(0);
+        if (s_begin + 1 < s_end) load_tile(s_begin + 1);
+        __syncthreads();
+        for (int st = s_begin; st < s_end; ++st) {
+            const bool more = st + 1 < s_end;
+            const int cur = ((st - s_begin) & 1) * STAGE;
+            if (more) {
+                store_tile(STAGE - cur);
+                if (st + 2 < s_end) load_tile(st + 2);
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                bf16x8 af[NP], bf[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int oa = cur + a_base0 + p * A_PLANE + 16 * sl * RS;
+                    const int ob = cur + b_base0 + p * B_PLANE + 16 * sl * RS;
+                    af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(oa), tr(oa + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
+                    bf[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr(ob), tr(ob + 4 * RS), 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                constexpr int NPROD = nprod<NP>();
+#pragma unroll
+                for (int q = 0; q < NPROD; ++q) acc = mma16<NP>(af[prod_a<NP>(q)], bf[prod_b<NP>(q)], acc);
+            }
+            __syncthreads();
+        }
+    }
+    const int li = lane & 31, h = lane >> 5;
+    const int col = n0 + wn * 32 + li;
+    float* out = partial + (size_t)z * Cin * Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rw = cm0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(size_t)rw * Cout + col] = acc[r];
+    }
+}
+
+// split-K plan of the single-tap kernel: never more splits than rpnet_conv_wgrad_workspace_bytes (wgrad_plan) provides for
+void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split) {
+    const int tiles = (Cin / 64) * (Cout / 64);
+    const int total_steps = (M + 31) / 32;
+    int ks = (512 + tiles - 1) / tiles;                    // two blocks per CU
+    ks = std::max(1, std::min(ks, std::max(1, total_steps / 8)));
+    ks = std::min(ks, 32);
+    *steps_per_split = (total_steps + ks - 1) / ks;
+    *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
+}
+
+int conv_wgrad1_split(const rpnet_conv_desc* d, const void* dy, float* part, int M, int Cin, int Cout, int ks, int sps, hipStream_t s) {
+    const int tiles_n = Cout / 64, tiles = (Cin / 64) * tiles_n;
+    const unsigned short* dys = (const unsigned short*)dy;
+    if (d->split_planes == 3)
+        hipLaunchKernelGGL((conv_wgrad1_split_kernel<3>), dim3(tiles * ks), dim3(256), 0, s, *d, dys, part, M, Cin, Cout, tiles, tiles_n, sps);
+    else if (d->split_planes == 2)
+        hipLaunchKernelGGL((conv_wgrad1_split_kernel<2>), dim3(tiles * ks), dim3(256), 0, s, *d, dys, part, M, Cin, Cout, tiles, tiles_n, sps);
+    else
+        hipLaunchKernelGGL((conv_wgrad1_split_kernel<1>), dim3(tiles * ks), dim3(256), 0, s, *d, dys, part, M, Cin, Cout, tiles, tiles_n, sps);
+    return check_launch("conv_wgrad1_split");
+}
+
 static int ilog2x(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                                                                       float* __restrict__ corr, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
                                                                       const float inv_sqrt_c_in, const float* __restrict__ s1,
-                                                                      const float* __restrict__ s2) {
+                                                                      const float* __restrict__ s2, float* __restrict__ out_absmax) {
     // NP <= 2: fp16 planes of f / s with the producers' tensor scales (rpnet_bn_relu); the scores are multiplied by s1 s2
     const float inv_sqrt_c = NP <= 2 ? inv_sqrt_c_in * (*s1 * *s2) : inv_sqrt_c_in;
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NT_N = (NQ + 31) / 32, NQP = NT_N * 32;
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
     // gather the (2R+1)^2 window of every pixel out of S, half a tile (32 pixels) at a time
     float* S = reinterpret_cast<float*>(smem);          // [32][NQP]
     float* cb = corr + (size_t)b * h * w * cstride;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -148,8 +149,16 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                 const int a = o / K, c = o - a * K;
                 v = S[pl * NQP + (py + c) * HT + px + a] * inv_sqrt_c;
             }
-            if (y < h && x < w) cb[((size_t)y * w + x) * cstride + o] = v;
+            if (y < h && x < w) {
+                cb[((size_t)y * w + x) * cstride + o] = v;
+                amax = fmaxf(amax, fabsf(v));
+            }
         }
+    }
+    if (out_absmax) {      // max |corr| of the launch (as rpnet_conv_desc.out_absmax): the bound its fp16 planes are scaled by
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(out_absmax), __float_as_uint(amax));
     }
 }
 
@@ -291,7 +300,7 @@ int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, i
 }  // namespace rpnet
 
 extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, float* corr, int B, int h, int w, int C, int r,
-                                          int cstride, int planes, const float* scale1, const float* scale2,
+                                          int cstride, int planes, const float* scale1, const float* scale2, float* out_absmax,
                                           rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
@@ -306,13 +315,13 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
     const unsigned short* b2 = (const unsigned short*)f2s;
     if (planes == 3)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc,
-                           (const float*)nullptr, (const float*)nullptr);
+                           (const float*)nullptr, (const float*)nullptr, out_absmax);
     else if (planes == 2)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
-                           cstride, isc, scale1, scale2);
+                           cstride, isc, scale1, scale2, out_absmax);
     else
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 1>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
-                           cstride, isc, scale1, scale2);
+                           cstride, isc, scale1, scale2, out_absmax);
     return check_launch("local_corr_split_fwd");
 }
 

@@ -247,10 +247,19 @@ def _split_operand(op, planes, scale=None, mode=0):
     return op.pbf
 
 
+# the 1x1 convolution over cat([corr, fm1]) on split planes too (gathering weight pack, per-source fp16 scales, single-tap
+# split weight gradient); RPNET_CONV1X1_SPLIT=0 keeps it on the fp32-MFMA kernels (A/B switch)
+_CONV1X1_SPLIT = os.environ.get("RPNET_CONV1X1_SPLIT", "1") == "1"
+
+
 def _use_split(pw, x0, x1):
-    """3x3 convolutions whose channel counts fit the split pack run on the 16-bit matrix pipe when enabled."""
-    return (_MATH["planes"] and pw is not None and pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0
-            and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0))
+    """convolutions whose channel counts fit the split pack run on the 16-bit matrix pipe when enabled: the 3x3 layers
+    (channel ranges in multiples of 32) and the 1x1 layer over two sources (its 121 + 256 channels are packed as 128 + 256)"""
+    if not (_MATH["planes"] and pw is not None and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0)):
+        return False
+    if pw.taps == 9:
+        return pw.cin_pad == pw.cin and pw.cin % 32 == 0
+    return _CONV1X1_SPLIT and pw.taps == 1 and pw.cin_pad % 64 == 0 and pw.cout % 64 == 0 and x0.shape[-1] % 64 == 0
 
 
 def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None, a_is_bound=False):
@@ -267,24 +276,32 @@ def split_f16(x, s_a, s_b=None, mask=None, mode=0, want_scale=True, planes=None,
     return out, s
 
 
-def _f16_sources(op0, op1, in_scale, in_mode):
-    """fp16 operand planes of a convolution's source(s) with ONE tensor scale, or None when a source carries no
-    rigorous bound (then the caller runs on three bf16 planes).  A BatchNorm output arrives with its planes and scale
-    (Operand.p16 / .scale, written by rpnet_bn_relu); pooled / masked / concatenated sources are split here from the
-    fp32 tensor with the scale(s) of their producer(s)."""
+def _f16_sources(op0, op1, in_scale, in_mode, two_scales=False):
+    """fp16 operand planes of a convolution's source(s) -> (planes0, planes1, scale, scale1), or None when a source
+    carries no bound (then the caller runs on three bf16 planes).  scale1 is None when both sources share ONE tensor
+    scale (`scale`).  A BatchNorm output arrives with its planes and scale (Operand.p16 / .scale, written by
+    rpnet_bn_relu); pooled / masked / concatenated sources are split here from the fp32 tensor with the joint scale of
+    their producers.  two_scales: the kernel takes a scale per source (the 1x1 convolution: rpnet_conv_desc.acc_scale_x1),
+    so two sources that both arrive with planes are used as they are."""
     s0 = op0.scale
     s1 = op1.scale if op1 is not None else None
     if s0 is None or (op1 is not None and s1 is None):
         return None
     masked = in_scale is not None and in_mode
     fp = _MATH["f16_planes"]
-    if op1 is None and not masked and op0.p16 is not None and op0.p16.shape[1:] == op0.x.shape and op0.p16.shape[0] == fp:
-        return op0.p16, None, s0
+
+    def ready(op):
+        return op.p16 is not None and op.p16.shape[1:] == op.x.shape and op.p16.shape[0] == fp
+
+    if op1 is None and not masked and ready(op0):
+        return op0.p16, None, s0, None
+    if two_scales and op1 is not None and not masked and ready(op0) and ready(op1):
+        return op0.p16, op1.p16, s0, s1
     xs0, s = split_f16(op0.values(), s0, s1, in_scale if masked else None, in_mode if masked else 0)
     xs1 = split_f16(op1.values(), s0, s1, want_scale=False)[0] if op1 is not None else None
     if op1 is None and not masked:
         op0.p16 = xs0            # s == s0: a later consumer of the same operand reuses the planes
-    return xs0, xs1, s
+    return xs0, xs1, s, None
 
 
 # ------------------------------------------------------------------ weight packing
@@ -457,13 +474,13 @@ class ConvBnRelu(Function):
             if first:
                 call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout, ptr(mx))
             elif _use_split(pw, x0, x1):
-                f16 = _f16_sources(op0, op1, in_scale, in_mode) if f16_mode() else None
+                f16 = _f16_sources(op0, op1, in_scale, in_mode, pw.taps == 1) if f16_mode() else None
                 if f16 is not None:      # fp16 planes of the sources (their scales measured by their own launches)
                     fp = _MATH["f16_planes"]
                     wps, _, t_row, _ = pw.split_packs(fp)
                     d = _desc(f16[0], f16[1], wps, bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                     d.split_planes = fp
-                    d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(f16[2])
+                    d.acc_scale_col, d.acc_scale_x, d.acc_scale_x1 = ptr(t_row), ptr(f16[2]), ptr(f16[3])
                     d._keep = f16
                 else:
                     np_ = _MATH["planes"]
@@ -489,21 +506,21 @@ class ConvBnRelu(Function):
             return z
         y = _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
-        fused, xs, sx = 0, None, None
+        fused, xs, sx, sx1 = 0, None, None, None
         if first:
             call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout, None)
         else:
-            f16 = _f16_sources(op0, op1, in_scale, in_mode) if (f16_mode() and _use_split(pw, x0, x1)) else None
+            f16 = _f16_sources(op0, op1, in_scale, in_mode, pw.taps == 1) if (f16_mode() and _use_split(pw, x0, x1)) else None
             if op0.planes_only and not (f16 is not None and op1 is None and in_scale is None and pw.cin % 64 == 0 and cout % 64 == 0):
                 raise RuntimeError("rpnet_amd: a planes-only operand (conv_bn_relu_op(z_unused=True)) reached a convolution "
                                    "that cannot run forward AND weight gradient from its fp16 planes")
             if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
-                xs, sx = (f16[0], f16[1]), f16[2]
+                xs, sx, sx1 = (f16[0], f16[1]), f16[2], f16[3]
                 fp = _MATH["f16_planes"]
                 wps, _, t_row, _ = pw.split_packs(fp)
                 d = _desc(xs[0], xs[1], wps, bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
                 d.split_planes = fp
-                d.acc_scale_col, d.acc_scale_x = ptr(t_row), ptr(sx)
+                d.acc_scale_col, d.acc_scale_x, d.acc_scale_x1 = ptr(t_row), ptr(sx), ptr(sx1)
             elif _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
                 xs = (_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_))
@@ -552,7 +569,7 @@ class ConvBnRelu(Function):
             produced["scale"] = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
-        ctx.bias, ctx.beta, ctx.xs, ctx.sx = bias, beta, xs, sx
+        ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
         return z
 
     @staticmethod
@@ -572,7 +589,7 @@ class ConvBnRelu(Function):
         # which forms of dy the two consumers (wgrad, dgrad) want: split-bf16 planes and / or fp32
         np_ = ctx.xs[0].shape[0] if ctx.xs is not None else 0
         need_d = not first and (ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]))
-        wsplit = bool(np_) and pw.cin % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
+        wsplit = bool(np_) and pw.cin_pad % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
         dsplit = bool(np_) and cout % 32 == 0 and need_d
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
         sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ <= 2) else None   # fp16: tensor scale
@@ -596,7 +613,7 @@ class ConvBnRelu(Function):
                           co_split=(cout, 0))
                 d.split_planes = np_
                 if np_ <= 2:
-                    d.acc_scale_x, d.acc_scale_dy = ptr(ctx.sx), ptr(sdy)
+                    d.acc_scale_x, d.acc_scale_dy, d.acc_scale_x1 = ptr(ctx.sx), ptr(sdy), ptr(ctx.sx1)
             else:
                 dyp = dy
                 d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
@@ -612,7 +629,7 @@ class ConvBnRelu(Function):
                         _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
                         red = _reduce_stream(dev)
                         red.wait_stream(side)
-                        for tns in (ws2, ctx.sx, sdy):           # read by the reduce (partials, the two operand scales)
+                        for tns in (ws2, ctx.sx, ctx.sx1, sdy):           # read by the reduce (partials, the operand scales)
                             if tns is not None:
                                 tns.record_stream(red)
                         with torch.cuda.stream(red):
@@ -621,7 +638,7 @@ class ConvBnRelu(Function):
                     else:
                         _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                              ptr(ws2), wb)
-                for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
+                for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
                     if tns is not None:
                         tns.record_stream(side)
                 if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
@@ -869,7 +886,9 @@ class LocalCorr(Function):
     separate autograd add over the tensor."""
 
     @staticmethod
-    def forward(ctx, f1, f2, r, ops=None):
+    def forward(ctx, f1, f2, r, ops=None, produced=None):
+        """produced (a dict, optional): receives the correlation's own fp16 planes and measured scale ("p16", "scale") when
+        its consumer (the 1x1 convolution) reads planes"""
         ctx.set_materialize_grads(False)
         B, h, w, Cc = f1.shape
         corr = _empty((B, h, w, CORR_STRIDE), f1)
@@ -881,12 +900,17 @@ class LocalCorr(Function):
             (f1s, s1), (f2s, s2) = (o1.p16, o1.scale), (o2.p16, o2.scale)
             np_ = f1s.shape[0]          # 2, or 1 in "f16" mode
             ARITH[("corr", _PLANE_NAME[np_])] += 1
-            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, ptr(s1), ptr(s2))
+            # the correlation has no a-priori bound: the launch measures max |corr|, its planes are scaled by that
+            mx = _absmax_slot(f1.device) if (produced is not None and _CONV1X1_SPLIT) else None
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, ptr(s1), ptr(s2),
+                 ptr(mx))
+            if mx is not None:
+                produced["p16"], produced["scale"] = split_f16(corr, mx, planes=np_, a_is_bound=True)
             ctx.save_for_backward(f1s, f2s, s1, s2)
         elif np_:
             f1s, f2s = _split_operand(o1, np_), _split_operand(o2, np_)
             ARITH[("corr", _PLANE_NAME[np_])] += 1
-            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None)
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None, None)
             ctx.save_for_backward(f1s, f2s)
         else:
             ARITH[("corr", "f32")] += 1
@@ -902,7 +926,7 @@ class LocalCorr(Function):
         s1, s2 = ctx.saved_tensors[2:] if ctx.np_ in (1, 2) else (None, None)
         B, h, w, Cc = ctx.shape
         if dcorr is None:
-            return d_alias, None, None, None
+            return d_alias, None, None, None, None
         add = d_alias.contiguous() if d_alias is not None else None
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
@@ -914,13 +938,16 @@ class LocalCorr(Function):
         else:
             call("rpnet_local_corr_bwd", ptr(f1), ptr(f2), ptr(dcorr.contiguous()), ptr(df1), ptr(df2), B, h, w, Cc, ctx.r,
                  CORR_STRIDE, ptr(add), ptr(ws), wb)
-        return df1, df2, None, None
+        return df1, df2, None, None, None
 
 
 def local_corr(f1, f2, r):
-    """LocalCorr on Operands -> (corr tensor, alias of f1 for its other consumer)"""
+    """LocalCorr on Operands -> (Operand of corr, Operand of the alias of f1 for its other consumer): the correlation with
+    its measured fp16 planes (when it ran on fp16 planes), the alias with f1's own planes and scale"""
     o1, o2 = as_operand(f1), as_operand(f2)
-    return LocalCorr.apply(o1.x, o2.x, r, (o1, o2))
+    produced = {}
+    corr, alias = LocalCorr.apply(o1.x, o2.x, r, (o1, o2), produced)
+    return Operand(corr, produced.get("p16"), None, produced.get("scale")), Operand(alias, o1.p16, o1.pbf, o1.scale)
 
 
 # ------------------------------------------------------------------------ matcher

@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
-                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("out_absmax", vp), ("tune", ci)]
+                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci)]
 
 
 PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
@@ -68,7 +68,7 @@ _SIGS = {
     "rpnet_local_corr_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
-    "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, cs, vp]),
     "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp]),
     "rpnet_sum_n": (ci, [vp, ci, vp, cs, vp]),

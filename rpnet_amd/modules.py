@@ -325,8 +325,8 @@ class RP_Net(nn.Module):
         ns = supp.shape[0]
         thr = _F16_MIN_PIXELS if (self.training or not _F16_MIN_PIXELS_EVAL or not _F16_MIN_PIXELS) else _F16_MIN_PIXELS_EVAL
         RF.set_f16_active((ns + B) * H * W >= thr)      # f16x2 mode: fp16 planes only where they pay
-        if not self.training and RF.f16_mode():
-            RF.reset_absmax_pool(supp.device)                        # eval-mode fp16 scales are measured (one fill per forward)
+        if RF.f16_mode():
+            RF.reset_absmax_pool(supp.device)       # measured fp16 scales (eval-mode layers, the correlation): one fill per forward
         planes = RF.pack_planes()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer

@@ -451,7 +451,7 @@ def test_local_correlation_f16_planes(RF):
             b = RF.conv_bn_relu_op(xg, gb, gbb, cache, True, out_split="corr")
             if math == "f16x2":
                 assert a.p16 is not None and a.scale is not None
-            out, _ = RF.local_corr(a, b, r)
+            out = RF.local_corr(a, b, r)[0].x
             gop = torch.zeros(N, H, W, 128)
             gop[..., :121] = go.permute(0, 2, 3, 1)
             out.backward(gop.to(DEV))
@@ -591,3 +591,48 @@ def test_maxpool3(RF, stride):
     out.backward(nhwc(go).to(DEV))
     assert torch.equal(nchw(out).cpu(), ref.detach())
     assert rel_err(nchw(xg.grad), xr.grad) < 1e-6
+
+
+def test_conv1x1_over_corr_and_features(RF, conv_math):
+    """cre.q (net/rp_net.py:65-69,81): 1x1 convolution over cat([corr (121 channels, stored as 128), fm1 (256)]) + BatchNorm
+    + ReLU, on the split path (gathering weight pack of the 377 = 121 + 256 input channels, a tensor scale per source,
+    single-tap split weight gradient) and on the fp32 kernels: output, both input gradients and the weight gradient against
+    torch; fm1 arrives as a BatchNorm output with planes, the correlation measures its own scale."""
+    import copy
+    N, H, W, C, r = 2, 16, 24, 256, 5
+    kk = (2 * r + 1) ** 2
+    ca, ba = _mk_layer(C, C, 3, 81)
+    cb, bb_ = _mk_layer(C, C, 3, 82)
+    cq, bq = _mk_layer(kk + C, 64, 1, 83)
+    x = rnd(84, N, C, H, W)
+    go = rnd(85, N, 64, H, W)
+    # torch reference (fp64): two conv-BN-ReLU branches, local correlation, 1x1 conv over the concatenation
+    from oracle import rpnet_oracle as O
+    ref_mods = [copy.deepcopy(m).double() for m in (ca, ba, cb, bb_, cq, bq)]
+    xr = x.double().requires_grad_(True)
+    f1 = torch.relu(ref_mods[1].train()(ref_mods[0](xr)))
+    f2 = torch.relu(ref_mods[3].train()(ref_mods[2](xr)))
+    corr = O.local_correlation(f1, f2, r)
+    zr = torch.relu(ref_mods[5].train()(ref_mods[4](torch.cat([corr, f1], 1))))
+    zr.backward(go.double())
+    mods = [m.to(DEV) for m in (ca, ba, cb, bb_, cq, bq)]
+    for m in mods[1::2]:
+        m.train()
+    cache = RF.WeightCache()
+    xg = nhwc(x).to(DEV).requires_grad_(True)
+    RF.reset_arith()
+    a = RF.conv_bn_relu_op(xg, mods[0], mods[1], cache, True, out_split="corr")
+    b = RF.conv_bn_relu_op(xg, mods[2], mods[3], cache, True, out_split="corr")
+    co, a2 = RF.local_corr(a, b, r)
+    z = RF.conv_bn_relu(co, mods[4], mods[5], cache, True, x1=a2, split=(kk, RF.CORR_STRIDE), out_split=False)
+    z.backward(nhwc(go).to(DEV))
+    counts = RF.arith_counts()
+    # a raw input tensor carries no bound, so under f16x2 the two 3x3 layers run on bf16 planes; the 1x1 layer takes what its
+    # sources carry: fp16 planes (BatchNorm output + measured correlation) under f16x2, bf16 planes under bf16x3
+    want = {"f32": "f32", "bf16x3": "bf16x3", "f16x2": "f16x2"}[conv_math]
+    assert set(counts["conv1x1"]) == {want} and set(counts["wgrad1x1"]) == {want}, counts
+    tol = 1e-4
+    assert rel_err(nchw(z), zr) < tol
+    assert rel_err(nchw(xg.grad), xr.grad) < 5e-4
+    assert rel_err(mods[4].weight.grad, ref_mods[4].weight.grad) < 5e-4
+    assert rel_err(mods[5].weight.grad, ref_mods[5].weight.grad) < 5e-4 and rel_err(mods[0].weight.grad, ref_mods[0].weight.grad) < 5e-4
