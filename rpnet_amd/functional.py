@@ -412,7 +412,7 @@ class WeightCache:
 
 # tuning / test override of the kernel variant, carried by every descriptor (rpnet_conv_desc.tune): 0 = the library's
 # choice, v + 1 = tile variant v of the split forward kernels, 4 (weight gradient) = the 4-wave layout
-TUNE = {"tile": 0}
+TUNE = {"tile": 0, "wgrad": int(os.environ.get("RPNET_TUNE_WGRAD", "0"))}
 
 
 def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups=1, ep_scale=None, ep_shift=None,
@@ -611,7 +611,7 @@ class ConvBnRelu(Function):
                 dyp = dys
                 d = _desc(ctx.xs[0], ctx.xs[1], None, None, None, 0, None, None, N, H, W, pw.taps, upsample,
                           co_split=(cout, 0))
-                d.split_planes = np_
+                d.split_planes, d.tune = np_, TUNE["wgrad"]
                 if np_ <= 2:
                     d.acc_scale_x, d.acc_scale_dy, d.acc_scale_x1 = ptr(ctx.sx), ptr(sdy), ptr(ctx.sx1)
             else:
