@@ -7,8 +7,9 @@ blank line, then the payload (`encoding`: raw, gzip / gz, bzip2 / bz2, ascii / t
 `line skip`; attached payload or a single detached `data file`).  Like pynrrd's default (index_order='F') the array
 comes back with `shape == sizes`, i.e. the FIRST header axis is the fastest one in the file, and the header as a dict
 (`sizes` an int array, `type`, `dimension`, `encoding`, `endian`, every other field as its string; `key:=value`
-pairs as strings).  Parity with pynrrd itself is unpinned (the package is absent); the tests hold the reader to
-hand-built files and to round trips through `write`.
+pairs as strings).  Parity with pynrrd itself is unpinned (the package is absent); the tests hold the reader to files
+written by an independent path (hand-written headers + numpy / gzip / bz2 payloads, both byte orders, attached and
+detached), the writer to an independent parser, and both to round trips.
 """
 import bz2
 import gzip

@@ -206,3 +206,50 @@ def test_reg_reader_item_vs_reference(golden, tmp_path, tag):
             flips = (got.numpy().astype(np.uint8) != g[p + key]).mean()
             assert flips < 0.01, (tag, idx, key, flips)
         assert tuple(it["original_support_images"][0][0].shape) == tuple(g[p + "orig_support_images_shape"])
+
+
+@pytest.mark.parametrize("dt", ["int16", "float32", "uint8"])
+@pytest.mark.parametrize("endian", ["little", "big"])
+@pytest.mark.parametrize("enc", ["raw", "gzip", "bzip2"])
+@pytest.mark.parametrize("detached", [False, True])
+def test_nrrd_read_against_independent_writer(tmp_path, dt, endian, enc, detached):
+    """The reader against files produced WITHOUT this module: header lines written by hand per the published format
+    (teem.sourceforge.net/nrrd/format.html), payload = numpy bytes of a 3-D volume in file order (first header axis
+    fastest), byte-swapped for `endian: big`, compressed by Python's own gzip / bz2, attached or in a detached data file."""
+    import bz2
+    import gzip
+    rs = np.random.RandomState(hash((dt, endian, enc, detached)) % (2 ** 31))
+    a = (rs.randn(5, 4, 3) * 100).astype(dt)                    # shape == sizes: axis 0 fastest in the file
+    names = {"int16": "short", "float32": "float", "uint8": "unsigned char"}
+    wire = a.astype(np.dtype(dt).newbyteorder(">" if endian == "big" else "<")).tobytes(order="F")
+    payload = {"raw": wire, "gzip": gzip.compress(wire), "bzip2": bz2.compress(wire)}[enc]
+    hdr = (f"NRRD0004\n# written by the test, not by rpnet_amd.utils.nrrd\ntype: {names[dt]}\ndimension: 3\nsizes: 5 4 3\n"
+           f"endian: {endian}\nencoding: {enc}\nspace: left-posterior-superior\nmodality:=CT\n")
+    if detached:
+        (tmp_path / "v.raw").write_bytes(payload)
+        (tmp_path / "v.nhdr").write_bytes((hdr + "data file: v.raw\n").encode("ascii"))
+        got, h = nrrd.read(str(tmp_path / "v.nhdr"))
+    else:
+        (tmp_path / "v.nrrd").write_bytes((hdr + "\n").encode("ascii") + payload)
+        got, h = nrrd.read(str(tmp_path / "v.nrrd"))
+    assert got.shape == (5, 4, 3) and got.dtype == np.dtype(dt) and np.array_equal(got, a)
+    assert list(h["sizes"]) == [5, 4, 3] and h["space"] == "left-posterior-superior" and h["modality"] == "CT"
+
+
+@pytest.mark.parametrize("enc", ["raw", "gzip"])
+def test_nrrd_write_against_independent_parser(tmp_path, enc):
+    """The writer against a parser that shares nothing with the reader: split at the first blank line, read the fields
+    with str methods, decode the payload with zlib / numpy."""
+    import zlib
+    a = (np.arange(2 * 3 * 4).reshape(2, 3, 4) - 7).astype(np.int16)
+    p = tmp_path / "w.nrrd"
+    nrrd.write(str(p), a, encoding=enc)
+    blob = p.read_bytes()
+    head, _, payload = blob.partition(b"\n\n")
+    lines = head.decode("ascii").split("\n")
+    assert lines[0].startswith("NRRD000")
+    f = dict(ln.split(": ", 1) for ln in lines[1:] if ": " in ln and not ln.startswith("#"))
+    assert f["dimension"] == "3" and f["sizes"].split() == ["2", "3", "4"] and f["type"] in ("short", "int16")
+    raw = payload if enc == "raw" else zlib.decompress(payload, 16 + zlib.MAX_WBITS)
+    got = np.frombuffer(raw, dtype="<i2" if f["endian"] == "little" else ">i2").reshape((2, 3, 4), order="F")
+    assert np.array_equal(got, a)
