@@ -65,12 +65,25 @@ def up_conv(P, name, x, training):
     return conv_bn_relu(P, name + ".up.1", name + ".up.2", x, training)
 
 
-def unet_d4(P, x, training, prefix="encoder"):
-    """U_Net.forward with mask_feature_map == False (net/unet.py:435-467)."""
+def unet_d4(P, x, training, prefix="encoder", mask=None, mask_feature_map=False):
+    """U_Net.forward (net/unet.py:435-467).  mask_feature_map 'x' / 'x2' / 'x3' (:437-449): the mask [N,1,H,W] is concatenated
+    as one more input channel of Conv1 / Conv2 (average-pooled by 2) / Conv3 (by 4); False / 'no': the mask is ignored."""
     e = prefix + "."
+    if mask_feature_map == "x":
+        x = torch.cat([x, mask], 1)                                                  # :437-438
     x1 = conv_block(P, e + "Conv1", x, training)
-    x2 = conv_block(P, e + "Conv2", F.max_pool2d(x1, 2, 2), training)
-    x3 = conv_block(P, e + "Conv3", F.max_pool2d(x2, 2, 2), training)
+    x2 = F.max_pool2d(x1, 2, 2)
+    if mask_feature_map == "x2":
+        x2 = torch.cat([x2, F.avg_pool2d(mask, 2)], 1)                               # :443-444
+    x2 = conv_block(P, e + "Conv2", x2, training)
+    x3 = F.max_pool2d(x2, 2, 2)
+    if mask_feature_map == "x3":
+        x3 = torch.cat([x3, F.avg_pool2d(mask, 4)], 1)                               # :448-449
+    x3 = conv_block(P, e + "Conv3", x3, training)
+    return _unet_tail(P, e, x3, training)
+
+
+def _unet_tail(P, e, x3, training):
     x4 = conv_block(P, e + "Conv4", F.max_pool2d(x3, 2, 2), training)
     x5 = conv_block(P, e + "Conv5", F.max_pool2d(x4, 2, 2), training)
     d5 = up_conv(P, e + "Up5", x5, training)
@@ -260,10 +273,12 @@ def rp_net_forward(P, cfg, supp_imgs, fore_mask, back_mask, qry_imgs, appr_query
     taps = taps if taps is not None else {}
 
     imgs = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0)          # :245
-    supp_d4 = unet_d4(P, imgs, training)                                   # :248-249
+    mfm = cfg.get("mask_feature_map", False)
+    enc_mask = fore_mask[0][0].unsqueeze(1)                                # both encoder calls get the SUPPORT mask (:248,257)
+    supp_d4 = unet_d4(P, imgs, training, mask=enc_mask, mask_feature_map=mfm)           # :248-249
     hw = supp_d4.shape[-2:]
     supp_d4 = supp_d4.view(n_ways, n_shots, B, -1, *hw)                    # :252
-    qry_d4 = unet_d4(P, torch.cat(qry_imgs, 0), training)                  # :254-258
+    qry_d4 = unet_d4(P, torch.cat(qry_imgs, 0), training, mask=enc_mask, mask_feature_map=mfm)   # :254-258
     qry_fts = qry_d4.view(len(qry_imgs), B, -1, *hw)
     taps["supp_d4"], taps["qry_d4"] = supp_d4, qry_d4
 
@@ -352,9 +367,10 @@ def total_loss(out, query_labels, align_loss_scaler=1.0):
 
 
 # ---------------------------------------------------------------------- parameters
-def param_shapes(radius=5, in_ch=1):
+def param_shapes(radius=5, in_ch=1, mask_feature_map=False):
     """The 147 state_dict entries RP_Net(backbone='UNet') creates
-    (net/rp_net.py:209-221, net/unet.py:394-430): name -> shape, in module order."""
+    (net/rp_net.py:209-221, net/unet.py:394-430): name -> shape, in module order.  mask_feature_map 'x' / 'x2' / 'x3' gives
+    Conv1 / Conv2 / Conv3 one more input channel (net/unet.py:401-414)."""
     shapes = {}
 
     def conv(name, cin, cout, k):
@@ -374,9 +390,9 @@ def param_shapes(radius=5, in_ch=1):
         conv(name + ".up.1", cin, cout, 3); bn(name + ".up.2", cout)
 
     f = [64, 128, 256, 512, 1024]
-    block("encoder.Conv1", in_ch, f[0])
-    block("encoder.Conv2", f[0], f[1])
-    block("encoder.Conv3", f[1], f[2])
+    block("encoder.Conv1", in_ch + (mask_feature_map == "x"), f[0])
+    block("encoder.Conv2", f[0] + (mask_feature_map == "x2"), f[1])
+    block("encoder.Conv3", f[1] + (mask_feature_map == "x3"), f[2])
     block("encoder.Conv4", f[2], f[3])
     block("encoder.Conv5", f[3], f[4])
     up("encoder.Up5", f[4], f[3]); block("encoder.Up_conv5", f[3] * 2, f[3])
@@ -390,10 +406,10 @@ def param_shapes(radius=5, in_ch=1):
     return shapes
 
 
-def seeded_params(radius=5, requires_grad=False):
+def seeded_params(radius=5, requires_grad=False, mask_feature_map=False):
     from rpnet_amd.utils.seeding import seeded_tensor
     P = {}
-    for name, shape in param_shapes(radius).items():
+    for name, shape in param_shapes(radius, mask_feature_map=mask_feature_map).items():
         leaf = name.rsplit(".", 1)[-1]
         like = torch.empty(shape, dtype=torch.int64 if leaf == "num_batches_tracked" else torch.float32)
         t = seeded_tensor(name, like)

@@ -257,8 +257,8 @@ def _use_split(pw, x0, x1):
     (channel ranges in multiples of 32) and the 1x1 layer over two sources (its 121 + 256 channels are packed as 128 + 256)"""
     if not (_MATH["planes"] and pw is not None and x0.shape[-1] % 32 == 0 and (x1 is None or x1.shape[-1] % 32 == 0)):
         return False
-    if pw.taps == 9:
-        return pw.cin_pad == pw.cin and pw.cin % 32 == 0
+    if pw.taps == 9:      # channel ranges in multiples of 32, or padded ranges through the gathering pack (mask_feature_map)
+        return (pw.cin_pad == pw.cin and pw.cin % 32 == 0) or (pw.cin_pad != pw.cin and pw.cin_pad % 64 == 0)
     return _CONV1X1_SPLIT and pw.taps == 1 and pw.cin_pad % 64 == 0 and pw.cout % 64 == 0 and x0.shape[-1] % 64 == 0
 
 
@@ -313,9 +313,11 @@ class PackedWeight:
         self.taps = kh * kw
         if split is None:
             self.off0, self.split, self.off1, self.cin_pad = 0, cin, cin, cin
-        else:  # (first-source channels, padded first-source channels): concat [corr(121->128), fm1]
-            n0, n0_pad = split
-            self.off0, self.split, self.off1, self.cin_pad = 0, n0, n0_pad, n0_pad + (cin - n0)
+        else:  # (first-source channels, padded first-source channels[, padded total]): concat [corr(121->128), fm1];
+            # [features(64), mask(1->64)] of mask_feature_map: the weight's input channels n0.. land on packed rows n0_pad..
+            n0, n0_pad = split[:2]
+            self.off0, self.split, self.off1 = 0, n0, n0_pad
+            self.cin_pad = split[2] if len(split) > 2 else n0_pad + (cin - n0)
         self.cout, self.cin = cout, cin
         self.has_wd = cin >= 32
         self._weight = weight
@@ -694,7 +696,7 @@ def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mo
     unmasked source (conv_block's first layer): in train mode on fp16 planes the fp32 form is then not written at all
     (a third of the launch's bytes) and the returned Operand is `planes_only`."""
     op0, op1 = as_operand(x0), as_operand(x1)
-    pw = cache.get(conv.weight, split) if conv.weight.shape[1] >= 32 else None
+    pw = cache.get(conv.weight, split) if (conv.weight.shape[1] >= 32 or split is not None) else None
     produced = {"z_unused": bool(z_unused) and training and conv.weight.shape[0] % 64 == 0}
     z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,

@@ -59,12 +59,13 @@ class conv_block(nn.Module):
             nn.Conv2d(ch_out, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
-    def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True):
+    def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True, split=None):
         """RF.Operand (or tensor) in, RF.Operand out; out_split: whether a 3x3 convolution reads the block's output as is
-        (RF.conv_bn_relu_op)"""
+        (RF.conv_bn_relu_op); split: channel ranges of the first layer's packed weight when its sources are padded
+        (RF.PackedWeight)"""
         t = self.training
         # the first layer's output feeds the second convolution and nothing else: on fp16 planes its fp32 form is not written
-        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=_ZSKIP)
+        x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=_ZSKIP, split=split)
         return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
@@ -112,15 +113,20 @@ class U_Net(Unet_2D):
 
     def __init__(self, cfg, img_ch=1, output_ch=6, resnet_type=None):
         super().__init__(cfg, img_ch, output_ch)
-        if cfg["mask_feature_map"]:
-            raise NotImplementedError(f"mask_feature_map={cfg['mask_feature_map']!r}: only the default "
-                                      "`no` (yamls/example.yml:103) is implemented on MI355X")
+        mfm = cfg["mask_feature_map"]
+        if mfm not in (False, None, "no", "x", "x2", "x3"):
+            # 'x4' / 'x5' widen Conv4 / Conv5 in the reference's constructor (net/unet.py:416-424) but its forward never
+            # concatenates a mask there (:451-455): unreachable in the reference too
+            raise NotImplementedError(f"mask_feature_map={mfm!r}: the reference's forward only implements 'x', 'x2', 'x3' "
+                                      "(net/unet.py:437-449)")
+        self.mask_feature_map = mfm if mfm in ("x", "x2", "x3") else False
         nt = cfg["unet_normalize_type"]
         self.Maxpool = nn.MaxPool2d(kernel_size=2, stride=2)
         f = [64, 128, 256, 512, 1024]
-        self.Conv1 = conv_block(self.img_ch, f[0], nt)
-        self.Conv2 = conv_block(f[0], f[1], nt)
-        self.Conv3 = conv_block(f[1], f[2], nt)
+        # the mask as one more input channel of Conv1 / Conv2 / Conv3 (net/unet.py:401-414)
+        self.Conv1 = conv_block(self.img_ch + (mfm == "x"), f[0], nt)
+        self.Conv2 = conv_block(f[0] + (mfm == "x2"), f[1], nt)
+        self.Conv3 = conv_block(f[1] + (mfm == "x3"), f[2], nt)
         self.Conv4 = conv_block(f[2], f[3], nt)
         self.Conv5 = conv_block(f[3], f[4], nt)
         self.Up5 = up_conv(f[4], f[3], nt)
@@ -128,18 +134,44 @@ class U_Net(Unet_2D):
         self.Up4 = up_conv(f[3], f[2], nt)
         self.Up_conv4 = conv_block(f[2] * 2, f[2], nt)
 
-    def forward_nhwc(self, x, cache, groups=1):
+    def _mask_source(self, mask, scale):
+        """the mask channel of mask_feature_map 'x2' / 'x3' as a second, 64-channel conv source (channel 0 = the mask
+        average-pooled by `scale`, net/unet.py:444,449; the other 63 channels and their weight rows are zero); |mask| <= 1
+        bounds it: fp16 tensor scale 2^-15"""
+        m = RF.mask_avgpool(mask, scale) if scale > 1 else mask
+        src = torch.zeros(*m.shape, 64, device=m.device, dtype=torch.float32)
+        src[..., 0] = m
+        return RF.Operand(src, scale=torch.full((1,), 2.0 ** -15, device=m.device, dtype=torch.float32))
+
+    def forward_nhwc(self, x, cache, groups=1, mask=None):
         """x [N,H,W,1]; `groups` consecutive image groups keep separate BatchNorm statistics
-        (= that many reference calls, in order).  Returns the RF.Operand of d4 (tensor `.x`, fp16 tensor scale `.scale`)."""
+        (= that many reference calls, in order); mask [N,H,W]: used only with mask_feature_map 'x' / 'x2' / 'x3'.
+        Returns the RF.Operand of d4 (tensor `.x`, fp16 tensor scale `.scale`)."""
         if x.shape[1] % 16 or x.shape[2] % 16:
             raise ValueError(f"U_Net needs H, W multiples of 16, got {tuple(x.shape[1:3])}")
+        mfm = self.mask_feature_map
+        if mfm and mask is None:
+            raise ValueError(f"mask_feature_map={mfm!r} needs the mask")
         pool = RF.maxpool2
         # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
         # scale per convolution), so those producers skip their own operand planes
         sk = "scale" if (RF.f16_mode() and self.training) else True
-        x1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk)
-        x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups, out_split=sk)
-        x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups, out_split=sk)
+        if mfm == "x":      # cat([x, mask], 1) (net/unet.py:437-438): image and mask as channels 0 / 1 of a 64-channel source
+            xin = torch.zeros(*x.shape[:3], 64, device=x.device, dtype=torch.float32)
+            xin[..., 0], xin[..., 1] = x[..., 0], mask.float()
+            x1 = self.Conv1.forward_nhwc(xin, cache, groups=groups, out_split=sk, split=(2, 64, 64))
+        else:
+            x1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk)
+        if mfm == "x2":     # cat([pool(x1), avg_pool2d(mask, 2)], 1) (:443-444) as two sources
+            x2 = self.Conv2.forward_nhwc(pool(x1), cache, x1=self._mask_source(mask.float(), 2), groups=groups, out_split=sk,
+                                         split=(64, 64, 128))
+        else:
+            x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups, out_split=sk)
+        if mfm == "x3":     # cat([pool(x2), avg_pool2d(mask, 4)], 1) (:448-449)
+            x3 = self.Conv3.forward_nhwc(pool(x2), cache, x1=self._mask_source(mask.float(), 4), groups=groups, out_split=sk,
+                                         split=(128, 128, 192))
+        else:
+            x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups, out_split=sk)
         x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups, out_split=sk)
         x5 = self.Conv5.forward_nhwc(pool(x4), cache, groups=groups)
         d5 = self.Up5.forward_nhwc(x5, cache, groups=groups, out_split=sk)
@@ -150,7 +182,8 @@ class U_Net(Unet_2D):
     def forward(self, x, mask=None, do_last_conv=True):
         n, c, h, w = x.shape
         assert c == 1
-        return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache()).x)}
+        m = None if mask is None else mask.reshape(n, h, w)
+        return {"d4": _to_nchw(self.forward_nhwc(x.reshape(n, h, w, 1), RF.WeightCache(), mask=m).x)}
 
 
 class Encoder(nn.Module):
@@ -331,8 +364,14 @@ class RP_Net(nn.Module):
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
             cache.prepack(self._pack_weights(), planes)
+        # both encoder calls of the reference get the SUPPORT foreground mask of way 0 / shot 0 (net/rp_net.py:248,257)
+        enc_mask = fore_mask[0][0].float() if self.encoder.mask_feature_map else None
+        if enc_mask is not None and ns != B:
+            raise NotImplementedError("mask_feature_map with more than one support image per episode: the reference "
+                                      "concatenates B masks onto Wa*Sh*B images (net/unet.py:438) and fails")
         if ns == B:
-            d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2)
+            d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2,
+                                           mask=None if enc_mask is None else torch.cat([enc_mask, enc_mask], 0))
             s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it
             d4 = d4.x
             supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
@@ -406,7 +445,8 @@ class RP_Net(nn.Module):
             enc = self.encoder
             convs = [m for blk in (enc.Conv1, enc.Conv2, enc.Conv3, enc.Conv4, enc.Conv5, enc.Up_conv5, enc.Up_conv4)
                      for m in (blk.conv[0], blk.conv[3])] + [enc.Up5.up[1], enc.Up4.up[1], self.cre.w_k[0], self.cre.w_q[0]]
-            ws = self._pack_list = [m.weight for m in convs if m.weight.shape[1] >= 32]
+            # (layers whose channel ranges are padded — mask_feature_map — pack on first use with their own ranges)
+            ws = self._pack_list = [m.weight for m in convs if m.weight.shape[1] >= 32 and m.weight.shape[1] % 32 == 0]
         return ws
 
     def alignLoss(self, qry_fts, pred, supp_fts, fore_mask, back_mask):

@@ -184,9 +184,11 @@ def to_t(ep):
             t(ep["appr_query_labels"]))
 
 
-def gen_model(tag, size, B, T, training, seed, stride=1, d4_stride=1, fts_stride=1):
+def gen_model(tag, size, B, T, training, seed, stride=1, d4_stride=1, fts_stride=1, mask_feature_map=None):
     cfg = dict(CFG)
     cfg["n_iter_refinement"] = T
+    if mask_feature_map is not None:      # net/unet.py:401-414,437-449: the mask as one more input channel of Conv1 / 2 / 3
+        cfg["mask_feature_map"] = mask_feature_map
     net = build_ref(cfg)
     net.train(training)
     ep = make_episode(seed, B, size)
@@ -240,7 +242,8 @@ def gen_model(tag, size, B, T, training, seed, stride=1, d4_stride=1, fts_stride
                 fx["sd." + k] = v
     # ---- pin the oracle end to end (both modes) on this very case
     for as_written in (True, False):
-        P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=training)
+        P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=training,
+                            mask_feature_map=cfg["mask_feature_map"])
         taps = {}
         with torch.set_grad_enabled(training):
             o = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, training, align=True, as_written=as_written, taps=taps)
@@ -293,5 +296,7 @@ if __name__ == "__main__":
     gen_model("m64_eval", 64, 2, 2, False, 1001)
     gen_model("m128_train", 128, 1, 1, True, 1002, d4_stride=4)      # BASELINE config 1
     gen_model("m256_train", 256, 2, 5, True, 1003, stride=8, d4_stride=16, fts_stride=4)
+    for mfm in ("x", "x2", "x3"):      # the yaml's non-default mask_feature_map settings
+        gen_model(f"m64_train_{mfm}", 64, 2, 2, True, 1004, d4_stride=4, mask_feature_map=mfm)
     gen_vgg()
     print("golden fixtures regenerated; oracle pinned against the reference")

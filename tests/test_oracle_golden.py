@@ -91,15 +91,18 @@ def test_blocks(golden, tag, fn):
     assert rel_err(fn(P, pre, x1, False), g[f"{tag}_yeval"]) < 1e-5
 
 
-@pytest.mark.parametrize("tag", ["m64_train", "m64_eval", "m128_train"])
+@pytest.mark.parametrize("tag", ["m64_train", "m64_eval", "m128_train", "m64_train_x", "m64_train_x2", "m64_train_x3"])
 def test_model_vs_golden(golden, tag):
     g = golden(tag)
     size, B, T, training, seed = (int(v) for v in g["meta"])
     cfg = load_cfg(T)
+    if tag.count("_") == 2:                     # m64_train_x2: mask_feature_map = 'x2' (net/unet.py:401-414,437-449)
+        cfg["mask_feature_map"] = tag.rsplit("_", 1)[1]
     (si, fg, bg, qi, ql, appr), ep = episode_tensors(seed, B, size)
     assert np.allclose(in_checksum(ep), g["in_checksum"], rtol=0, atol=1e-6), "synthetic inputs drifted"
     s_out, s_d4, s_f = (int(v) for v in g["strides"])
-    P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=bool(training))
+    P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=bool(training),
+                        mask_feature_map=cfg["mask_feature_map"])
     taps = {}
     with torch.set_grad_enabled(bool(training)):
         out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, bool(training), taps=taps)
