@@ -55,21 +55,23 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
-// one 64-lane wave per channel: lanes stride over the per-block partials, xor-shuffle sum
-__global__ __launch_bounds__(64) void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
+// one 256-thread block per channel: threads stride over the per-block partials (up to 2048 rows per group: a single wave
+// walked them in 32 dependent rounds, 7 us for a few KB), wave shuffles + one LDS round for the sum
+__global__ __launch_bounds__(256) void bn_stats_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* running_mean, float* running_var, long long* num_batches_tracked,
                                   float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
+    __shared__ double red4[8];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (num_batches_tracked && c == 0 && lane == 0) *num_batches_tracked += G;  // one "forward call" per group
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {  // sequential: one running-stat update per group, in call order
         double s = 0, q = 0;
-        for (int b = lane; b < nblk; b += 64) {
+        for (int b = lane; b < nblk; b += 256) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s += p[0]; q += p[1];
         }
-        s = wave_sum(s); q = wave_sum(q);
+        s = block_sum256(s, red4); q = block_sum256(q, red4 + 4);
         const double m = s / (double)R;
         double var = q / (double)R - m * m;
         if (var < 0) var = 0;
@@ -251,24 +253,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 // coef[g][C][2] floats = (s1/R, s2/R); dgamma/dbeta summed over groups
 // bound[c] (optional, with pmax): a rigorous bound of |dy| of channel c over all groups,
 //   |dy| = |scale| |dz m - s1/R - xhat s2/R| <= |scale| (max |dz m| + |s1|/R + sqrt(R) |s2|/R)
-__global__ __launch_bounds__(64) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                 float* coef, float* dgamma, float* dbeta, int accumulate, const float* __restrict__ pmax,
                                 const float* __restrict__ scale, float* __restrict__ bound) {
+    __shared__ double red4[8];
+    __shared__ float redm[4];
     const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     float bnd = 0.f;
     for (int g = 0; g < G; ++g) {
         double s1 = 0, s2 = 0;
         float mx = 0.f;
-        for (int b = lane; b < nblk; b += 64) {
+        for (int b = lane; b < nblk; b += 256) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
             if (pmax) mx = fmaxf(mx, pmax[(size_t)(g * nblk + b) * C + c]);
         }
-        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        s1 = block_sum256(s1, red4); s2 = block_sum256(s2, red4 + 4);
         if (pmax) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = block_max256(mx, redm);
             bnd = fmaxf(bnd, fabsf(scale[g * C + c]) * (mx + (float)(fabs(s1) / (double)R) + (float)(fabs(s2) / sqrt((double)R))));
         }
         if (lane == 0) {
@@ -397,7 +400,7 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     const BnGeom gm = bn_geom(R, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, s, (const double*)workspace, gm.nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(256), 0, s, (const double*)workspace, gm.nblk, R, C,
                        groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
                        mean, invstd);
     return check_launch("bn_stats");
@@ -412,7 +415,7 @@ extern "C" int rpnet_bn_stats_from_partial(const double* partial, int nblk, int 
                   "bn_stats_from_partial: null pointer");
     RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "bn_stats_from_partial: N=%d groups=%d", N, groups);
     const long R = (long)(N / groups) * HW;
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
                        beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
     return check_launch("bn_stats_from_partial");
 }
@@ -489,7 +492,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     float* bound = f16 ? pmax + (size_t)groups * 256 * C : nullptr;
     hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
                        pmax, R, C, gm);
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(64), 0, s, (const double*)partial, gm.nblk, R, C, groups,
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                        coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (dy_split) {
