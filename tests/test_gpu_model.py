@@ -355,10 +355,17 @@ def test_config3_full_size_properties():
     torch.cuda.synchronize()
 
 
-def test_odd_shapes_vs_oracle():
+@pytest.mark.parametrize("fp16_planes", [False, True])
+def test_odd_shapes_vs_oracle(fp16_planes):
     """Ragged everything: 96x96 images (24x24 feature maps: not powers of two -> the division paths of
-    the wgrad strips), batch 3 (statistic groups of 3 images, M tails in every tile variant), T=2."""
+    the wgrad strips), batch 3 (statistic groups of 3 images, M tails in every tile variant), T=2.  The default f16x2
+    arithmetic keeps a call this small on three bf16 planes; fp16_planes forces its fp16 planes (train AND eval mode, whose
+    scales are measured) through the same ragged shapes."""
     from oracle import rpnet_oracle as O
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    if fp16_planes:
+        RM._F16_MIN_PIXELS = 0          # restored by tests/conftest.py
     cfg = load_cfg(2)
     (si, fg, bg, qi, ql, appr), _ = episode_tensors(123, 3, 96, "cpu")
     P = O.seeded_params(requires_grad=True)
@@ -380,6 +387,15 @@ def test_odd_shapes_vs_oracle():
         assert abs(a - b) < (1e-2 if n.startswith("encoder.") else 2e-3) * b, f"{n}: {a} vs {b}"
     for k in ("encoder.Conv2.conv.4.running_var", "cre.w_q.1.running_mean"):
         assert rel_err(net.state_dict()[k], P[k]) < 1e-4
+    # eval mode on the same ragged shapes (running statistics as the train step above left them, on both sides)
+    net.eval()
+    RF.reset_arith()
+    with torch.no_grad():
+        ev = net([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], appr_query_labels=mv(appr))
+        ref_ev = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, False)
+    assert set(RF.arith_counts()["conv3x3"]) == {"f16x2" if fp16_planes else "bf16x3"}
+    for i in range(2):
+        assert rel_err(ev["refinement"][i], ref_ev["refinement"][i]) < TOL
 
 
 def test_training_driver_learns_and_checkpoints(tmp_path):
