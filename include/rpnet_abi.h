@@ -189,7 +189,12 @@ int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float* dw, int c
 /* first layer, Cin = 1 (net/unet.py:407 Conv1.conv.0): direct convolution */
 int rpnet_conv1_fwd(const float* x, const float* w /*[Cout][1][3][3]*/, const float* bias, float* y,
                     const float* ep_scale, const float* ep_shift, int N, int H, int W, int cout,
-                    float* out_absmax /* may be NULL; as rpnet_conv_desc.out_absmax */, rpnet_stream_t stream);
+                    float* out_absmax /* may be NULL; as rpnet_conv_desc.out_absmax */,
+                    double* stats_partial /* may be NULL; the train-mode BatchNorm statistics of y fused as in
+                                             rpnet_conv_desc.stats_partial: [groups * rpnet_conv1_stats_blocks()][cout][2]
+                                             for rpnet_bn_stats_from_partial (ep_scale must be NULL) */,
+                    int groups, rpnet_stream_t stream);
+int rpnet_conv1_stats_blocks(int N, int H, int W, int cout, int groups);
 size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cout);
 int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout,
                       void* workspace, size_t workspace_bytes, rpnet_stream_t stream);

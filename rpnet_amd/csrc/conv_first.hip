@@ -11,8 +11,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          const float* __restrict__ ep_scale,
                                                          const float* __restrict__ ep_shift, int N, int H, int W, int Cout,
-                                                         float* __restrict__ out_absmax) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout]
+                                                         float* __restrict__ out_absmax, double* __restrict__ stats_partial,
+                                                         const int groups) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout] (+ the statistics reduction)
     const int t = threadIdx.x;
     for (int i = t; i < 9 * Cout; i += 256) { const int co = i / 9, tap = i - co * 9; wl[tap * Cout + co] = w[i]; }
     for (int i = t; i < Cout; i += 256) wl[9 * Cout + i] = bias ? bias[i] : 0.f;
@@ -21,7 +22,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int q = t % Q, pl = t / Q;
     float amax = 0.f;
     const size_t M = (size_t)N * H * W;
-    for (size_t p = (size_t)blockIdx.x * ppb + pl; pl < ppb && p < M; p += (size_t)gridDim.x * ppb) {
+    // stats_partial (train-mode BatchNorm statistics fused, as rpnet_conv_desc.stats_partial): grid (blocks, groups), a block
+    // owns a CONTIGUOUS pixel range of one statistic group and leaves one (sum, sum of squares) row per channel;
+    // otherwise a grid-stride loop over all pixels
+    size_t p_lo = (size_t)blockIdx.x * ppb, p_hi = M, p_step = (size_t)gridDim.x * ppb;
+    if (stats_partial) {
+        const size_t Mg = M / groups, chunk = (Mg + gridDim.x - 1) / gridDim.x;
+        p_lo = (size_t)blockIdx.y * Mg + (size_t)blockIdx.x * chunk;
+        p_hi = min(p_lo + chunk, (size_t)(blockIdx.y + 1) * Mg);
+        p_step = ppb;
+    }
+    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+    for (size_t p = p_lo + pl; pl < ppb && p < p_hi; p += p_step) {
         const int ox = (int)(p % W), oy = (int)((p / W) % H);
         const size_t nb = p - (size_t)oy * W - ox;  // n*H*W
         f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[9 * Cout + q * 4]);
@@ -42,6 +54,25 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         }
         *reinterpret_cast<f32x4*>(y + p * Cout + q * 4) = acc;
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+        if (stats_partial) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ssum[k] += acc[k]; ssq[k] += (double)acc[k] * acc[k]; }
+        }
+    }
+    if (stats_partial) {        // the ppb pixel lanes of a channel quad are added up through LDS (behind the filter)
+        double* red = reinterpret_cast<double*>(wl + 10 * Cout + (10 * Cout & 1));      // 8-byte aligned
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[t * 8 + k] = ssum[k]; red[t * 8 + 4 + k] = ssq[k]; }
+        __syncthreads();
+        if (pl == 0) {
+            for (int r = 1; r < ppb; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ssum[k] += red[(r * Q + q) * 8 + k]; ssq[k] += red[(r * Q + q) * 8 + 4 + k]; }
+            double* o = stats_partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * Cout + q * 4) * 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[k * 2] = ssum[k]; o[k * 2 + 1] = ssq[k]; }
+        }
     }
     if (out_absmax) {       // as rpnet_conv_desc.out_absmax
 #pragma unroll
@@ -103,18 +134,34 @@ constexpr int kConv1WgradBlocks = 1024;
 
 }  // namespace rpnet
 
+extern "C" int rpnet_conv1_stats_blocks(int N, int H, int W, int cout, int groups) {
+    (void)cout;
+    if (groups < 1 || N % groups) return 0;
+    const size_t per_group = (size_t)(N / groups) * H * W;
+    const size_t nb = (per_group + 511) / 512;               // >= 512 pixels per block: enough blocks to stream at HBM rate
+    return (int)(nb > 2048 ? 2048 : nb);
+}
+
 extern "C" int rpnet_conv1_fwd(const float* x, const float* w, const float* bias, float* y, const float* ep_scale,
                                const float* ep_shift, int N, int H, int W, int cout, float* out_absmax,
-                               rpnet_stream_t stream) {
+                               double* stats_partial, int groups, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && w && y, RPNET_ERR_ARG, "conv1_fwd: null pointer");
     RPNET_REQUIRE(cout % 4 == 0 && cout <= 1024 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_fwd: cout=%d", cout);
     const int ppb = 256 / (cout / 4);
     const size_t M = (size_t)N * H * W;
+    if (stats_partial) {
+        const int nblk = rpnet_conv1_stats_blocks(N, H, W, cout, groups);
+        RPNET_REQUIRE(nblk > 0 && !ep_scale, RPNET_ERR_ARG, "conv1_fwd: fused statistics need N %% groups == 0 and no epilogue affine");
+        const size_t lds = (size_t)(10 * cout + 2) * sizeof(float) + (size_t)256 * 8 * sizeof(double);
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(nblk, groups), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, ep_scale,
+                           ep_shift, N, H, W, cout, out_absmax, stats_partial, groups);
+        return check_launch("conv1_fwd");
+    }
     size_t nb = (M + ppb - 1) / ppb;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((int)nb), dim3(256), (size_t)10 * cout * sizeof(float), (hipStream_t)stream, x,
-                       w, bias, y, ep_scale, ep_shift, N, H, W, cout, out_absmax);
+                       w, bias, y, ep_scale, ep_shift, N, H, W, cout, out_absmax, (double*)nullptr, 1);
     return check_launch("conv1_fwd");
 }
 

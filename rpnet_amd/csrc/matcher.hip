@@ -52,7 +52,17 @@ __global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__
     const int b = blockIdx.x % B, k = blockIdx.x / B;
     const float* m = masks + ((size_t)k * B + b) * HW;
     double s = 0;
-    for (int i = threadIdx.x; i < HW; i += 256) s += m[i];
+    if ((HW & 3) == 0) {        // 16-byte loads, four independent partial sums per thread
+        double s4[4] = {0, 0, 0, 0};
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(m)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] += v[q];
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) s += m[i];
+    }
     s = block_sum256(s, sm4);
     if (threadIdx.x == 0) msum[b * nmask + k] = (float)s;
 }

@@ -474,7 +474,8 @@ class ConvBnRelu(Function):
             np_out = _MATH["planes"] if (out_split in (True, "corr") and cout % 32 == 0 and not first and not want16) else 0
             zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
             if first:
-                call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout, ptr(mx))
+                call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout, ptr(mx),
+                     None, 1)
             elif _use_split(pw, x0, x1):
                 f16 = _f16_sources(op0, op1, in_scale, in_mode, pw.taps == 1) if f16_mode() else None
                 if f16 is not None:      # fp16 planes of the sources (their scales measured by their own launches)
@@ -509,8 +510,10 @@ class ConvBnRelu(Function):
         y = _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
         fused, xs, sx, sx1 = 0, None, None, None
-        if first:
-            call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout, None)
+        if first:      # batch statistics out of the same launch (one partial row per block and group)
+            fused = query("rpnet_conv1_stats_blocks", N, H, W, cout, groups)
+            part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64) if fused else None
+            call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(y), None, None, N, H, W, cout, None, ptr(part), groups)
         else:
             f16 = _f16_sources(op0, op1, in_scale, in_mode, pw.taps == 1) if (f16_mode() and _use_split(pw, x0, x1)) else None
             if op0.planes_only and not (f16 is not None and op1 is None and in_scale is None and pw.cin % 64 == 0 and cout % 64 == 0):

@@ -47,7 +47,8 @@ _SIGS = {
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
     "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),
-    "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "rpnet_conv1_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
+    "rpnet_conv1_stats_blocks": (ci, [ci, ci, ci, ci, ci]),
     "rpnet_pow2_scale": (ci, [vp, vp, vp]),
     "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
