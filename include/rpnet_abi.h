@@ -152,6 +152,14 @@ typedef struct rpnet_conv_desc {
        the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
        rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
     const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
+    /* optional (rpnet_conv_fwd used as the INPUT-GRADIENT launch of a layer whose single source x0 is the output of a
+       train-mode BatchNorm + ReLU with no other consumer — single destination, no out_scale / accumulate, whole tiles per
+       statistic group: rpnet_conv_stats_blocks(d) with d->groups = bnb_groups must be > 0): the reduction pass of THAT
+       BatchNorm's backward fused into this epilogue.  bnb_y: its saved pre-BatchNorm tensor [N*H*W][Cout]; bnb_stats:
+       [4][bnb_groups][Cout] = scale, shift, mean, invstd (the four outputs of rpnet_bn_stats, contiguous); outputs
+       bnb_partial [bnb_groups * rows][Cout][2] (sum dz m, sum dz m xhat) and bnb_pmax [same rows][Cout] (max |dz m|; may
+       be NULL) for rpnet_bn_bwd(given_partial, given_pmax, given_rows = rows) */
+    const float* bnb_y; const float* bnb_stats; double* bnb_partial; float* bnb_pmax; int bnb_groups;
     const float* acc_scale_x1;         /* optional (fp16 planes, two sources, rpnet_conv_fwd with taps == 1 and rpnet_conv_wgrad with
                                           taps == 1 only): the tensor scale of source x1 when it differs from source x0's
                                           (*acc_scale_x) — cat([corr, fm1]) of net/rp_net.py:81: the correlation's scale is
@@ -241,8 +249,10 @@ int rpnet_bn_act_scale(const float* gamma, const float* beta, float* split_scale
                        rpnet_stream_t stream);
 int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
                  const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
-                 float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
-                 size_t workspace_bytes, rpnet_stream_t stream);
+                 float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
+                 const double* given_partial, const float* given_pmax, int given_rows /* NULL, NULL, 0: the reduction pass
+                 runs here; else it already ran in the epilogue that produced dz (rpnet_conv_desc.bnb_*) */,
+                 void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:
  * dy = dz * [z > 0] (z may be NULL: no ReLU behind the conv) and db[c] = sum_pixels dy[p][c] */

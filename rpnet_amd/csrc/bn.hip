@@ -471,7 +471,8 @@ extern "C" int rpnet_bn_act_scale(const float* gamma, const float* beta, float* 
 
 extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
                             const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
-                            float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate, void* workspace,
+                            float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
+                            const double* given_partial, const float* given_pmax, int given_rows, void* workspace,
                             size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
@@ -490,10 +491,18 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: fp16 planes (1 or 2) need the scale output");
     float* pmax = f16 ? coef + (size_t)groups * C * 2 : nullptr;
     float* bound = f16 ? pmax + (size_t)groups * 256 * C : nullptr;
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
-                       pmax, R, C, gm);
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
-                       coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
+    if (given_partial) {
+        // the reduction pass already happened in the epilogue of the launch that produced dz (rpnet_conv_desc.bnb_*):
+        // [groups * given_rows][C][2] sums (and [..][C] maxima for fp16 planes)
+        RPNET_REQUIRE(given_rows > 0 && (!f16 || given_pmax), RPNET_ERR_ARG, "bn_bwd: given partial sums need their row count (and maxima for fp16 planes)");
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, given_partial, given_rows, R, C, groups, coef, dgamma, dbeta,
+                           accumulate, f16 ? given_pmax : (const float*)nullptr, scale, bound);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                           pmax, R, C, gm);
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
+                           coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
+    }
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (dy_split) {
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;

@@ -21,7 +21,7 @@ struct PatchRows {    // the block's rows walk a (rows / TW) x TW patch of one i
 // LDS bytes the epilogue may use (statistics reduction; per-wave 32-row slabs of the split output)
 template <int WN, int WGM>
 constexpr int epilogue_lds_bytes() {
-    constexpr int stats = WGM * 64 * WN * 2 * 8, slabs = WGM * 2 * 32 * (WN * 32 + 4) * 4;
+    constexpr int stats = WGM * 64 * WN * (2 * 8 + 4), slabs = WGM * 2 * 32 * (WN * 32 + 4) * 4;   // (sum, sumsq) doubles + a max
     return stats > slabs ? stats : slabs;
 }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -108,6 +108,64 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
                 }
             }
         }
+    }
+    if (d.bnb_y) {
+        // This launch is the input gradient dz of a layer whose source is the output of a train-mode BatchNorm + ReLU with
+        // no other consumer: the reduction pass of THAT BatchNorm's backward (sum dz m, sum dz m xhat, max |dz m| per
+        // channel; m = its ReLU mask, xhat its normalised pre-activation, both recomputed from its saved y) happens here,
+        // on the tile that is still in registers, instead of in a separate pass over dz and y (rpnet_bn_bwd given_partial).
+        // One row per block tile, as the forward statistics; tiles never straddle a statistic group (host-checked).
+        constexpr int BNC = 64 * WN;
+        double* red = reinterpret_cast<double*>(lds);                       // [WGM][BNC][2]
+        float* redm = reinterpret_cast<float*>(red + WGM * BNC * 2);       // [WGM][BNC]
+        __syncthreads();                                   // every wave is done with the staging memory
+        const int G = d.bnb_groups, gper = (d.N / G) * HW;
+        const int g = rows(0) / gper;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + wn * WN * 32 + j * 32 + li;
+            const float sc = d.bnb_stats[(0 * G + g) * Cout + col], sh = d.bnb_stats[(1 * G + g) * Cout + col];
+            const float mu = d.bnb_stats[(2 * G + g) * Cout + col], is = d.bnb_stats[(3 * G + g) * Cout + col];
+            double s1 = 0.0, s2 = 0.0;
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    if (row >= 0) {
+                        const float yv = d.bnb_y[(size_t)row * Cout + col];
+                        const float dm = (yv * sc + sh > 0.f) ? acc[i][j][r] : 0.f;
+                        s1 += dm;
+                        s2 += (double)dm * ((yv - mu) * is);
+                        mx = fmaxf(mx, fabsf(dm));
+                    }
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (h == 0) {
+                const int cl = wn * WN * 32 + j * 32 + li;
+                red[((size_t)wm * BNC + cl) * 2] = s1;
+                red[((size_t)wm * BNC + cl) * 2 + 1] = s2;
+                redm[wm * BNC + cl] = mx;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < BNC; e += WGM * 128) {
+            double a1 = 0.0, a2 = 0.0;
+            float m = 0.f;
+#pragma unroll
+            for (int r = 0; r < WGM; ++r) {
+                a1 += red[((size_t)r * BNC + e) * 2];
+                a2 += red[((size_t)r * BNC + e) * 2 + 1];
+                m = fmaxf(m, redm[r * BNC + e]);
+            }
+            d.bnb_partial[((size_t)tm * Cout + n0 + e) * 2] = a1;
+            d.bnb_partial[((size_t)tm * Cout + n0 + e) * 2 + 1] = a2;
+            if (d.bnb_pmax) d.bnb_pmax[(size_t)tm * Cout + n0 + e] = m;
+        }
+        __syncthreads();                                   // out_absmax / y_split below may reuse the memory
     }
     if (d.out_absmax) {      // max |output| of the launch: one order-independent atomic per wave (values >= 0: uint order = float order)
 #pragma unroll

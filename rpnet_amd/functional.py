@@ -199,10 +199,14 @@ class Operand:
              f16x2 / f16 mode runs on three bf16 planes, and the launch counters (arith_counts) show it.
     A tensor derived from x whose values are a subset of x's (max-pool, a batch slice, an alias) keeps the bound:
     `derive`."""
-    __slots__ = ("x", "p16", "pbf", "scale", "planes_only")
+    __slots__ = ("x", "p16", "pbf", "scale", "planes_only", "bn_ref")
 
-    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False):
+    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False, bn_ref=None):
         self.x, self.p16, self.pbf, self.scale = x, p16, pbf, scale
+        # bn_ref (only on a planes_only operand, i.e. a BatchNorm output with exactly one consumer): the producer's saved
+        # pre-BatchNorm tensor and statistics, so that the consumer's input-gradient launch can run the reduction pass of
+        # the producer's BatchNorm backward in its epilogue (BnRef)
+        self.bn_ref = bn_ref
         # planes_only: x is a shape-only placeholder for autograd (a zero-storage expanded tensor) — its fp32 values were
         # never written because the single consumer reads p16 (conv_bn_relu_op(z_unused=True)); reading x is an error
         self.planes_only = planes_only
@@ -220,6 +224,24 @@ class Operand:
 
     def derive(self, x):
         return Operand(x, scale=self.scale)
+
+
+class BnRef:
+    """Link between a train-mode conv + BatchNorm + ReLU layer and the ONE convolution that consumes its output: the
+    consumer's backward (which runs first) leaves the BatchNorm-backward partial sums it computed in its dgrad epilogue
+    here (`fused` = (partial, pmax, rows, data_ptr of the dz tensor they belong to)), the producer's backward picks them
+    up instead of running its own reduction pass."""
+    __slots__ = ("y", "stats", "groups", "fused")
+
+    def __init__(self, y, stats, groups):
+        self.y, self.stats, self.groups, self.fused = y, stats, groups, None
+
+
+# the BatchNorm-backward reduction in the consumer's dgrad epilogue: OFF by default — measured on one box, two runs each:
+# 364.3 / 364.2 pairs/s with it against 367.0 / 366.5 without (the 64 strided reads of y per lane and the fp64 sums in
+# the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
+# launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
+_BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
 
 
 def as_operand(t):
@@ -562,6 +584,7 @@ class ConvBnRelu(Function):
             # of the right shape for autograd
             z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, H, W, cout)
             produced["planes_only"] = True
+            produced["bn_ref"] = BnRef(y, stats, groups)
         # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
              np_out, ptr(gamma), ptr(beta),
@@ -575,6 +598,8 @@ class ConvBnRelu(Function):
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
+        ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
+        ctx.src_bn = op0.bn_ref if (op0.planes_only and _BNBWD_FUSE) else None   # this layer as the single consumer
         return z
 
     @staticmethod
@@ -601,9 +626,20 @@ class ConvBnRelu(Function):
         dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
+        # the reduction pass may already have run in the epilogue of the launch that produced dz (the single consumer's
+        # input gradient: BnRef) — taken only if dz is that very tensor
+        gp = gm_ = None
+        grows = 0
+        fz = ctx.bn_ref.fused if ctx.bn_ref is not None else None
+        if fz is not None and fz[3] == dz.data_ptr():
+            gp, gm_, grows = fz[0], fz[1], fz[2]
+        if ctx.bn_ref is not None:
+            ctx.bn_ref.fused = None
+        ARITH[("bn_bwd", "reduction in the consumer's dgrad epilogue" if gp is not None else "own reduction pass")] += 1
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
-             ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(ws), wsb)
+             ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(gp), ptr(gm_), grows,
+             ptr(ws), wsb)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:
@@ -669,6 +705,18 @@ class ConvBnRelu(Function):
                     dd.split_planes = np_
                     if np_ <= 2:
                         dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
+                    sb = ctx.src_bn
+                    if sb is not None and x1 is None and in_scale is None and not upsample and sb.y.shape == g0.shape:
+                        dd.groups = sb.groups
+                        rows = query("rpnet_conv_stats_blocks", C.byref(dd))
+                        if rows > 0:      # whole tiles per statistic group: the producer's BatchNorm-backward sums from this epilogue
+                            bp = torch.empty(sb.groups * rows * c0 * 2, device=y.device, dtype=torch.float64)
+                            bm = torch.empty(sb.groups * rows * c0, device=y.device, dtype=torch.float32)
+                            dd.bnb_y, dd.bnb_stats, dd.bnb_partial, dd.bnb_pmax = ptr(sb.y), ptr(sb.stats), ptr(bp), ptr(bm)
+                            dd.bnb_groups = sb.groups
+                            sb.fused = (bp, bm, rows, g0.data_ptr())
+                        else:
+                            dd.groups = 1
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
@@ -704,7 +752,8 @@ def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mo
     z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
                          1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
-    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")))
+    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")),
+                   produced.get("bn_ref"))
 
 
 def conv_bn_relu(x0, conv, bn, cache, training, **kw):

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                 ("in_scale_mode", ci), ("y0", vp), ("y1", vp), ("Co0", ci), ("Co1", ci), ("ep_scale", vp),
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
-                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci)]
+                ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("bnb_y", vp), ("bnb_stats", vp), ("bnb_partial", vp), ("bnb_pmax", vp), ("bnb_groups", ci),
+                ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci)]
 
 
 PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
@@ -57,7 +58,7 @@ _SIGS = {
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
     "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_bn_act_scale": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
-    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, cs, vp]),
     "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
     "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
     "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

@@ -214,6 +214,7 @@ def test_full_size_properties():
     counts = RF.arith_counts()
     assert counts["conv3x3"] == {"f16x2": 54} and counts["wgrad3x3"] == {"f16x2": 27}, counts
     assert counts["corr"] == {"f16x2": 6} and counts["corr_bwd"] == {"f16x2": 6}, counts
+    assert counts["bn_bwd"] == {"own reduction pass": 34}, counts
     # episodes are independent given fixed BN statistics: in eval mode a batch equals its halves
     net.eval()
     with torch.no_grad():
@@ -227,6 +228,30 @@ def test_full_size_properties():
     for n, p in net2.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, g1[n]), n
+
+
+def test_bn_bwd_reduction_in_dgrad_epilogue(monkeypatch):
+    """rpnet_conv_desc.bnb_*: the first layer of each of the seven conv_blocks has ONE consumer, whose input-gradient
+    launch can run the reduction pass of that layer's BatchNorm backward in its epilogue (off by default: measured
+    slower, rpnet_amd/functional.py).  Switched on, the step must give the same gradients as the separate pass."""
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    RM._F16_MIN_PIXELS = 0
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(321, 4, 128, DEV)
+    grads = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(RF, "_BNBWD_FUSE", fuse)
+        net = build(cfg, True)
+        RF.reset_arith()
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        total_loss(out, ql, 1.0).backward()
+        counts = RF.arith_counts()["bn_bwd"]
+        assert counts == ({"reduction in the consumer's dgrad epilogue": 7, "own reduction pass": 18} if fuse else
+                          {"own reduction pass": 25}), counts
+        grads[fuse] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for n, gr in grads[False].items():
+        assert rel_l2(grads[True][n], gr) < 1e-5 or float(gr.abs().max()) < 1e-6, n
 
 
 def test_five_shot_extension_vs_composed_oracle():
