@@ -446,7 +446,7 @@ __global__ __launch_bounds__(WGM * 128, (DB ? 1 : (WGM == 2 ? 2 : 1))) void conv
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
     }
-    conv_epilogue<WM, WN, WGM>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h, smem);
+    conv_epilogue<WM, WN, WGM, LinearRows, NP == 1>(d, acc, LinearRows{m0, M}, M, Cout, HW, n0, tm, wm, wn, li, h, smem);
 }
 
 // 256 x 128 tile whose 256 output pixels are a (256 / TW) x TW PATCH of one image, 8 waves (4 x 2), 3x3 taps only.
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_split_halo_kernel(const rpn
             }
         }
     }
-    conv_epilogue<WM, WN, 4, PatchRows<TW>>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
+    conv_epilogue<WM, WN, 4, PatchRows<TW>, NP == 1>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
                                             li, h, smem);
 }
 
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_halo4_kernel(const rp
         __syncthreads();
         if (++tap == 9) { tap = 0; ++ci; }
     }
-    conv_epilogue<WM, WN, 2, PatchRows<TW>>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
+    conv_epilogue<WM, WN, 2, PatchRows<TW>, NP == 1>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
                                             li, h, smem);
 }
 

@@ -10,7 +10,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librpnet_hip.so")
+_LIB_PATH = os.environ.get("RPNET_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librpnet_hip.so")
 _lib = None
 
 vp, ci, cf, cs, cd = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_double
