@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__
     if (threadIdx.x == 0) msum[b * nmask + k] = (float)s;
 }
 
-constexpr int kPoolSplit = 16;
+constexpr int kPoolSplit = 64;      // pixel chunks per episode (blocks = 64 x B: 16 left a batch-4 launch on 64 blocks)
 constexpr int kMaxMask = 4;
 
 // partial[b][s][k][C] = sum_{q in chunk s} f[b,q,:] * am[b,k,q]
@@ -234,7 +234,14 @@ __global__ void cosine_dproto_final(const float* __restrict__ dpart, float* __re
     dproto[i] = s;
 }
 
-constexpr int kCosBlocks = 32;
+// blocks per episode of the cosine-match backward: enough for ~8 blocks per CU whatever the batch (a fixed 32 left the
+// machine a quarter full at batch 4: 72 us at 512^2), never more than one block per 64 pixels
+static int cos_blocks(int B, int hw) {
+    int nb = 2048 / (B > 0 ? B : 1);
+    nb = nb < 32 ? 32 : (nb > 256 ? 256 : nb);
+    const int cap = hw / 64 > 0 ? hw / 64 : 1;
+    return nb < cap ? nb : cap;
+}
 
 __global__ void bilinear_up_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int H, int W) {
     const size_t total = (size_t)planes * H * W;
@@ -434,7 +441,7 @@ extern "C" int rpnet_cosine_match_fwd(const float* f, const float* proto, float*
 
 extern "C" size_t rpnet_cosine_match_bwd_workspace_bytes(int B, int K, int hw, int C) {
     (void)hw;
-    return (size_t)B * rpnet::kCosBlocks * K * C * sizeof(float);
+    return (size_t)B * rpnet::cos_blocks(B, hw) * K * C * sizeof(float);
 }
 
 extern "C" int rpnet_cosine_match_bwd(const float* f, const float* proto, const float* dpred, float* df, float* dproto,
@@ -445,11 +452,12 @@ extern "C" int rpnet_cosine_match_bwd(const float* f, const float* proto, const 
     RPNET_REQUIRE(C % 4 == 0 && K >= 1 && K <= kMaxK, RPNET_ERR_SHAPE, "cosine_match_bwd: C=%d K=%d", C, K);
     RPNET_REQUIRE(workspace_bytes >= rpnet_cosine_match_bwd_workspace_bytes(B, K, hw, C), RPNET_ERR_WORKSPACE, "cosine_match_bwd: workspace");
     hipStream_t s = (hipStream_t)stream;
+    const int nblk = cos_blocks(B, hw);
     RPNET_COS_DISPATCH(C / 4, {
-        hipLaunchKernelGGL((cosine_match_bwd_kernel<LL>), dim3(kCosBlocks, B), dim3(256), 0, s, f, proto, dpred, df,
+        hipLaunchKernelGGL((cosine_match_bwd_kernel<LL>), dim3(nblk, B), dim3(256), 0, s, f, proto, dpred, df,
                            (float*)workspace, B, K, hw, scaler, accumulate_df);
     });
-    hipLaunchKernelGGL(cosine_dproto_final, dim3(cdiv(B * K * C, 256)), dim3(256), 0, s, (const float*)workspace, dproto, B, kCosBlocks, K, C);
+    hipLaunchKernelGGL(cosine_dproto_final, dim3(cdiv(B * K * C, 256)), dim3(256), 0, s, (const float*)workspace, dproto, B, nblk, K, C);
     return check_launch("cosine_match_bwd");
 }
 
