@@ -83,18 +83,28 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sw = (li >> 2) & 3;
+    // the next 32-channel slab travels from global memory to registers while the MFMAs of the current one run
+    u32x4 ra[NP], rb[NP][BJ];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ra[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r1[p], aoff * (C * 2) + skg * 16, c0 * 2, 0));
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                rb[p][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r2[p], boff[j] * (C * 2) + skg * 16, c0 * 2, 0));
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < C; c0 += 32) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            *reinterpret_cast<u32x4*>(smem + p * A_BYTES + adst) =
-                __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r1[p], aoff * (C * 2) + skg * 16, c0 * 2, 0));
+            *reinterpret_cast<u32x4*>(smem + p * A_BYTES + adst) = ra[p];
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r2[p], boff[j] * (C * 2) + skg * 16, c0 * 2, 0));
-                if (bdst[j] >= 0) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + bdst[j]) = v;
-            }
+            for (int j = 0; j < BJ; ++j)
+                if (bdst[j] >= 0) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + bdst[j]) = rb[p][j];
         }
+        if (c0 + 32 < C) fetch(c0 + 32);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -163,14 +173,16 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
 }
 
 // df[b,p,ch] = inv_sqrt_c * sum_o g[b,p,o] * fo[b, p + SIGN*off(o), ch]   (see corr.hip)
-template <int R, int NP, int SIGN>
+// A block = 8 x 8 pixels x 128 NJ channels: building the split G slab (VALU work that does not depend on the channel) is
+// what a block spends most of its issue slots on, so NJ = 2 (all 256 channels of the encoder features) halves it per MFMA.
+template <int R, int NP, int SIGN, int NJ>
 __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float* __restrict__ g, const unsigned short* __restrict__ fos,
                                                                       float* __restrict__ df, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
                                                                       const float inv_sqrt_c, const float* __restrict__ s_fo,
                                                                       const float* __restrict__ add) {
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NCH = (NQ + 31) / 32, GS = (KK + 3) & ~3;
-    constexpr int BN = 128, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
+    constexpr int BN = 128 * NJ, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
     constexpr int A_BYTES = 64 * 64, B_BYTES = 32 * RSB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[64 * GS * 4 + NP * (A_BYTES + B_BYTES)];
     float* gs = reinterpret_cast<float*>(smem);                     // [64][GS] window gradients of the tile
@@ -188,6 +200,24 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
 #pragma unroll
     for (int p = 0; p < NP; ++p)
         rf[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(fos + p * plane + img), (short)0, h * w * C * 2, 0x00020000);
+
+    // fo slab pieces: rows brow + RPP j, 16-byte piece t % PR of the row's BN channels
+    constexpr int PR = 16 * NJ, RPP = 256 / PR, BJ = 32 / RPP;
+    const int brow = t / PR, bpc = (t % PR) * 16;
+    // the fo rows of the next slab travel from global memory to registers while the MFMAs of the current one run
+    u32x4 rfo[NP][BJ];
+    auto fetch_fo = [&](int q0) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int q = q0 + brow + RPP * j;
+            const int y = ty0 + q / HT - R, x = tx0 + q % HT - R;
+            const int voff = (q < NQ && y >= 0 && y < h && x >= 0 && x < w) ? (y * w + x) * (C * 2) + bpc : (int)0x80000000;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                rfo[p][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rf[p], voff, n0 * 2, 0));
+        }
+    };
+    fetch_fo(0);
 
     const float* gb = g + (size_t)b * h * w * cstride;
     for (int e = t; e < 64 * GS; e += 256) {
@@ -214,14 +244,14 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
     // G slab piece of this thread: pixel row ap = t >> 2 (py, px), k-group t & 3
     const int ap = t >> 2, apy = ap >> 3, apx = ap & 7, akg = t & 3;
     const int adst = ap * 64 + 16 * (akg ^ ((ap >> 2) & 3));
-    // fo slab pieces: rows (t >> 4) + 16 j, 16-byte piece t & 15
-    const int brow = t >> 4, bpc = (t & 15) * 16;
 
-    f32x16 acc[2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
     const int sw = (li >> 2) & 3;
     const int gq = lane >> 4, L = lane & 15;
@@ -231,14 +261,15 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
         __syncthreads();      // previous slab consumed (and gs complete on the first pass)
         {   // G[p][q0 + 8 akg .. +7]
             float v[8];
+            const int qs = q0 + akg * 8;
+            int qy = qs / HT, qx = qs - qy * HT;              // rows beyond NQ fall outside the window by themselves (c >= K)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int q = q0 + akg * 8 + i;
-                const int qy = q / HT, qx = q - qy * HT;
                 const int c = SIGN > 0 ? qy - apy : apy + 2 * R - qy;
                 const int a = SIGN > 0 ? qx - apx : apx + 2 * R - qx;
-                const bool in = q < NQ && c >= 0 && c < K && a >= 0 && a < K;
+                const bool in = (unsigned)c < (unsigned)K && (unsigned)a < (unsigned)K;
                 v[i] = in ? gs[ap * GS + a * K + c] * g_inv : 0.f;
+                if (++qx == HT) { qx = 0; ++qy; }
             }
             u32x4 o[NP];
             split8<NP>(v, o);
@@ -246,35 +277,35 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(asm_ + p * A_BYTES + adst) = o[p];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = brow + 16 * j, q = q0 + r;
-            const int y = ty0 + q / HT - R, x = tx0 + q % HT - R;
-            const int voff = (q < NQ && y >= 0 && y < h && x >= 0 && x < w) ? (y * w + x) * (C * 2) + bpc : (int)0x80000000;
+        for (int j = 0; j < BJ; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-                *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + r * RSB + bpc) =
-                    __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rf[p], voff, n0 * 2, 0));
-        }
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + (brow + RPP * j) * RSB + bpc) = rfo[p][j];
+        if (ch + 1 < NCH) fetch_fo(q0 + 32);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int koff = 16 * ((2 * s + hh) ^ sw);
-            bf16x8 af[NP][2], bfr[NP];
+            bf16x8 af[NP][2], bfr[NP][NJ];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(asm_ + p * A_BYTES + (i * 32 + li) * 64 + koff);
-                const unsigned char* bp = bsm + p * B_BYTES + b_lane + 16 * s * RSB;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)bp);
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(bp + 4 * RSB));
-                bfr[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const unsigned char* bp = bsm + p * B_BYTES + b_lane + 16 * s * RSB + jn * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)bp);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(bp + 4 * RSB));
+                    bfr[p][jn] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
             }
             constexpr int NPROD = nprod<NP>();
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
                 const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = mma16<NP>(af[pa][i], bfr[pb], acc[i]);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = mma16<NP>(af[pa][i], bfr[pb][jn], acc[i][jn]);
             }
         }
     }
@@ -288,9 +319,12 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
             const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
             if (y < h && x < w) {
-                const size_t o = ((size_t)y * w + x) * C + col;
-                const float v = NP <= 2 ? acc[i][r] * out_scale : acc[i][r];
-                dfb[o] = addb ? v + addb[o] : v;
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const size_t o = ((size_t)y * w + x) * C + col + jn * 128;
+                    const float v = NP <= 2 ? acc[i][jn][r] * out_scale : acc[i][jn][r];
+                    dfb[o] = addb ? v + addb[o] : v;
+                }
             }
         }
 }
@@ -342,19 +376,22 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
     const int tiles = cdiv(h, 8) * cdiv(w, 8);
     const unsigned short* a = (const unsigned short*)f1s;
     const unsigned short* b2 = (const unsigned short*)f2s;
-    const dim3 grid(tiles, C / 128, B);
-    if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, (const float*)nullptr, df1_add);
-    else if (planes == 2)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2, df1_add);
-    else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, 1>), grid, dim3(256), 0, s, dcorr, b2, df1, B, h, w, C, cstride, isc, scale2, df1_add);
+    // two planes or one: a block covers 256 channels when C allows (the G slab is built once for all of them)
+    const bool wide = planes <= 2 && C % 256 == 0;
+    const dim3 grid(tiles, wide ? C / 256 : C / 128, B);
+#define RPNET_CORR_BWD(NP_, SIGN_, NJ_, ...) hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, NP_, SIGN_, NJ_>), grid, dim3(256), 0, s, __VA_ARGS__)
+#define RPNET_CORR_BWD_PASS(SIGN_, G_, FO_, DF_, SFO_, ADD_)                                                       \
+    do {                                                                                                            \
+        if (planes == 3) RPNET_CORR_BWD(3, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, (const float*)nullptr, ADD_); \
+        else if (planes == 2 && wide) RPNET_CORR_BWD(2, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);     \
+        else if (planes == 2) RPNET_CORR_BWD(2, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);             \
+        else if (wide) RPNET_CORR_BWD(1, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);                    \
+        else RPNET_CORR_BWD(1, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);                              \
+    } while (0)
+    RPNET_CORR_BWD_PASS(1, dcorr, b2, df1, scale2, df1_add);
     if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;
-    if (planes == 3)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 3, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, (const float*)nullptr, (const float*)nullptr);
-    else if (planes == 2)
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 2, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1, (const float*)nullptr);
-    else
-        hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, 1, -1>), grid, dim3(256), 0, s, (const float*)dct, a, df2, B, h, w, C, cstride, isc, scale1, (const float*)nullptr);
+    RPNET_CORR_BWD_PASS(-1, (const float*)dct, a, df2, scale1, (const float*)nullptr);
+#undef RPNET_CORR_BWD_PASS
+#undef RPNET_CORR_BWD
     return check_launch("local_corr_split_bwd");
 }

@@ -426,12 +426,14 @@ def test_local_correlation(RF, conv_math, dims):
     assert rel_err(nchw(a.grad), g1 + nchw(g_alias)) < tol and rel_err(nchw(bb.grad), g2) < tol
 
 
-def test_local_correlation_f16_planes(RF):
+@pytest.mark.parametrize("c", [128, 256])
+def test_local_correlation_f16_planes(RF, c):
     """f16x2: the correlation of two BatchNorm outputs runs on their fp16 planes (tensor scales from the BatchNorm
-    bound; block-local scale for the window gradients in the backward) — against the same composite in fp64."""
+    bound; block-local scale for the window gradients in the backward) — against the same composite in fp64.
+    C = 256 takes the 256-channel blocks of the backward kernel, C = 128 the 128-channel ones."""
     import copy
     from oracle import rpnet_oracle as O
-    N, H, W, c, r = 2, 16, 16, 128, 5
+    N, H, W, r = 2, 16, 16, 5
     (ca, ba), (cb, bb_) = _mk_layer(c, c, 3, 81), _mk_layer(c, c, 3, 82)
     x = rnd(83, N, c, H, W)
     go = rnd(84, N, 121, H, W)
