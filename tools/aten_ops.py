@@ -1,5 +1,6 @@
 """Which torch (non-rpnet) GPU kernels does one training step launch, from where?  torch.profiler over one bench step,
-grouped by operator + input shapes, with the Python call site (debug aid for removing element-wise launches)."""
+grouped by operator + input shapes, with the Python call site (debug aid for removing element-wise launches).
+Environment: B (8), SIZE (256), ITERS (5), WAYS (1), MATH (library default) — configs[4] is B=4 SIZE=512 ITERS=10 WAYS=2 MATH=f16."""
 import os
 import sys
 
@@ -14,11 +15,14 @@ from rpnet_amd.parallel import FlatGradBucket  # noqa: E402
 
 dev = torch.device("cuda", 0)
 cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
-cfg["n_iter_refinement"] = 5
+cfg["n_iter_refinement"] = int(os.environ.get("ITERS", "5"))
+if os.environ.get("MATH"):
+    RF.set_conv_math(os.environ["MATH"])
 RF.set_async_wgrad(True)
 net = bench.build_model(cfg, dev)
 bucket = FlatGradBucket(net)
-inp = bench.make_inputs(1234, 8, 256, dev)
+inp = bench.make_inputs(1234, int(os.environ.get("B", "8")), int(os.environ.get("SIZE", "256")), dev,
+                        n_ways=int(os.environ.get("WAYS", "1")))
 for _ in range(2):
     bench.step(net, bucket, inp, cfg["align_loss_scaler"])
 torch.cuda.synchronize()
