@@ -29,6 +29,9 @@ _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
 # of the convolution): batch 2 at 256^2 (the reference driver's call) is small-grid bound and 5 % slower with it (5.33 vs
 # 5.07 ms), batch 8 is 20 % faster (9.8 vs 11.8 ms), batch 32 37 % (32.5 vs 44.5 ms).  0 = as in training.
 _F16_MIN_PIXELS_EVAL = int(os.environ.get("RPNET_F16_MIN_PIXELS_EVAL", "524288"))
+# eval-mode CRE: w_q on a second HIP stream beside w_k while a call has at most this many feature pixels (B h w)
+_CRE_STREAMS = os.environ.get("RPNET_CRE_STREAMS", "1") != "0"
+_CRE_STREAMS_MAX_PIXELS = int(os.environ.get("RPNET_CRE_STREAMS_MAX_PIXELS", "16384"))
 
 
 def _to_nhwc(x):
@@ -270,10 +273,29 @@ class ContextCorrelationEncoder(nn.Module):
         m1, m2 = (1, 2) if mask is not None else (0, 0)
         sp = "corr" if self.radius == 5 else False       # the correlation then takes the split planes of fm1 / fm2
         # fts_scale: the fp16 tensor scale of the features (their producer's bound; slicing / fan-out keeps it)
-        fm1 = RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask, in_mode=m1,
-                                 out_split=sp)
-        fm2 = RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale), self.w_q[0], self.w_q[1], cache, t, in_scale=mask, in_mode=m2,
-                                 out_split=sp)
+        def w_k():
+            return RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask,
+                                      in_mode=m1, out_split=sp)
+
+        def w_q():
+            return RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale), self.w_q[0], self.w_q[1], cache, t, in_scale=mask,
+                                      in_mode=m2, out_split=sp)
+
+        # inference on a few slices (test_rpnet.py: 2 per call): either convolution is 256 four-wave blocks of a machine
+        # that holds 512 — the two are independent, so w_q runs on the side stream beside w_k (one block of each per CU)
+        pixels = fk.shape[0] * fk.shape[1] * fk.shape[2]
+        if _CRE_STREAMS and not t and not torch.is_grad_enabled() and fk.is_cuda and pixels <= _CRE_STREAMS_MAX_PIXELS:
+            main, side = torch.cuda.current_stream(fk.device), RF._side_stream(fk.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fm2 = w_q()
+            fm1 = w_k()
+            main.wait_stream(side)
+            for tns in (fm2.x, fm2.p16, fm2.pbf, fm2.scale):     # allocated on the side stream, read on the main one from here on
+                if tns is not None:
+                    tns.record_stream(main)
+        else:
+            fm1, fm2 = w_k(), w_q()
         return self._tail(fm1, fm2, cache)
 
     def _tail(self, fm1, fm2, cache):
