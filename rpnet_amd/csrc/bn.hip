@@ -14,12 +14,18 @@ struct BnGeom {
     int rows_blk;  // rows per block
 };
 
+// most blocks (= partial-sum rows) per group: the reduction passes keep two 16-byte loads per thread in flight, so the
+// 64- and 128-channel levels (0.13 - 0.5 M rows per group) need ~8 blocks per CU to cover the HBM latency (bn_bwd_partial:
+// 28.7 -> 23.8 us per launch against 2 per CU); bounded by the workspace, 131072 partial sums per group
+static int bn_max_blocks(int C) { const int m = 131072 / C; return m < 256 ? 256 : (m > 1024 ? 1024 : m); }
+
 static BnGeom bn_geom(long R, int C) {
     BnGeom g;
     g.C4 = C / 4;
     g.rows_it = 256 / g.C4;
     long nb = (R + (long)g.rows_it * 4 - 1) / ((long)g.rows_it * 4);
-    g.nblk = (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    const int cap = bn_max_blocks(C);
+    g.nblk = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
     g.rows_blk = (int)((R + g.nblk - 1) / g.nblk);
     return g;
 }
@@ -217,9 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
         const long r0 = (long)blk * gm.rows_blk;
         const long r1 = min(r0 + gm.rows_blk, R);
         const size_t base = ((size_t)g * R) * C + tc * 4;
-        for (long r = r0 + tr; r < r1; r += gm.rows_it) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C);
+        auto take = [&](const f32x4 v, const f32x4 d) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
@@ -227,7 +231,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                 s2[k] += (double)dm * ((v[k] - mu[k]) * is[k]);
                 mx[k] = fmaxf(mx[k], fabsf(dm));
             }
+        };
+        long r = r0 + tr;
+        for (; r + gm.rows_it < r1; r += 2 * gm.rows_it) {      // two rows per pass: four 16-byte loads in flight per thread
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(y + base + (size_t)(r + gm.rows_it) * C);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)(r + gm.rows_it) * C);
+            take(v0, d0);
+            take(v1, d1);
         }
+        if (r < r1)
+            take(*reinterpret_cast<const f32x4*>(y + base + (size_t)r * C), *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; redm[t * 4 + k] = mx[k]; }
@@ -376,8 +391,9 @@ static int elt_grid(size_t total4) {
 
 extern "C" size_t rpnet_bn_workspace_bytes(int C, int groups) {
     // partial sums (fp64), coefficients, per-block maxima and per-channel bounds (the last two for fp16 split outputs)
-    return (size_t)groups * 256 * C * 2 * sizeof(double) + (size_t)groups * C * 2 * sizeof(float) +
-           (size_t)groups * 256 * C * sizeof(float) + (size_t)C * sizeof(float);
+    const size_t rows = (size_t)groups * rpnet::bn_max_blocks(C);
+    return rows * C * 2 * sizeof(double) + (size_t)groups * C * 2 * sizeof(float) + rows * C * sizeof(float) +
+           (size_t)C * sizeof(float);
 }
 
 static int bn_check(const char* who, int N, int HW, int C, int groups) {
@@ -486,11 +502,11 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     const BnGeom gm = bn_geom(R, C);
     hipStream_t s = (hipStream_t)stream;
     double* partial = (double*)workspace;
-    float* coef = (float*)((char*)workspace + (size_t)groups * 256 * C * 2 * sizeof(double));
+    float* coef = (float*)((char*)workspace + (size_t)groups * bn_max_blocks(C) * C * 2 * sizeof(double));
     const bool f16 = dy_split && planes <= 2;
     RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: fp16 planes (1 or 2) need the scale output");
     float* pmax = f16 ? coef + (size_t)groups * C * 2 : nullptr;
-    float* bound = f16 ? pmax + (size_t)groups * 256 * C : nullptr;
+    float* bound = f16 ? pmax + (size_t)groups * bn_max_blocks(C) * C : nullptr;
     if (given_partial) {
         // the reduction pass already happened in the epilogue of the launch that produced dz (rpnet_conv_desc.bnb_*):
         // [groups * given_rows][C][2] sums (and [..][C] maxima for fp16 planes)
