@@ -47,15 +47,16 @@ __global__ __launch_bounds__(256) void dice_ce_partial(const float* __restrict__
 }
 
 // stats: [B][2K+2] per sample, then [2K+2] totals.  loss[0] = dice + ce.
-// One 256-thread block: each wave sums the per-block partials of one (sample, slot) pair at a
+// One 1024-thread block: each of its 16 waves sums the per-block partials of one (sample, slot) pair at a
 // time; thread 0 then does the O(B*K) scalar combine.
-__global__ __launch_bounds__(256) void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats,
+__global__ __launch_bounds__(1024) void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats,
                                                       float* __restrict__ loss, int B, int K, int nblk, int with_dice,
                                                       int per_sample, const float* __restrict__ sample_weight) {
     extern __shared__ double sums[];  // [B][S]
     const int S = 2 * K + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int idx = wv; idx < B * S; idx += 4) {
+    const int nwv = blockDim.x >> 6;
+    for (int idx = wv; idx < B * S; idx += nwv) {
         const int b = idx / S, j = idx - b * S;
         double v = 0;
         for (int blk = lane; blk < nblk; blk += 64) v += partial[((size_t)b * nblk + blk) * S + j];
@@ -179,7 +180,7 @@ extern "C" int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, flo
     RPNET_REQUIRE(workspace_bytes >= rpnet_loss_workspace_bytes(B, K, H, W), RPNET_ERR_WORKSPACE, "dice_ce_fwd: workspace");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B), dim3(256), 0, s, logits, labels, (double*)workspace, K, H * W, ignore_index);
-    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(256), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
+    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
                        per_sample, sample_weight);
     return check_launch("dice_ce_fwd");
 }
