@@ -40,3 +40,19 @@ tot = sum(r[1] for r in rows)
 print(f"aten ops with device time: {sum(r[0] for r in rows)} calls, {tot / 1e3:.2f} ms")
 for r in rows[:70]:
     print(f"{r[0]:4d} x {r[1]:9.1f} us  {r[2]:28s} {r[3]:92s} {r[4]}")
+# memcpy / memset activity of the step (runtime copies are not aten kernels: listed by kind and by the aten op that issued them)
+mem = {}
+for e in prof.events():
+    if "Memcpy" in e.name or "Memset" in e.name:
+        mem.setdefault(e.name, [0, 0.0])
+        mem[e.name][0] += 1
+        mem[e.name][1] += e.device_time
+for k, v in mem.items():
+    print(f"{v[0]:4d} x {v[1]:9.1f} us  {k}")
+cp = {}
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8):
+    if e.key in ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like"):
+        stack = [s_ for s_ in e.stack if "rpnet_amd" in s_ or "bench.py" in s_ or "parallel.py" in s_][:2]
+        cp[(e.key, str(e.input_shapes)[:60], " <- ".join(s_.split("/")[-1] for s_ in stack))] = e.count
+for k, v in sorted(cp.items(), key=lambda kv: -kv[1])[:40]:
+    print(f"{v:4d} x {k[0]:18s} {k[1]:62s} {k[2]}")
