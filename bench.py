@@ -238,13 +238,16 @@ def eval_leg(net, cfg, dev, size, RF):
                     orig(name, *args)
                     b.record()
                     recs.append((2.0 * d.N * d.H * d.W * (d.C0 + d.C1) * (d.Co0 + d.Co1) * d.taps, d.split_planes, a, b))
+                import rpnet_amd.modules as RM
                 RF.call = timed
                 RF.reset_arith()
+                cre_streams, RM._CRE_STREAMS = RM._CRE_STREAMS, False   # per-launch durations: one launch at a time on the GPU
                 try:
                     net(si, fg, bg, qi, appr_query_labels=appr)
                     torch.cuda.synchronize()
                 finally:
                     RF.call = orig
+                    RM._CRE_STREAMS = cre_streams
             fl = sum(r[0] for r in recs)
             tt = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
             planes = max((r[1] for r in recs if r[0] > 1e9), default=0)
