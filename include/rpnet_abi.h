@@ -241,9 +241,14 @@ int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* run
  * beta; |xhat| <= sqrt(n) for any batch), rpnet_bn_bwd  |dy_c| <= |scale_c| (max|dz m| + |s1|/n + |s2|/sqrt(n)) with the
  * maxima gathered by the reduction pass; s = pow2ceil(bound) 2^-15.  The consumer multiplies its accumulator by s
  * (rpnet_conv_desc.acc_scale_x / acc_scale_dy). */
+/* pool_w > 0 (the image width W; H = HW / W, both even): BatchNorm + ReLU + nn.MaxPool2d(2, 2) (net/unet.py:397,442-448) in
+ * one pass for an output that feeds nothing but its pool — z (may be NULL) and z_split (required) are then
+ * [N, H/2, W/2, C], the full-resolution z is never written; rpnet_bn_bwd with the same pool_w takes dz of that pooled
+ * shape, finds each window's first maximum (row, column scan order, as rpnet_maxpool2_bwd) again from y and writes dy at
+ * full resolution (dy_split required, no given_partial). */
 int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
                   const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
-                  rpnet_stream_t stream);
+                  int pool_w, rpnet_stream_t stream);
 /* the fp16 tensor scale of a BatchNorm + ReLU output alone (same value rpnet_bn_relu writes with planes == 2) */
 int rpnet_bn_act_scale(const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
                        rpnet_stream_t stream);
@@ -252,7 +257,7 @@ int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const floa
                  float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
                  const double* given_partial, const float* given_pmax, int given_rows /* NULL, NULL, 0: the reduction pass
                  runs here; else it already ran in the epilogue that produced dz (rpnet_conv_desc.bnb_*) */,
-                 void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+                 int pool_w, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:
  * dy = dz * [z > 0] (z may be NULL: no ReLU behind the conv) and db[c] = sum_pixels dy[p][c] */

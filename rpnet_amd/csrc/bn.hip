@@ -382,6 +382,216 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restric
     }
 }
 
+
+// ---- BatchNorm + ReLU + MaxPool2d(2, 2) in one pass (train mode; net/unet.py:442-448: x1 and x2 feed nothing but their
+// pool).  The fp32 z of the full-resolution tensor is never written: max and ReLU commute, so the pooled value is
+// relu(max of the four affine values), and the backward finds the window's first maximum again from y.
+struct PoolGeom {
+    int Ho, Wo, W;          // pooled height / width, input width
+    int imgs_per_group;     // N / groups
+    size_t img_elems;       // H W C of one input image
+};
+
+// thread = one pooled pixel x 8 channels; planes [NP][N, Ho, Wo, C] of relu(max) / s (and the fp32 pooled tensor when zp != NULL)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float* __restrict__ zp,
+                                                                  unsigned short* __restrict__ zs, size_t total8, int C8,
+                                                                  PoolGeom pg, size_t plane_elems, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float sqrt_n,
+                                                                  float* __restrict__ s_out) {
+    float inv_s = 1.f;
+    if (NP <= 2) {
+        __shared__ float red4[4];
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C8 * 8; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
+        const float sc = pow2_scale(block_max256(m, red4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
+        inv_s = 1.f / sc;
+    }
+    const size_t rowC = (size_t)pg.W * C8 * 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        size_t pp = i / C8;
+        const int ox = (int)(pp % pg.Wo); pp /= pg.Wo;
+        const int oy = (int)(pp % pg.Ho);
+        const int n = (int)(pp / pg.Ho);
+        const int g = n / pg.imgs_per_group;
+        const float* sc = scale + (size_t)(g * C8 + c8) * 8;
+        const float* sh = shift + (size_t)(g * C8 + c8) * 8;
+        const float* src = y + (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C8 * 8 + c8 * 8;
+        float v[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + hh * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(src + C8 * 8 + hh * 4);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + rowC + hh * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(src + rowC + C8 * 8 + hh * 4);
+            const f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = fmaxf(fmaxf(a[k] * s4[k] + h4[k], b[k] * s4[k] + h4[k]), fmaxf(c[k] * s4[k] + h4[k], d[k] * s4[k] + h4[k]));
+                o[k] = fmaxf(m, 0.f);
+                v[hh * 4 + k] = o[k];
+            }
+            if (zp) reinterpret_cast<f32x4*>(zp)[i * 2 + hh] = o;
+        }
+        if (NP <= 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= inv_s;
+        }
+        u32x4 pl[NP];
+        split8<NP>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(zs + p * plane_elems + i * 8) = pl[p];
+    }
+}
+
+// the window's first maximum in (row, column) scan order (maxpool2_bwd_kernel's rule) receives the pooled gradient
+__device__ __forceinline__ int pool_argmax(const float a0, const float a1, const float a2, const float a3, float& best) {
+    int q = 0; best = a0;
+    if (a1 > best) { best = a1; q = 1; }
+    if (a2 > best) { best = a2; q = 2; }
+    if (a3 > best) { best = a3; q = 3; }
+    return q;
+}
+
+// reduction pass over POOLED rows (Rp = R / 4 per group): dz is zero off the window maxima, so
+// s1 = sum dp [z_max > 0], s2 = sum dp [z_max > 0] xhat(argmax); same partial layout as bn_bwd_partial
+__global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restrict__ dp, const float* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            double* __restrict__ partial, float* __restrict__ pmax, long Rp, int C,
+                                                            BnGeom gm, PoolGeom pg) {
+    __shared__ double red[256 * 8];
+    __shared__ float redm[256 * 4];
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    const int t = threadIdx.x;
+    const int tc = t % gm.C4, tr = t / gm.C4;
+    const int g = blockIdx.y, blk = blockIdx.x;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (tr < gm.rows_it) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + g * C + tc * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + g * C + tc * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tc * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * C + tc * 4);
+        const long r0 = (long)blk * gm.rows_blk;
+        const long r1 = min(r0 + gm.rows_blk, Rp);
+        const size_t gbase = (size_t)g * pg.imgs_per_group * pg.img_elems + tc * 4;
+        const size_t rowC = (size_t)pg.W * C;
+        const int hw = pg.Ho * pg.Wo;
+        for (long r = r0 + tr; r < r1; r += gm.rows_it) {
+            const int nl = (int)(r / hw), rem = (int)(r - (long)nl * hw);
+            const int oy = rem / pg.Wo, ox = rem - oy * pg.Wo;
+            const float* src = y + gbase + (size_t)nl * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + rowC), v3 = *reinterpret_cast<const f32x4*>(src + rowC + C);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dp + ((size_t)g * Rp + r) * C + tc * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float best;
+                const int q = pool_argmax(v0[k] * sc[k] + sh[k], v1[k] * sc[k] + sh[k], v2[k] * sc[k] + sh[k], v3[k] * sc[k] + sh[k], best);
+                const float vq = q == 0 ? v0[k] : q == 1 ? v1[k] : q == 2 ? v2[k] : v3[k];
+                const float dm = best > 0.f ? d[k] : 0.f;
+                s1[k] += dm;
+                s2[k] += (double)dm * ((vq - mu[k]) * is[k]);
+                mx[k] = fmaxf(mx[k], fabsf(dm));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; redm[t * 4 + k] = mx[k]; }
+    __syncthreads();
+    if (tr == 0) {
+        for (int rr = 1; rr < gm.rows_it; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s1[k] += red[(rr * gm.C4 + tc) * 8 + k];
+                s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k];
+                mx[k] = fmaxf(mx[k], redm[(rr * gm.C4 + tc) * 4 + k]);
+            }
+        double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k * 2] = s1[k]; o[k * 2 + 1] = s2[k]; }
+        if (pmax) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pmax[(size_t)(g * gm.nblk + blk) * C + tc * 4 + k] = mx[k];
+        }
+    }
+}
+
+// thread = one pooled pixel x 8 channels: the four dy of its window (planes at full resolution, fp32 too when dy != NULL)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const float* __restrict__ y,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ coef, float* __restrict__ dy,
+                                                                unsigned short* __restrict__ dys, size_t total8, int C, PoolGeom pg,
+                                                                size_t plane_elems, const float* __restrict__ bound,
+                                                                float* __restrict__ s_out) {
+    const int C8 = C / 8;
+    float inv_s = 1.f;
+    if (NP <= 2) {
+        __shared__ float red4[4];
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, bound[c]);
+        const float sc = pow2_scale(block_max256(m, red4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
+        inv_s = 1.f / sc;
+    }
+    const size_t rowC = (size_t)pg.W * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        size_t pp = i / C8;
+        const int ox = (int)(pp % pg.Wo); pp /= pg.Wo;
+        const int oy = (int)(pp % pg.Ho);
+        const int n = (int)(pp / pg.Ho);
+        const int g = n / pg.imgs_per_group;
+        const size_t e00 = (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C + c8 * 8;
+        const size_t offs[4] = {e00, e00 + C, e00 + rowC, e00 + rowC + C};
+        float r[4][8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int o = g * C + c8 * 8 + hh * 4;
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(y + offs[q] + hh * 4);
+            const f32x4 d = reinterpret_cast<const f32x4*>(dp)[i * 2 + hh];
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float best;
+                const int qb = pool_argmax(v[0][k] * sc[k] + sh[k], v[1][k] * sc[k] + sh[k], v[2][k] * sc[k] + sh[k],
+                                           v[3][k] * sc[k] + sh[k], best);
+                const float dm = best > 0.f ? d[k] : 0.f;
+                const float c1 = coef[(o + k) * 2], c2 = coef[(o + k) * 2 + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r[q][hh * 4 + k] = sc[k] * ((q == qb ? dm : 0.f) - c1 - (v[q][k] - mu[k]) * is[k] * c2);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (dy) {
+                *reinterpret_cast<f32x4*>(dy + offs[q]) = f32x4{r[q][0], r[q][1], r[q][2], r[q][3]};
+                *reinterpret_cast<f32x4*>(dy + offs[q] + 4) = f32x4{r[q][4], r[q][5], r[q][6], r[q][7]};
+            }
+            if (NP <= 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[q][k] *= inv_s;
+            }
+            u32x4 pl[NP];
+            split8<NP>(r[q], pl);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dys + p * plane_elems + offs[q]) = pl[p];
+        }
+    }
+}
+
 static int elt_grid(size_t total4) {
     size_t b = (total4 + 255) / 256;
     return (int)(b > 2048 * 4 ? 2048 * 4 : (b < 1 ? 1 : b));
@@ -448,10 +658,26 @@ extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const
 
 extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
                              const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
-                             rpnet_stream_t stream) {
+                             int pool_w, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && scale && shift && (z || z_split), RPNET_ERR_ARG, "bn_relu: null pointer");
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
+    if (pool_w > 0) {      // + MaxPool2d(2, 2): z / z_split are [N, H/2, W/2, C]
+        RPNET_REQUIRE(z_split && planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_ARG, "bn_relu: the pooled form writes split planes (planes=%d C=%d)", planes, C);
+        RPNET_REQUIRE(HW % pool_w == 0 && pool_w % 2 == 0 && (HW / pool_w) % 2 == 0, RPNET_ERR_SHAPE, "bn_relu: pooled image %d x %d", HW / pool_w, pool_w);
+        RPNET_REQUIRE(planes == 3 || (gamma && beta && split_scale), RPNET_ERR_ARG, "bn_relu: fp16 planes (1 or 2) need gamma, beta and the scale output");
+        const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
+        const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * (HW / 4) * C;
+        const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
+#define RPNET_BN_POOL(NP_)                                                                                                  \
+    hipLaunchKernelGGL(bn_relu_pool_split_kernel<NP_>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z, \
+                       (unsigned short*)z_split, total8, C / 8, pg, pe, gamma, beta, sqrt_n, split_scale)
+        if (planes == 3) RPNET_BN_POOL(3);
+        else if (planes == 2) RPNET_BN_POOL(2);
+        else RPNET_BN_POOL(1);
+#undef RPNET_BN_POOL
+        return check_launch("bn_relu_pool");
+    }
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (z_split) {
         RPNET_REQUIRE(planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
@@ -488,7 +714,7 @@ extern "C" int rpnet_bn_act_scale(const float* gamma, const float* beta, float* 
 extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const float* scale, const float* shift,
                             const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
                             float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
-                            const double* given_partial, const float* given_pmax, int given_rows, void* workspace,
+                            const double* given_partial, const float* given_pmax, int given_rows, int pool_w, void* workspace,
                             size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
@@ -507,6 +733,28 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     RPNET_REQUIRE(!f16 || split_scale, RPNET_ERR_ARG, "bn_bwd: fp16 planes (1 or 2) need the scale output");
     float* pmax = f16 ? coef + (size_t)groups * C * 2 : nullptr;
     float* bound = f16 ? pmax + (size_t)groups * bn_max_blocks(C) * C : nullptr;
+    if (pool_w > 0) {
+        // dz is the gradient of the POOLED output [N, H/2, W/2, C] (rpnet_bn_relu(pool_w)): the window maxima are found
+        // again from y; dy comes out at full resolution
+        RPNET_REQUIRE(dy_split && !given_partial, RPNET_ERR_ARG, "bn_bwd: the pooled form writes split planes and runs its own reduction");
+        RPNET_REQUIRE(HW % pool_w == 0 && pool_w % 2 == 0 && (HW / pool_w) % 2 == 0, RPNET_ERR_SHAPE, "bn_bwd: pooled image %d x %d", HW / pool_w, pool_w);
+        const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
+        const long Rp = R / 4;
+        const BnGeom gp = bn_geom(Rp, C);
+        hipLaunchKernelGGL(bn_bwd_partial_pool, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                           pmax, Rp, C, gp, pg);
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
+                           coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
+        const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * HW * C;
+#define RPNET_BN_POOL_BWD(NP_)                                                                                              \
+    hipLaunchKernelGGL(bn_bwd_apply_pool_split<NP_>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, \
+                       (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale)
+        if (planes == 3) RPNET_BN_POOL_BWD(3);
+        else if (planes == 2) RPNET_BN_POOL_BWD(2);
+        else RPNET_BN_POOL_BWD(1);
+#undef RPNET_BN_POOL_BWD
+        return check_launch("bn_bwd_pool");
+    }
     if (given_partial) {
         // the reduction pass already happened in the epilogue of the launch that produced dz (rpnet_conv_desc.bnb_*):
         // [groups * given_rows][C][2] sums (and [..][C] maxima for fp16 planes)

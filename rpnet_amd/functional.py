@@ -242,6 +242,8 @@ class BnRef:
 # the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
 # launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
 _BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
+# A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
+_POOL_FUSE = os.environ.get("RPNET_POOL_FUSE", "1") == "1"
 
 
 def as_operand(t):
@@ -577,18 +579,30 @@ class ConvBnRelu(Function):
         np_out = 0
         if out_split in (True, "corr") and cout % 32 == 0 and _MATH["planes"]:
             np_out = _MATH["f16_planes"] if want16 else _MATH["planes"]
-        zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.float16 if np_out <= 2 else torch.bfloat16) if np_out else None
+        # pool: BatchNorm + ReLU + MaxPool2d(2, 2) in one pass (the output feeds nothing but its pool): possible when this
+        # layer runs on split planes forward AND backward (its dy then exists as planes: the pooled backward writes those)
+        pool = bool(produced.get("pool")) and np_out > 0 and out_split is True and xs is not None and not first and \
+            H % 2 == 0 and W % 2 == 0 and pw.cin_pad % 64 == 0 and cout % 64 == 0 and x0.shape[-1] % 64 == 0
+        produced["pooled"] = pool
+        Hz, Wz = (H // 2, W // 2) if pool else (H, W)
+        if pool:
+            z = _empty((N, Hz, Wz, cout), x0)
+        zs = torch.empty((np_out, N, Hz, Wz, cout), device=x0.device, dtype=torch.float16 if np_out <= 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
-        if produced.get("z_unused") and want16 and np_out and out_split is True:
+        if produced.get("z_unused") and want16 and np_out and out_split is True and (pool or not produced.get("pool_req")):
             # the single consumer reads the fp16 planes: the fp32 form is never written, z is a zero-storage placeholder
-            # of the right shape for autograd
-            z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, H, W, cout)
+            # of the right shape for autograd (a pool request that could not be fused keeps the fp32 form: the separate
+            # max-pool reads it)
+            z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, Hz, Wz, cout)
             produced["planes_only"] = True
-            produced["bn_ref"] = BnRef(y, stats, groups)
+            if not pool:
+                produced["bn_ref"] = BnRef(y, stats, groups)
         # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
              np_out, ptr(gamma), ptr(beta),
-             ptr(sz) if want16 else None, N, H * W, cout, groups)
+             ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0)
+        if pool:
+            ARITH[("bn_relu", "with the 2x2 max-pool")] += 1
         if want16 and np_out:
             produced["p16"] = zs          # the next convolution's operand, produced here instead of by a separate pass
         elif zs is not None:
@@ -596,7 +610,7 @@ class ConvBnRelu(Function):
         if want16:
             produced["scale"] = sz
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
-        ctx.pw, ctx.cfg, ctx.eval_mode = pw, (groups, upsample, in_mode, first), False
+        ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
         ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
         ctx.src_bn = op0.bn_ref if (op0.planes_only and _BNBWD_FUSE) else None   # this layer as the single consumer
@@ -624,6 +638,8 @@ class ConvBnRelu(Function):
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
         sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ <= 2) else None   # fp16: tensor scale
         dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
+        if ctx.pool and (dys is None or dz.shape[1] * 2 != H):
+            raise RuntimeError("rpnet_amd: the pooled BatchNorm backward needs dy as split planes and the pooled gradient")
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
         # the reduction pass may already have run in the epilogue of the launch that produced dz (the single consumer's
@@ -639,7 +655,7 @@ class ConvBnRelu(Function):
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
              ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(gp), ptr(gm_), grows,
-             ptr(ws), wsb)
+             W if ctx.pool else 0, ptr(ws), wsb)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:
@@ -738,22 +754,30 @@ class ConvBnRelu(Function):
 
 
 def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
-                    out_split=True, z_unused=False):
+                    out_split=True, z_unused=False, pool=False):
     """Conv -> BatchNorm -> ReLU on Operands (tensors are wrapped: no planes, no bound); returns the output Operand.
     out_split: also write the output as the operand planes of its consumer (when the split arithmetic is on): True = a
     3x3 convolution reads it as is, "corr" = the local correlation, "scale" = no planes, only the fp16 tensor scale (a
     pooled / concatenated / masked 3x3 consumer splits the fp32 tensor itself), False = neither (1x1 consumers).
     z_unused: the caller guarantees that the ONLY consumer of the output is a 3x3 convolution that takes it as its single,
     unmasked source (conv_block's first layer): in train mode on fp16 planes the fp32 form is then not written at all
-    (a third of the launch's bytes) and the returned Operand is `planes_only`."""
+    (a third of the launch's bytes) and the returned Operand is `planes_only`.
+    pool: the caller wants MaxPool2d(2, 2) of the output and nothing else of it (net/unet.py:442-448): returns the POOLED
+    Operand — in train mode on split planes out of the BatchNorm + ReLU pass itself (rpnet_bn_relu(pool_w): the
+    full-resolution activation is never written, the backward finds the window maxima again from the conv output),
+    otherwise through the separate max-pool launch."""
     op0, op1 = as_operand(x0), as_operand(x1)
     pw = cache.get(conv.weight, split) if (conv.weight.shape[1] >= 32 or split is not None) else None
-    produced = {"z_unused": bool(z_unused) and training and conv.weight.shape[0] % 64 == 0}
+    produced = {"z_unused": bool(z_unused) and training and conv.weight.shape[0] % 64 == 0,
+                "pool": bool(pool) and training and _POOL_FUSE, "pool_req": bool(pool)}
     z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
                          1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
-    return Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")),
-                   produced.get("bn_ref"))
+    out = Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")),
+                  produced.get("bn_ref"))
+    if pool and not produced.get("pooled"):
+        out = maxpool2(out)
+    return out
 
 
 def conv_bn_relu(x0, conv, bn, cache, training, **kw):

@@ -56,9 +56,9 @@ _SIGS = {
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
     "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
-    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_bn_act_scale": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
-    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, cs, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp, cs, vp]),
     "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
     "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
     "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

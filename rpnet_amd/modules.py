@@ -62,13 +62,17 @@ class conv_block(nn.Module):
             nn.Conv2d(ch_out, ch_out, kernel_size=kernel, stride=1, padding=padding, bias=True),
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
-    def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True, split=None):
+    def forward_nhwc(self, x0, cache, x1=None, groups=1, out_split=True, split=None, pool=False):
         """RF.Operand (or tensor) in, RF.Operand out; out_split: whether a 3x3 convolution reads the block's output as is
         (RF.conv_bn_relu_op); split: channel ranges of the first layer's packed weight when its sources are padded
-        (RF.PackedWeight)"""
+        (RF.PackedWeight); pool: return MaxPool2d(2, 2) of the block's output instead of the output — the caller needs
+        nothing else of it, and the single consumer of the pooled tensor is an unmasked single-source 3x3 convolution"""
         t = self.training
         # the first layer's output feeds the second convolution and nothing else: on fp16 planes its fp32 form is not written
         x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=_ZSKIP, split=split)
+        if pool:
+            return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=True, z_unused=_ZSKIP,
+                                      pool=True)
         return RF.conv_bn_relu_op(x, self.conv[3], self.conv[4], cache, t, groups=groups, out_split=out_split)
 
     def forward(self, x):
@@ -159,22 +163,30 @@ class U_Net(Unet_2D):
         # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
         # scale per convolution), so those producers skip their own operand planes
         sk = "scale" if (RF.f16_mode() and self.training) else True
+        # x1 and x2 feed nothing but their pool (:442-448; x3 and x4 are also skip connections): in training the pooled
+        # tensor comes out of the block's last BatchNorm + ReLU pass (p1 / p2 are then already pooled) unless a mask
+        # channel is concatenated behind the pool
+        f1, f2 = self.training and mfm != "x2", self.training and mfm != "x3"
         if mfm == "x":      # cat([x, mask], 1) (net/unet.py:437-438): image and mask as channels 0 / 1 of a 64-channel source
             xin = torch.zeros(*x.shape[:3], 64, device=x.device, dtype=torch.float32)
             xin[..., 0], xin[..., 1] = x[..., 0], mask.float()
-            x1 = self.Conv1.forward_nhwc(xin, cache, groups=groups, out_split=sk, split=(2, 64, 64))
+            p1 = self.Conv1.forward_nhwc(xin, cache, groups=groups, out_split=sk, split=(2, 64, 64), pool=f1)
         else:
-            x1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk)
+            p1 = self.Conv1.forward_nhwc(x, cache, groups=groups, out_split=sk, pool=f1)
+        if not f1:
+            p1 = pool(p1)
         if mfm == "x2":     # cat([pool(x1), avg_pool2d(mask, 2)], 1) (:443-444) as two sources
-            x2 = self.Conv2.forward_nhwc(pool(x1), cache, x1=self._mask_source(mask.float(), 2), groups=groups, out_split=sk,
-                                         split=(64, 64, 128))
+            p2 = self.Conv2.forward_nhwc(p1, cache, x1=self._mask_source(mask.float(), 2), groups=groups, out_split=sk,
+                                         split=(64, 64, 128), pool=f2)
         else:
-            x2 = self.Conv2.forward_nhwc(pool(x1), cache, groups=groups, out_split=sk)
+            p2 = self.Conv2.forward_nhwc(p1, cache, groups=groups, out_split=sk, pool=f2)
+        if not f2:
+            p2 = pool(p2)
         if mfm == "x3":     # cat([pool(x2), avg_pool2d(mask, 4)], 1) (:448-449)
-            x3 = self.Conv3.forward_nhwc(pool(x2), cache, x1=self._mask_source(mask.float(), 4), groups=groups, out_split=sk,
+            x3 = self.Conv3.forward_nhwc(p2, cache, x1=self._mask_source(mask.float(), 4), groups=groups, out_split=sk,
                                          split=(128, 128, 192))
         else:
-            x3 = self.Conv3.forward_nhwc(pool(x2), cache, groups=groups, out_split=sk)
+            x3 = self.Conv3.forward_nhwc(p2, cache, groups=groups, out_split=sk)
         x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups, out_split=sk)
         x5 = self.Conv5.forward_nhwc(pool(x4), cache, groups=groups)
         d5 = self.Up5.forward_nhwc(x5, cache, groups=groups, out_split=sk)

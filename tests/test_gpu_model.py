@@ -254,6 +254,33 @@ def test_bn_bwd_reduction_in_dgrad_epilogue(monkeypatch):
         assert rel_l2(grads[True][n], gr) < 1e-5 or float(gr.abs().max()) < 1e-6, n
 
 
+@pytest.mark.parametrize("math", ["f16x2", "bf16x3", "f16"])
+def test_bn_relu_maxpool_in_one_pass(monkeypatch, math):
+    """rpnet_bn_relu(pool_w) / rpnet_bn_bwd(pool_w): x1 and x2 of the encoder feed nothing but their MaxPool2d(2, 2)
+    (net/unet.py:442-448), so in training the pooled operand planes come out of the BatchNorm + ReLU pass and the backward
+    finds the window maxima again from the conv output.  Same logits (bit-identical: max and ReLU commute) and the same
+    gradients as BatchNorm + ReLU, max-pool and operand split as three launches; two of the 25 BatchNorm passes take it."""
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    RM._F16_MIN_PIXELS = 0
+    RF.set_conv_math(math)
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(322, 4, 128, DEV)
+    grads, outs = {}, {}
+    for fuse in (False, True):
+        monkeypatch.setattr(RF, "_POOL_FUSE", fuse)
+        net = build(cfg, True)
+        RF.reset_arith()
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        total_loss(out, ql, 1.0).backward()
+        assert RF.arith_counts().get("bn_relu", {}) == ({"with the 2x2 max-pool": 2} if fuse else {}), RF.arith_counts()
+        outs[fuse] = out["output"].detach().clone()
+        grads[fuse] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert torch.equal(outs[True], outs[False])
+    for n, gr in grads[False].items():
+        assert rel_l2(grads[True][n], gr) < 1e-5 or float(gr.abs().max()) < 1e-6, n
+
+
 def test_five_shot_extension_vs_composed_oracle():
     """BASELINE config 3 shape class (multi-shot): no reference behaviour (net/rp_net.py:275,288
     raise for n_shots > 1); pinned by the oracle composed from the reference's own pieces."""
