@@ -206,6 +206,13 @@ int rpnet_conv1_stats_blocks(int N, int H, int W, int cout, int groups);
 size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cout);
 int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout,
                       void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+/* the same weight gradient straight from the gradient dz of the layer's BatchNorm + ReLU OUTPUT: dy is formed on the spot
+ * from dz, the pre-BatchNorm tensor y, stats [4][groups][cout] (scale, shift, mean, invstd of rpnet_bn_stats, contiguous) and
+ * coef [groups][cout][2] (rpnet_bn_bwd with dy == dy_split == NULL leaves it at workspace + rpnet_bn_bwd_coef_offset) —
+ * Conv1.conv.0 has no input gradient, so its dy has no other reader and the BatchNorm backward's apply pass is not run */
+int rpnet_conv1_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* coef, float* dw,
+                         int N, int H, int W, int cout, int groups, void* workspace, size_t workspace_bytes,
+                         rpnet_stream_t stream);
 
 /* ---------------------------------------------------------------------- BatchNorm
  * Train-mode nn.BatchNorm2d + nn.ReLU(inplace) (net/modules.py:48-49,51-52,68-69),
@@ -221,8 +228,11 @@ int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  *   rpnet_bn_bwd     given dz: dgamma, dbeta (summed over groups; accumulate != 0: added to what the
  *                    pointers hold, i.e. straight into the parameters' gradient buffers) and
  *                    dy = scale*(dz*[z>0] - mean(dz*[z>0]) - xhat*mean(dz*[z>0]*xhat)), in fp32 (dy, may be
- *                    NULL when dy_split is given) and / or as split-bf16 planes (dy_split, may be NULL). */
+ *                    NULL when dy_split is given) and / or as split-bf16 planes (dy_split, may be NULL); both NULL: the
+ *                    reduction pass only (dgamma, dbeta, coefficients: rpnet_bn_bwd_coef_offset). */
 size_t rpnet_bn_workspace_bytes(int C, int groups);
+/* byte offset, in rpnet_bn_bwd's workspace, of the coefficients coef [groups][C][2] = (mean(dz m), mean(dz m xhat)) */
+size_t rpnet_bn_bwd_coef_offset(int C, int groups);
 int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, long long* num_batches_tracked,
                    float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,

@@ -606,6 +606,10 @@ extern "C" size_t rpnet_bn_workspace_bytes(int C, int groups) {
            (size_t)C * sizeof(float);
 }
 
+extern "C" size_t rpnet_bn_bwd_coef_offset(int C, int groups) {
+    return (size_t)groups * rpnet::bn_max_blocks(C) * C * 2 * sizeof(double);
+}
+
 static int bn_check(const char* who, int N, int HW, int C, int groups) {
     using namespace rpnet;
     RPNET_REQUIRE(C % 4 == 0 && C / 4 <= 256, RPNET_ERR_SHAPE, "%s: C=%d must be a multiple of 4 and <= 1024", who, C);
@@ -718,8 +722,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
                             size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
-    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && (dy || dy_split) && dgamma && dbeta && workspace,
-                  RPNET_ERR_ARG, "bn_bwd: null pointer");
+    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && dgamma && dbeta && workspace, RPNET_ERR_ARG, "bn_bwd: null pointer");
     RPNET_REQUIRE(!dy_split || (planes >= 1 && planes <= 3 && C % 8 == 0), RPNET_ERR_SHAPE, "bn_bwd: split planes=%d C=%d",
                   planes, C);
     if (int rc = bn_check("bn_bwd", N, HW, C, groups)) return rc;
@@ -767,6 +770,9 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
     }
+    // dy == NULL and dy_split == NULL: reduction pass only — dgamma, dbeta and the coefficients (workspace +
+    // rpnet_bn_bwd_coef_offset) for a consumer that forms dy itself (rpnet_conv1_wgrad_bn)
+    if (!dy && !dy_split) return check_launch("bn_bwd");
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
     if (dy_split) {
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;

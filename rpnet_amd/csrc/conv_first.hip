@@ -81,24 +81,50 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// partial[blk][Cout][9]
+// partial[group][blk][Cout][9].  BN = true: dy is not read but made on the spot from the gradient dz of the layer's
+// BatchNorm + ReLU output, its pre-BatchNorm tensor y and the coefficients of rpnet_bn_bwd's reduction pass,
+// dy = scale (dz [z > 0] - c1 - xhat c2) — the 12 bytes per element of a separate apply pass (this layer has no input
+// gradient, so its dy has no other reader) become 4
+template <bool BN>
 __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ partial, int N, int H, int W, int Cout) {
+                                                            const float* __restrict__ ybn, const float* __restrict__ stats,
+                                                            const float* __restrict__ coef, float* __restrict__ partial,
+                                                            int N, int H, int W, int Cout, int groups) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][Cout][9]
     const int t = threadIdx.x;
     const int Q = Cout / 4, ppb = 256 / Q;
     const int q = t % Q, pl = t / Q;
+    const int g = blockIdx.y;
     float acc[9][4];
 #pragma unroll
     for (int a = 0; a < 9; ++a)
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[a][k] = 0.f;
-    const size_t M = (size_t)N * H * W;
+    const size_t Mg = (size_t)(N / groups) * H * W, p_lo = (size_t)g * Mg;
+    f32x4 sc = {}, sh = {}, mu = {}, is = {}, c1 = {}, c2 = {};
+    if (BN) {
+        const int GC = groups * Cout, o = g * Cout + q * 4;
+        sc = *reinterpret_cast<const f32x4*>(stats + o);
+        sh = *reinterpret_cast<const f32x4*>(stats + GC + o);
+        mu = *reinterpret_cast<const f32x4*>(stats + 2 * GC + o);
+        is = *reinterpret_cast<const f32x4*>(stats + 3 * GC + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c1[k] = coef[(o + k) * 2]; c2[k] = coef[(o + k) * 2 + 1]; }
+    }
     if (pl < ppb) {
-        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < M; p += (size_t)gridDim.x * ppb) {
+        for (size_t pg = (size_t)blockIdx.x * ppb + pl; pg < Mg; pg += (size_t)gridDim.x * ppb) {
+            const size_t p = p_lo + pg;
             const int ox = (int)(p % W), oy = (int)((p / W) % H);
             const size_t nb = p - (size_t)oy * W - ox;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * Cout + q * 4);
+            f32x4 gr = *reinterpret_cast<const f32x4*>(dy + p * Cout + q * 4);
+            if (BN) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ybn + p * Cout + q * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? gr[k] : 0.f;
+                    gr[k] = sc[k] * (dm - c1[k] - (v[k] - mu[k]) * is[k] * c2[k]);
+                }
+            }
 #pragma unroll
             for (int ky = -1; ky <= 1; ++ky)
 #pragma unroll
@@ -106,7 +132,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
                     const int iy = oy + ky, ix = ox + kx;
                     const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[nb + (size_t)iy * W + ix] : 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[(ky + 1) * 3 + kx + 1][k] += xv * g[k];
+                    for (int k = 0; k < 4; ++k) acc[(ky + 1) * 3 + kx + 1][k] += xv * gr[k];
                 }
         }
 #pragma unroll
@@ -118,7 +144,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
     for (int i = t; i < Cout * 9; i += 256) {
         float s = 0.f;
         for (int r = 0; r < ppb; ++r) s += red[r * Cout * 9 + i];
-        partial[(size_t)blockIdx.x * Cout * 9 + i] = s;
+        partial[((size_t)g * gridDim.x + blockIdx.x) * Cout * 9 + i] = s;
     }
 }
 
@@ -170,19 +196,40 @@ extern "C" size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cou
     return (size_t)rpnet::kConv1WgradBlocks * cout * 9 * sizeof(float);
 }
 
-extern "C" int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout, void* workspace,
-                                 size_t workspace_bytes, rpnet_stream_t stream) {
+static int conv1_wgrad_launch(const float* x, const float* dy, const float* ybn, const float* stats, const float* coef, float* dw,
+                              int N, int H, int W, int cout, int groups, void* workspace, size_t workspace_bytes,
+                              rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(x && dy && dw && workspace, RPNET_ERR_ARG, "conv1_wgrad: null pointer");
     RPNET_REQUIRE(cout % 4 == 0 && cout <= 256 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_wgrad: cout=%d", cout);
+    RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "conv1_wgrad: N=%d groups=%d", N, groups);
     RPNET_REQUIRE(workspace_bytes >= rpnet_conv1_wgrad_workspace_bytes(N, H, W, cout), RPNET_ERR_WORKSPACE, "conv1_wgrad: workspace");
     const int ppb = 256 / (cout / 4);
-    const size_t M = (size_t)N * H * W;
-    int nb = (int)((M + ppb - 1) / ppb);
-    if (nb > kConv1WgradBlocks) nb = kConv1WgradBlocks;
+    const size_t Mg = (size_t)(N / groups) * H * W;
+    int nb = (int)((Mg + ppb - 1) / ppb);
+    if (nb > kConv1WgradBlocks / groups) nb = kConv1WgradBlocks / groups;
+    if (nb < 1) nb = 1;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv1_wgrad_partial, dim3(nb), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
-                       (float*)workspace, N, H, W, cout);
-    hipLaunchKernelGGL(conv1_wgrad_final, dim3(cout * 9), dim3(64), 0, s, (const float*)workspace, dw, nb, cout * 9);
+    if (ybn)
+        hipLaunchKernelGGL(conv1_wgrad_partial<true>, dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
+                           ybn, stats, coef, (float*)workspace, N, H, W, cout, groups);
+    else
+        hipLaunchKernelGGL(conv1_wgrad_partial<false>, dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, N, H, W, cout, groups);
+    hipLaunchKernelGGL(conv1_wgrad_final, dim3(cout * 9), dim3(64), 0, s, (const float*)workspace, dw, nb * groups, cout * 9);
     return check_launch("conv1_wgrad");
+}
+
+extern "C" int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int cout, void* workspace,
+                                 size_t workspace_bytes, rpnet_stream_t stream) {
+    return conv1_wgrad_launch(x, dy, nullptr, nullptr, nullptr, dw, N, H, W, cout, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rpnet_conv1_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* coef,
+                                    float* dw, int N, int H, int W, int cout, int groups, void* workspace,
+                                    size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(y && stats && coef, RPNET_ERR_ARG, "conv1_wgrad_bn: null pointer");
+    RPNET_REQUIRE(groups <= kConv1WgradBlocks, RPNET_ERR_SHAPE, "conv1_wgrad_bn: groups=%d", groups);
+    return conv1_wgrad_launch(x, dz, y, stats, coef, dw, N, H, W, cout, groups, workspace, workspace_bytes, stream);
 }

@@ -244,6 +244,8 @@ class BnRef:
 _BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
 # A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
 _POOL_FUSE = os.environ.get("RPNET_POOL_FUSE", "1") == "1"
+# A/B switch: the BatchNorm-backward apply pass of Conv1.conv.0 inside its direct weight gradient (rpnet_conv1_wgrad_bn)
+_CONV1_BN_FUSE = os.environ.get("RPNET_CONV1_BN_FUSE", "1") == "1"
 
 
 def as_operand(t):
@@ -638,6 +640,11 @@ class ConvBnRelu(Function):
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
         sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ <= 2) else None   # fp16: tensor scale
         dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
+        # Conv1.conv.0 (Cin = 1) has no input gradient: its direct weight gradient forms dy itself from dz, y and the
+        # coefficients of the reduction pass, so the apply pass (12 bytes per element of the largest tensor) is not run
+        fuse1 = first and _CONV1_BN_FUSE and stats.is_contiguous()
+        if fuse1:
+            dy = None
         if ctx.pool and (dys is None or dz.shape[1] * 2 != H):
             raise RuntimeError("rpnet_amd: the pooled BatchNorm backward needs dy as split planes and the pooled gradient")
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
@@ -661,7 +668,12 @@ class ConvBnRelu(Function):
         if first:
             wb = query("rpnet_conv1_wgrad_workspace_bytes", N, H, W, cout)
             ws2 = _ws(wb, y)
-            call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
+            if fuse1:
+                coef = ws.data_ptr() + query("rpnet_bn_bwd_coef_offset", cout, groups)
+                call("rpnet_conv1_wgrad_bn", ptr(x0), ptr(dz), ptr(y), ptr(stats), coef, ptr(dw), N, H, W, cout, groups,
+                     ptr(ws2), wb)
+            else:
+                call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
         else:
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)

@@ -53,6 +53,8 @@ _SIGS = {
     "rpnet_pow2_scale": (ci, [vp, vp, vp]),
     "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_conv1_wgrad_bn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_bn_bwd_coef_offset": (cs, [ci, ci]),
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
     "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),

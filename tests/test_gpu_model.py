@@ -281,6 +281,30 @@ def test_bn_relu_maxpool_in_one_pass(monkeypatch, math):
         assert rel_l2(grads[True][n], gr) < 1e-5 or float(gr.abs().max()) < 1e-6, n
 
 
+def test_conv1_weight_gradient_from_bn_output_gradient(monkeypatch):
+    """rpnet_conv1_wgrad_bn: Conv1.conv.0 (Cin = 1, no input gradient) forms dy inside its direct weight gradient from dz,
+    y and the coefficients of rpnet_bn_bwd's reduction pass (dy == dy_split == NULL) instead of reading the output of a
+    separate apply pass: same gradients (two BatchNorm groups, so both coefficient rows are exercised)."""
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    RM._F16_MIN_PIXELS = 0
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(323, 2, 64, DEV)
+    grads = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(RF, "_CONV1_BN_FUSE", fuse)
+        net = build(cfg, True)
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        total_loss(out, ql, 1.0).backward()
+        grads[fuse] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for n, gr in grads[False].items():
+        tol = 1e-5 if n.startswith("encoder.Conv1.conv.0") or n.startswith("encoder.Conv1.conv.1") else 0.0
+        if tol:
+            assert rel_l2(grads[True][n], gr) < tol or float(gr.abs().max()) < 1e-6, n
+        else:
+            assert torch.equal(grads[True][n], gr), n
+
+
 def test_five_shot_extension_vs_composed_oracle():
     """BASELINE config 3 shape class (multi-shot): no reference behaviour (net/rp_net.py:275,288
     raise for n_shots > 1); pinned by the oracle composed from the reference's own pieces."""
