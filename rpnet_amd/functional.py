@@ -545,6 +545,10 @@ class ConvBnRelu(Function):
             if op0.planes_only and not (f16 is not None and op1 is None and in_scale is None and pw.cin % 64 == 0 and cout % 64 == 0):
                 raise RuntimeError("rpnet_amd: a planes-only operand (conv_bn_relu_op(z_unused=True)) reached a convolution "
                                    "that cannot run forward AND weight gradient from its fp16 planes")
+            if op1 is not None and op1.planes_only and not (f16 is not None and f16[1] is op1.p16 and pw.cin_pad % 64 == 0
+                                                            and cout % 64 == 0 and x0.shape[-1] % 64 == 0):
+                raise RuntimeError("rpnet_amd: a planes-only second source reached a convolution that does not read its "
+                                   "fp16 planes as they are (forward and weight gradient)")
             if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
                 xs, sx, sx1 = (f16[0], f16[1]), f16[2], f16[3]
                 fp = _MATH["f16_planes"]
@@ -591,13 +595,13 @@ class ConvBnRelu(Function):
             z = _empty((N, Hz, Wz, cout), x0)
         zs = torch.empty((np_out, N, Hz, Wz, cout), device=x0.device, dtype=torch.float16 if np_out <= 2 else torch.bfloat16) if np_out else None
         sz = torch.empty(1, device=x0.device, dtype=torch.float32) if want16 else None
-        if produced.get("z_unused") and want16 and np_out and out_split is True and (pool or not produced.get("pool_req")):
+        if produced.get("z_unused") and want16 and np_out and out_split in (True, "corr") and (pool or not produced.get("pool_req")):
             # the single consumer reads the fp16 planes: the fp32 form is never written, z is a zero-storage placeholder
             # of the right shape for autograd (a pool request that could not be fused keeps the fp32 form: the separate
             # max-pool reads it)
             z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, Hz, Wz, cout)
             produced["planes_only"] = True
-            if not pool:
+            if not pool and out_split is True:
                 produced["bn_ref"] = BnRef(y, stats, groups)
         # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
         call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
@@ -1037,7 +1041,7 @@ def local_corr(f1, f2, r):
     o1, o2 = as_operand(f1), as_operand(f2)
     produced = {}
     corr, alias = LocalCorr.apply(o1.x, o2.x, r, (o1, o2), produced)
-    return Operand(corr, produced.get("p16"), None, produced.get("scale")), Operand(alias, o1.p16, o1.pbf, o1.scale)
+    return Operand(corr, produced.get("p16"), None, produced.get("scale")), Operand(alias, o1.p16, o1.pbf, o1.scale, o1.planes_only)
 
 
 # ------------------------------------------------------------------------ matcher

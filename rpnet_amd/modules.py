@@ -285,13 +285,18 @@ class ContextCorrelationEncoder(nn.Module):
         m1, m2 = (1, 2) if mask is not None else (0, 0)
         sp = "corr" if self.radius == 5 else False       # the correlation then takes the split planes of fm1 / fm2
         # fts_scale: the fp16 tensor scale of the features (their producer's bound; slicing / fan-out keeps it)
+        # fm1 / fm2 feed the correlation and (fm1) the 1x1 convolution, both of which read fp16 planes in f16x2 / f16
+        # training: their fp32 form is then never written (RF.conv_bn_relu_op(z_unused); a consumer that wanted the
+        # values would raise)
+        zu = _ZSKIP and sp == "corr" and RF._CORR16 and RF._CONV1X1_SPLIT
+
         def w_k():
             return RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask,
-                                      in_mode=m1, out_split=sp)
+                                      in_mode=m1, out_split=sp, z_unused=zu)
 
         def w_q():
             return RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale), self.w_q[0], self.w_q[1], cache, t, in_scale=mask,
-                                      in_mode=m2, out_split=sp)
+                                      in_mode=m2, out_split=sp, z_unused=zu)
 
         # inference on a few slices (test_rpnet.py: 2 per call): either convolution is 256 four-wave blocks of a machine
         # that holds 512 — the two are independent, so w_q runs on the side stream beside w_k (one block of each per CU)
