@@ -178,6 +178,10 @@ int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
 /* partial-statistic rows per group rpnet_conv_fwd writes for this descriptor (0: this shape cannot
  * fuse them — a group does not split into whole tiles — use rpnet_bn_stats on the output instead) */
 int rpnet_conv_stats_blocks(const rpnet_conv_desc* d);
+/* which tile variant of the split kernels rpnet_conv_fwd launches for this descriptor (incl. its `tune` override; -1 for
+ * fp32 operands): 0-3 plain split implicit GEMM, 7 the 8-wave patch kernel, 8-10 the 4-wave patch kernels, 11 the LDS-DMA
+ * patch kernel (conv_split_dma.hip).  Tests use it to assert that a forced variant actually ran. */
+int rpnet_conv_tile_variant(const rpnet_conv_desc* d);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dW[cout][cin][kh][kw] = sum_pixels A[pixel+tap][cin] * dy[pixel][cout], A gathered

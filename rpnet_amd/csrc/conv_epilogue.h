@@ -1,6 +1,19 @@
-// Epilogue shared by the implicit-GEMM convolution kernels (fp32-MFMA and split-bf16 variants):
+// Epilogue shared by the implicit-GEMM convolution kernels (fp32-MFMA and split-plane variants):
 // the accumulators of a (32*WGM*WM) x (64*WN) block tile held by WGM x 2 waves, each wave WM x WN
 // MFMA tiles of 32x32 in the C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+//
+// Round 3: rebuilt around what an epilogue costs on this machine.  Measured on the 256 x 128 patch kernels
+// (tools/bench_conv_split.py, DBG=2 ablation of tile variant 11): the round-2 epilogue took 32 us of a 194 us launch
+// (512 -> 512, one tile per CU) and 128 of the 306 us of the four-tiles-per-CU 128 -> 128 layer — a lane owns ONE column
+// of the MFMA tile, so the output left as 4-byte stores (128 per thread for a 128 x 64 wave tile: the store tail is bound
+// by instruction issue, cdna_hip_programming.md T21), every element walked a chain of data-independent branches (row
+// validity, eval affine, row factor, accumulate) with its group index from an integer division, and writing the final
+// value back into the accumulator array moved whole 16-register tiles between the accumulator and vector files.
+// Now: column-wise work (power-of-two scales, bias, eval affine, ReLU, BatchNorm statistics) happens in the MFMA layout
+// with per-column constants in registers; each wave then turns its 32-row tiles through a private LDS slab so that a
+// lane holds 4 consecutive channels of ONE pixel: row-wise work (mask factor, accumulate, max |value|) happens there and
+// the output leaves as 16-byte stores — a quarter of the store instructions, no per-element branches (the feature set is
+// resolved once per launch into one of four instantiations).
 #pragma once
 #include "common.h"
 #include "split_bf16.h"
@@ -9,16 +22,18 @@ namespace rpnet {
 
 // block-local accumulator row -> output pixel (linear NHW index), or -1 when the row is past the tensor
 struct LinearRows {   // the block's rows are consecutive pixels m0, m0 + 1, ...
+    static constexpr bool kAlwaysValid = false;
     int m0, M;
     __device__ __forceinline__ int operator()(int local) const { const int r = m0 + local; return r < M ? r : -1; }
 };
 template <int TW>
 struct PatchRows {    // the block's rows walk a (rows / TW) x TW patch of one image, row-major
+    static constexpr bool kAlwaysValid = true;
     int base, W;      // linear index of the patch's top-left pixel
     __device__ __forceinline__ int operator()(int local) const { return base + (local / TW) * W + (local % TW); }
 };
 
-// LDS bytes the epilogue may use (statistics reduction; per-wave 32-row slabs of the split output)
+// LDS bytes the epilogue may use (statistics reduction; per-wave 32-row slabs of the output)
 template <int WN, int WGM>
 constexpr int epilogue_lds_bytes() {
     constexpr int stats = WGM * 64 * WN * (2 * 8 + 4), slabs = WGM * 2 * 32 * (WN * 32 + 4) * 4;   // (sum, sumsq) doubles + a max
@@ -26,15 +41,124 @@ constexpr int epilogue_lds_bytes() {
 }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// WIDE: 16-byte output stores through a per-wave LDS transpose (below).  Measured A/B on one box: +4.5 % on the configs[4]
-// step (one fp16 plane: 94.8 / 95.0 vs 90.8 / 90.8 pairs/s, conv launches 715 vs 638 TF — a third of the matrix work, so the
-// store tail is a larger share of a launch), -0.6 % on the f16x2 headline step (377.5 / 377.9 / 373.6 vs 379.4 / 379.9 /
-// 378.0): the kernels instantiate it for one plane only.
+// Output of one wave's tiles.  AFF: eval-mode affine (+ ReLU) per (statistic group, column) — the group of a row is looked
+// up per row only when the block's rows may straddle groups (LinearRows); ROWOPS: any of row factor / accumulate /
+// max |value| / planes of the output.
+template <int WM, int WN, typename RowMap, bool AFF, bool ROWOPS>
+__device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows, const int M,
+                                                     const int Cout, const int per_group, const int n0, const int wm,
+                                                     const int wn, const int li, const int h, float* slab) {
+    constexpr int SW = WN * 32 + 4;
+    const int lane = li + 32 * h;
+    const int colbase = n0 + wn * WN * 32;
+    const float xs = d.acc_scale_x ? *d.acc_scale_x : 1.f;     // fp16 split operands: power-of-two tensor / row scales
+    float* dstb;
+    int Cd, cd0;
+    if (colbase < d.Co0) { dstb = d.y0; Cd = d.Co0; cd0 = colbase; } else { dstb = d.y1; Cd = d.Co1; cd0 = colbase - d.Co0; }
+    float asv[WN], bvv[WN], es[WN], eh[WN];
+    // one statistic group for the whole block tile (always so for image patches; for consecutive pixels when the tile does
+    // not cross a group boundary): the affine of that group sits in registers
+    const int r_first = rows(wm * WM * 32), r_last = rows(wm * WM * 32 + WM * 32 - 1);
+    const int g0 = (r_first >= 0 ? r_first : 0) / per_group;
+    const bool one_group = !AFF || !d.ep_scale || RowMap::kAlwaysValid || (r_last >= 0 && r_last / per_group == g0);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = colbase + j * 32 + li;
+        bvv[j] = d.bias ? d.bias[col] : 0.f;
+        asv[j] = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
+        es[j] = 1.f;
+        eh[j] = 0.f;
+        if (AFF && d.ep_scale) {
+            es[j] = d.ep_scale[g0 * Cout + col];
+            eh[j] = d.ep_shift[g0 * Cout + col];
+        }
+    }
+    float amax = 0.f;
+    unsigned short* ys = reinterpret_cast<unsigned short*>(d.y_split);
+    const size_t yplane = (size_t)M * Cout;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        // ---- MFMA layout -> slab: column-wise work
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float v = acc[i][j][r] * asv[j] + bvv[j];
+                if (AFF) {
+                    if (one_group) v = v * es[j] + eh[j];
+                    else {
+                        const int row = rows(wm * WM * 32 + i * 32 + rl);
+                        const int g = (row >= 0 ? row : 0) / per_group;
+                        const int col = colbase + j * 32 + li;
+                        v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];
+                    }
+                    if (d.ep_relu) v = fmaxf(v, 0.f);
+                }
+                slab[rl * SW + j * 32 + li] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();               // the slab is private to the wave: LDS ops of one wave complete in order
+        // ---- slab -> memory: a lane holds 4 consecutive channels of one pixel
+#pragma unroll
+        for (int q = 0; q < WN * 4; ++q) {
+            const int gidx = q * 64 + lane;            // (row, 4-channel group) of the 32 x (WN * 32) tile
+            const int rr = gidx / (WN * 8), c4 = gidx - rr * (WN * 8);
+            const int row = rows(wm * WM * 32 + i * 32 + rr);
+            if (RowMap::kAlwaysValid || row >= 0) {
+                f32x4 v4 = *reinterpret_cast<const f32x4*>(&slab[rr * SW + c4 * 4]);
+                f32x4* p = reinterpret_cast<f32x4*>(dstb + (size_t)row * Cd + cd0 + c4 * 4);
+                if (ROWOPS) {
+                    if (d.out_scale_mode) {
+                        float s = d.out_scale[row];
+                        if (d.out_scale_mode == 2) s = 1.f - s;
+                        v4 *= s;
+                    }
+                    if (d.accumulate) v4 += *p;
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v4[0]), fabsf(v4[1]))), fmaxf(fabsf(v4[2]), fabsf(v4[3])));
+                    if (d.y_split) *reinterpret_cast<f32x4*>(&slab[rr * SW + c4 * 4]) = v4;      // the planes below take the final values
+                }
+                *p = v4;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ROWOPS && d.y_split) {
+            // the output also as split planes (the operand format of the next convolution; eval mode): a lane holds 8
+            // consecutive channels of a pixel = one 16-byte store per plane
+#pragma unroll
+            for (int q = 0; q < 2 * WN; ++q) {
+                const int gidx = q * 64 + lane;        // (row, 8-channel group) of the 32 x (WN * 32) tile
+                const int rr = gidx / (WN * 4), cg = gidx - rr * (WN * 4);
+                const int row = rows(wm * WM * 32 + i * 32 + rr);
+                if (RowMap::kAlwaysValid || row >= 0) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8]);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8 + 4]);
+                    const float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    const size_t o = (size_t)row * Cout + colbase + cg * 8;
+                    if (d.split_out_planes == 3) {
+                        u32x4 pl[3];
+                        split8<3>(v8, pl);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(ys + p * yplane + o) = pl[p];
+                    } else {
+                        u32x4 pl[2];
+                        split8<2>(v8, pl);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * yplane + o) = pl[p];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    return amax;
+}
+
+// WIDE (template argument kept for the call sites of round 2): every instantiation stores 16 bytes per lane now.
 template <int WM, int WN, int WGM = 2, typename RowMap = LinearRows, bool WIDE = false>
 __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows,
                                               const int M, const int Cout, const int HW, const int n0, const int tm,
                                               const int wm, const int wn, const int li, const int h, void* lds) {
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
     const float xs = d.acc_scale_x ? *d.acc_scale_x : 1.f;     // fp16 split operands: power-of-two tensor / row scales
     if (d.stats_partial) {
@@ -46,6 +170,12 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
         constexpr int BNC = 64 * WN;
         double* red = reinterpret_cast<double*>(lds);     // [WGM][BNC][2]
         __syncthreads();                                   // every wave is done with the staging memory
+        bool valid[WM][16];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                valid[i][r] = RowMap::kAlwaysValid || rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) >= 0;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn * WN * 32 + j * 32 + li;
@@ -58,8 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    const double v = row >= 0 ? (double)(acc[i][j][r] * as + bv) : 0.0;
+                    const double v = valid[i][r] ? (double)(acc[i][j][r] * as + bv) : 0.0;
                     sm += v;
                     sq += v * v;
                 }
@@ -79,121 +208,33 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             d.stats_partial[((size_t)tm * Cout + n0) * 2 + e] = sacc;
         }
     }
+    __syncthreads();                                       // staging memory / statistics reduction: every wave is done with it
+    float* slab = reinterpret_cast<float*>(lds) + (size_t)(wm * 2 + wn) * 32 * (WN * 32 + 4);
+    const bool aff = d.ep_scale != nullptr || d.ep_relu != 0;
+    const bool rowops = d.out_scale_mode != 0 || d.accumulate != 0 || d.out_absmax != nullptr || d.y_split != nullptr;
     float amax = 0.f;
-    if constexpr (WIDE) {
-        // Output.  In the MFMA layout a lane owns ONE column and 16 rows per tile, i.e. 4-byte stores (64 per thread for a
-        // 64 x 64 wave tile): the store tail is bound by instruction issue, not by bytes.  Each wave therefore turns its 32-row
-        // tiles through a private LDS slab so that a lane holds 4 consecutive channels of a pixel: 16-byte stores, a quarter of
-        // the store instructions for the same bytes and addresses.
-        {
-            constexpr int SW = WN * 32 + 4;
-            float* slab = reinterpret_cast<float*>(lds) + (size_t)(wm * 2 + wn) * 32 * SW;
-            const int lane = li + 32 * h;
-            const int colbase = n0 + wn * WN * 32;
-            float* dstb; int Cd, cd0;
-            if (colbase < d.Co0) { dstb = d.y0; Cd = d.Co0; cd0 = colbase; } else { dstb = d.y1; Cd = d.Co1; cd0 = colbase - d.Co0; }
-            float asv[WN], bvv[WN];
-    #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int col = colbase + j * 32 + li;
-                bvv[j] = d.bias ? d.bias[col] : 0.f;
-                asv[j] = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
-            }
-            __syncthreads();                                   // staging memory / statistics reduction: every wave is done with it
-    #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int row = rows(wm * WM * 32 + i * 32 + rl);
-                    float osc = 1.f;
-                    if (d.out_scale_mode && row >= 0) {
-                        osc = d.out_scale[row];
-                        if (d.out_scale_mode == 2) osc = 1.f - osc;
-                    }
-    #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        float v = acc[i][j][r] * asv[j] + bvv[j];
-                        if (d.ep_scale) {
-                            const int col = colbase + j * 32 + li;
-                            const int g = (row >= 0 ? row : 0) / per_group;
-                            v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];
-                        }
-                        if (d.ep_relu) v = fmaxf(v, 0.f);
-                        v *= osc;
-                        if (row < 0) v = 0.f;
-                        acc[i][j][r] = v;
-                        amax = fmaxf(amax, fabsf(v));
-                        slab[rl * SW + j * 32 + li] = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();               // the slab is private to the wave: LDS ops of one wave complete in order
-    #pragma unroll
-                for (int q = 0; q < WN * 4; ++q) {
-                    const int gidx = q * 64 + lane;            // (row, 4-channel group) of the 32 x (WN * 32) tile
-                    const int rr = gidx / (WN * 8), c4 = gidx - rr * (WN * 8);
-                    const int row = rows(wm * WM * 32 + i * 32 + rr);
-                    if (row >= 0) {
-                        f32x4 v4 = *reinterpret_cast<const f32x4*>(&slab[rr * SW + c4 * 4]);
-                        f32x4* p = reinterpret_cast<f32x4*>(dstb + (size_t)row * Cd + cd0 + c4 * 4);
-                        if (d.accumulate) v4 += *p;
-                        *p = v4;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            __syncthreads();                                   // the sections below reuse the memory across waves
-        }
-    } else {
-    #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wn * WN * 32 + j * 32 + li;
-            const float bv = d.bias ? d.bias[col] : 0.f;
-            const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
-            float* dst; int Cd, cd;
-            if (col < d.Co0) { dst = d.y0; Cd = d.Co0; cd = col; } else { dst = d.y1; Cd = d.Co1; cd = col - d.Co0; }
-    #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    if (row >= 0) {
-                        float v = acc[i][j][r] * as + bv;
-                        if (d.ep_scale) {
-                            const int g = row / per_group;
-                            v = v * d.ep_scale[g * Cout + col] + d.ep_shift[g * Cout + col];
-                        }
-                        if (d.ep_relu) v = fmaxf(v, 0.f);
-                        if (d.out_scale_mode) {
-                            float s = d.out_scale[row];
-                            if (d.out_scale_mode == 2) s = 1.f - s;
-                            v *= s;
-                        }
-                        float* p = dst + (size_t)row * Cd + cd;
-                        if (d.accumulate) v += *p;
-                        *p = v;
-                        acc[i][j][r] = v;
-                        amax = fmaxf(amax, fabsf(v));
-                    }
-                }
-            }
-        }
-    }
+    if (!aff && !rowops) conv_epilogue_store<WM, WN, RowMap, false, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
+    else if (!aff) amax = conv_epilogue_store<WM, WN, RowMap, false, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
+    else if (!rowops) conv_epilogue_store<WM, WN, RowMap, true, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
+    else amax = conv_epilogue_store<WM, WN, RowMap, true, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
     if (d.bnb_y) {
         // This launch is the input gradient dz of a layer whose source is the output of a train-mode BatchNorm + ReLU with
         // no other consumer: the reduction pass of THAT BatchNorm's backward (sum dz m, sum dz m xhat, max |dz m| per
         // channel; m = its ReLU mask, xhat its normalised pre-activation, both recomputed from its saved y) happens here,
         // on the tile that is still in registers, instead of in a separate pass over dz and y (rpnet_bn_bwd given_partial).
         // One row per block tile, as the forward statistics; tiles never straddle a statistic group (host-checked).
+        // (single destination, no row factor / accumulate / eval affine: dz = acc * scale + bias)
         constexpr int BNC = 64 * WN;
         double* red = reinterpret_cast<double*>(lds);                       // [WGM][BNC][2]
         float* redm = reinterpret_cast<float*>(red + WGM * BNC * 2);       // [WGM][BNC]
-        __syncthreads();                                   // every wave is done with the staging memory
+        __syncthreads();                                   // every wave is done with its slab
         const int G = d.bnb_groups, gper = (d.N / G) * HW;
         const int g = rows(0) / gper;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn * WN * 32 + j * 32 + li;
+            const float bv = d.bias ? d.bias[col] : 0.f;
+            const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
             const float sc = d.bnb_stats[(0 * G + g) * Cout + col], sh = d.bnb_stats[(1 * G + g) * Cout + col];
             const float mu = d.bnb_stats[(2 * G + g) * Cout + col], is = d.bnb_stats[(3 * G + g) * Cout + col];
             double s1 = 0.0, s2 = 0.0;
@@ -205,7 +246,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
                     const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
                     if (row >= 0) {
                         const float yv = d.bnb_y[(size_t)row * Cout + col];
-                        const float dm = (yv * sc + sh > 0.f) ? acc[i][j][r] : 0.f;
+                        const float dm = (yv * sc + sh > 0.f) ? acc[i][j][r] * as + bv : 0.f;
                         s1 += dm;
                         s2 += (double)dm * ((yv - mu) * is);
                         mx = fmaxf(mx, fabsf(dm));
@@ -235,53 +276,11 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
             d.bnb_partial[((size_t)tm * Cout + n0 + e) * 2 + 1] = a2;
             if (d.bnb_pmax) d.bnb_pmax[(size_t)tm * Cout + n0 + e] = m;
         }
-        __syncthreads();                                   // out_absmax / y_split below may reuse the memory
     }
     if (d.out_absmax) {      // max |output| of the launch: one order-independent atomic per wave (values >= 0: uint order = float order)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(d.out_absmax), __float_as_uint(amax));
-    }
-    if (d.y_split) {
-        // the output also as split-bf16 planes (the operand format of the next convolution; eval mode, where the
-        // BatchNorm affine + ReLU are applied right here): each wave turns its 32-row MFMA tiles through a private
-        // LDS slab so that a lane holds 8 consecutive channels of a pixel = one 16-byte store per plane
-        constexpr int SW = WN * 32 + 4;
-        float* slab = reinterpret_cast<float*>(lds) + (size_t)(wm * 2 + wn) * 32 * SW;
-        unsigned short* ys = reinterpret_cast<unsigned short*>(d.y_split);
-        const size_t plane = (size_t)M * Cout;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * h) * SW + j * 32 + li] = acc[i][j][r];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 2 * WN; ++q) {
-                const int gidx = q * 64 + h * 32 + li;            // (row, 8-channel group) of the 32 x (WN*32) tile
-                const int rr = gidx / (WN * 4), cg = gidx - rr * (WN * 4);
-                const int row = rows(wm * WM * 32 + i * 32 + rr);
-                if (row >= 0) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8]);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8 + 4]);
-                    const float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                    const size_t o = (size_t)row * Cout + n0 + wn * WN * 32 + cg * 8;
-                    if (d.split_out_planes == 3) {
-                        u32x4 pl[3];
-                        split8<3>(v8, pl);
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(ys + p * plane + o) = pl[p];
-                    } else {
-                        u32x4 pl[2];
-                        split8<2>(v8, pl);
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * plane + o) = pl[p];
-                    }
-                }
-            }
-        }
     }
 }
 

@@ -249,6 +249,11 @@ extern "C" int rpnet_conv_stats_blocks(const rpnet_conv_desc* d) {
     return (int)(per_group / bm);        // one partial row per block tile (the wave rows are summed in the epilogue)
 }
 
+extern "C" int rpnet_conv_tile_variant(const rpnet_conv_desc* d) {
+    if (!d || !d->split_planes) return -1;
+    return rpnet::choose_tile_split(d, d->N * d->H * d->W, d->Co0 + d->Co1);
+}
+
 extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(d && d->x0 && d->w && d->y0, RPNET_ERR_ARG, "conv_fwd: null pointer");

@@ -887,6 +887,7 @@ static const SplitVariant kSplitVariants[] = {
     {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
     {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
     {2, 4, 2, 0, 512},    // 10: 256 x 128 on an image patch with FOUR waves (wave tile 128 x 64), two blocks per CU
+    {2, 4, 2, 0, 256},    // 11: 256 x 128 on an image patch, four waves (one per SIMD), operands by LDS-DMA (conv_split_dma.hip)
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -915,12 +916,16 @@ static int halo4_tw(const rpnet_conv_desc* d) {
     return 0;
 }
 
+// conv_split_dma.hip
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, hipStream_t s);
+
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
-        const int v = d->tune - 1;
-        if (((v == 7 || (v == 10 && d->split_planes <= 2)) && halo_tw(d, Cout) && halo_bn(d, Cout) == 128) ||
+        const int v = (d->tune & 0xff) - 1;      // bits 8..: ablation switches of conv_split_dma.hip
+        if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2)) && halo_tw(d, Cout) &&
+             halo_bn(d, Cout) == 128) ||
             ((v == 8 || v == 9) && halo4_tw(d)))
             return v;
         if (v >= 0 && v < 4 && (kSplitVariants[v].wn == 1 || n128)) return v;
@@ -967,6 +972,7 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);
         case 2: return launch_split<2, 1, 2, false>(d, M, Cin, Cout, s);
         case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
+        case 11: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), s);
         case 10:
             return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:

@@ -1,0 +1,321 @@
+// 3x3 convolution (forward / input gradient) on fp16 split planes — the patch kernel of conv_split.hip rebuilt around the
+// LDS-DMA path of gfx950 (buffer_load_dwordx4 ... lds) with ONE wave per SIMD.
+//
+// What the 8-wave patch kernel (conv_igemm_split_halo_kernel) spends outside its MFMAs (profiles/r02_pmc_sq_wave_cycles.txt:
+// 36 % of the wave cycles parked on s_waitcnt / the barrier of every K-step): operand tiles travel HBM -> VGPR -> LDS, so
+// every K-step ends in a barrier BEHIND which the fragment reads of the next step start from cold, and the staging
+// registers (halo waiting for nine taps, weight slab) cap the wave tile at 64 x 64.  Here:
+//   * block = 256 output pixels (a (256 / TW) x TW patch of one image) x 128 output channels, FOUR waves (2 x 2), wave
+//     tile 128 x 64: 12 ds_read_b128 per 24 MFMAs instead of 8 per 12, one wave per SIMD with the whole 512-register file;
+//   * no staging registers and no ds_write: the input halo of the patch (two buffers: the next channel chunk lands while
+//     the nine taps of the current one are multiplied) and the weight slabs (ring of four K-steps) are written by the
+//     DMA engine.  The LDS image is lane-linear per DMA instruction, so the XOR swizzle of the k-groups that keeps the
+//     b128 fragment reads conflict-free is applied to the per-lane SOURCE address (cdna_hip_programming.md rule 21);
+//   * one raw s_barrier per K-step with a COUNTED s_waitcnt vmcnt(N) in front of it: the DMAs of the next two steps stay
+//     in flight across the barrier; the weights of step k+1 are visible one barrier EARLY, so the fragments of step
+//     k+1 / slice 0 are read during the MFMAs of step k / slice 1 — the matrix pipe does not wait behind a barrier;
+//   * fragment registers are double-buffered by hand (slice s+1 is read while slice s is multiplied).
+// Zero padding, the nearest x2 up-sampling and the two concatenated sources are resolved by the per-lane source offset
+// of the halo DMA (out-of-image -> beyond num_records -> the DMA writes zeros), as in the register-staged kernel.
+#include <type_traits>
+
+#include "conv_epilogue.h"
+#include "split_bf16.h"
+
+namespace rpnet {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+template <int TW, int NP>
+__global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
+                                                                       const int tiles_n, const int ntiles) {
+    constexpr int BM = 256, BN = 128, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int HP = (HALO + 15) / 16;           // 1 KB DMA pieces (16 halo rows of 64 B) per plane
+    constexpr int HPW = (HP + 3) / 4;              // piece positions per wave and channel chunk (the last ones may repeat)
+    constexpr int A_BYTES = HP * 1024, HBUF = NP * A_BYTES;
+    constexpr int B_BYTES = BN * 64, STAGE = NP * B_BYTES;
+    constexpr int NS = 4;                          // weight ring: K-steps k .. k+3
+    constexpr int WM = 4, WN = 2;
+    constexpr int NW = 2 * NP;                     // weight DMAs per wave and K-step (32 rows x NP planes)
+    static_assert(HPW <= 6, "halo pieces are issued during taps 0 .. HPW-1; the wait counts below assume HPW <= 6");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>())];
+    constexpr int WOFF = 2 * HBUF;                 // weight ring behind the two halo buffers
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    const int tile = xcd_swizzle(blockIdx.x, ntiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int n0 = tn * BN;
+    const int H = d.H, W = d.W, HW = H * W;
+    const int ups = d.upsample;
+    const int Hs = H >> ups, Ws = W >> ups;
+    const int pxn = W / TW, ppi = (H / TH) * pxn;
+    const int n = tm / ppi, prem = tm - n * ppi;
+    const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
+
+    const int kchunks = Cin >> 5;
+    const int nsteps = 9 * kchunks;
+    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << 5; };
+
+    const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
+    const size_t planew = (size_t)9 * Cin * Cout;
+    const unsigned short* x0p = reinterpret_cast<const unsigned short*>(d.x0);
+    const unsigned short* x1p = reinterpret_cast<const unsigned short*>(d.x1 ? d.x1 : d.x0);
+    const unsigned short* wq = reinterpret_cast<const unsigned short*>(d.w);
+    // one descriptor per tensor over all its planes (the plane is part of the scalar offset): 12 SGPRs instead of 36
+    const int pb0 = (int)(plane0 * 2), pb1 = (int)((d.x1 ? plane1 : plane0) * 2), pbw = (int)(planew * 2);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p), (short)0, NP * pb0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x1p), (short)0, NP * pb1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), (short)0, NP * pbw, 0x00020000);
+
+    // DMA lane geometry: lane l of a 1 KB piece writes the 16 bytes at piece + 16 l = row (l >> 2), slot (l & 3); the slot
+    // holds k-group (slot ^ ((row >> 2) & 3)), and pieces start at multiples of 16 rows, so the k-group is a lane constant
+    const int drow = lane >> 2;
+    const int dkg16 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    // halo: this wave's piece positions wv + 4 i (positions past the last piece repeat the wave's previous one: every wave
+    // issues the same number of DMAs, which is what the counted waits below rely on)
+    int hoff[HPW];
+    int hpos[HPW];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        int pos = wv + 4 * i;
+        if (pos >= HP) pos -= 4;
+        hpos[i] = pos;
+        const int hr = pos * 16 + drow;
+        const int hy = hr / PW, hx = hr - hy * PW;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool inb = hr < HALO && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        hoff[i] = inb ? (n * Hs + (iy >> ups)) * Ws + (ix >> ups) : -1;      // -1 -> beyond num_records -> zeros (the padding)
+    }
+    auto dma_halo = [&](auto ic, int c0, int buf) {
+        constexpr int i = decltype(ic)::value;
+        const bool first = c0 < d.C0;
+        const int Cs = first ? d.C0 : d.C1;
+        const int soff = (first ? c0 : c0 - d.C0) * 2;
+        const int voff = hoff[i] * (Cs * 2) + dkg16;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + p * A_BYTES + hpos[i] * 1024);
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, soff + p * pb0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, soff + p * pb1, 0, 0);
+        }
+    };
+    // weights: this wave moves rows 32 wv .. 32 wv + 31 of every plane of a slab (two pieces each)
+    const int wvoff = (32 * wv + drow) * 64 + dkg16;
+    auto dma_w = [&](int tap, int c0, int stage) {
+        const int wsoff = ((tap * kchunks + (c0 >> 5)) * Cout + n0) * 64;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (32 * wv + 16 * q) * 64);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+            }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses.  A: MFMA row li of tile i = pixel (wm WM + i) 32 + li of the patch -> halo row + tap offset;
+    // slice s reads k-group 2 s + h: the address of slice 1 is that of slice 0 with bit 5 flipped
+    int hr00[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mloc = (wm * WM + i) * 32 + li;
+        hr00[i] = (mloc / TW) * PW + (mloc % TW);
+    }
+    const int b_off = WOFF + (wn * WN * 32 + li) * 64 + 16 * (h ^ ((li >> 2) & 3));
+
+    // Register double buffer of the fragments of one 16-deep slice: af / bfr [slice parity][plane][tile].  The issue order of
+    // a half K-step is PINNED (sched_barrier between the pieces; left to itself hipcc moves every read next to its
+    // consumer, which with one wave per SIMD exposes the LDS latency a dozen times per step):
+    //   MFMA m of slice s, then fragment read m of the NEXT slice (m < NR = 12 reads; they are consumed at least 12 MFMAs =
+    //   384 cycles later), a DMA behind every second one of the following MFMAs (~60 cycles of issue each).
+    // Reads are ordered by first use: the products run l*h, h*l, h*h (smallest first), so the l plane of A and the h plane
+    // of B go first.
+    bf16x8 af[2][NP][WM], bfr[2][NP][WN];
+    int aaddr[WM];                 // per tap: byte address of tile i's A fragment (slice 0, plane 0) inside a halo buffer
+    auto a_addr_tap = [&](auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int hr = hr00[i] + ky * PW + kx;
+            aaddr[i] = hr * 64 + 16 * (h ^ ((hr >> 2) & 3));
+        }
+    };
+    constexpr int NR = NP * (WM + WN), NMMA = nprod<NP>() * WM * WN;
+    // read k of a slice, in order of first use: plane order of A = (NP-1 .. 0), of B = (0 .. NP-1); per plane pair: A tile 0,
+    // the B tiles, the other A tiles
+    auto read_frag = [&](auto sc, auto kc, const int abase, const int bbase) {
+        constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
+        constexpr int grp = k / (WM + WN), r = k - grp * (WM + WN);      // grp-th plane pair
+        constexpr int pa = NP - 1 - grp, pb = grp;
+        if constexpr (r == 0 || r > WN) {
+            constexpr int i = r == 0 ? 0 : r - WN;
+            af[s][pa][i] = *reinterpret_cast<const bf16x8*>(smem + abase + (aaddr[i] ^ (32 * s)) + pa * A_BYTES);
+        } else {
+            constexpr int j = r - 1;
+            bfr[s][pb][j] = *reinterpret_cast<const bf16x8*>(smem + bbase + (b_off ^ (32 * s)) + pb * B_BYTES + j * 2048);
+        }
+    };
+    auto mma_one = [&](auto sc, auto mc) {
+        constexpr int s = decltype(sc)::value, m = decltype(mc)::value;
+        constexpr int q = m / (WM * WN), ij = m - q * (WM * WN), i = ij / WN, j = ij - i * WN;
+        constexpr int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
+        acc[i][j] = mma16<NP>(af[s][pa][i], bfr[s][pb][j], acc[i][j]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto dma_w_one = [&](auto ec, const int wsoff, const int stage) {
+        constexpr int e = decltype(ec)::value, p = e >> 1, q = e & 1;
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (32 * wv + 16 * q) * 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+    };
+
+    // ---- prologue: halo of chunk 0, weight slabs of steps 0, 1, 2
+    {
+        const int c0 = chunk_c0(0);
+        dma_halo(std::integral_constant<int, 0>{}, c0, 0);
+        if constexpr (HPW > 1) dma_halo(std::integral_constant<int, 1>{}, c0, 0);
+        if constexpr (HPW > 2) dma_halo(std::integral_constant<int, 2>{}, c0, 0);
+        if constexpr (HPW > 3) dma_halo(std::integral_constant<int, 3>{}, c0, 0);
+        if constexpr (HPW > 4) dma_halo(std::integral_constant<int, 4>{}, c0, 0);
+        if constexpr (HPW > 5) dma_halo(std::integral_constant<int, 5>{}, c0, 0);
+        dma_w(0, c0, 0);
+        dma_w(1, c0, 1);
+        dma_w(2, c0, 2);
+    }
+    // the halo and the slabs of steps 0 and 1 have landed (slab 2 may still fly): visible to every wave behind the barrier
+    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    a_addr_tap(I0{});
+    static_for<NR>([&](auto kc) { read_frag(I0{}, kc, 0, 0); });
+
+    // One K-step (tap TAP of chunk ci, step ks, weight stage ks & 3):
+    //   first half:  MFMAs of slice 0 | reads of slice 1 | DMA of the weight slab of step ks + 3 into the stage that step
+    //                ks - 1 used;
+    //   second half: MFMAs of slice 1 | reads of step ks + 1 / slice 0 (its slab was waited for BEFORE the previous barrier) |
+    //                during taps 0 .. HPW-1 the DMA of one halo piece position of chunk ci + 1 into the other halo buffer
+    //                (last read during chunk ci - 1);
+    //   before the barrier each wave waits until its part of slab ks + 2 (and every older DMA) has landed — N = the DMAs
+    //   it issued since: halo piece of the previous step + slab ks + 3 + halo piece of this step.
+    auto step = [&](auto tapc, const int ci, const int ks) {
+        constexpr int TAP = decltype(tapc)::value;
+        const int hb = ci & 1;
+        const bool last_chunk = ci + 1 >= kchunks;
+        // the tail of the last chunk re-fetches valid data into buffers nobody reads again (uniform DMA counts)
+        constexpr int t3 = TAP + 3 < 9 ? TAP + 3 : TAP - 6;
+        const int c3 = chunk_c0((TAP + 3 < 9 || last_chunk) ? ci : ci + 1);
+        const int wsoff = ((t3 * kchunks + (c3 >> 5)) * Cout + n0) * 64;
+        const int wstage = (ks + 3) & 3;
+        const int abase = hb * HBUF, bbase = (ks & 3) * STAGE;
+        static_for<NMMA>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            mma_one(I0{}, mc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m < NR) {
+                read_frag(I1{}, mc, abase, bbase);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr ((m - NR) % 2 == 1 && (m - NR) / 2 < NW) {
+                dma_w_one(std::integral_constant<int, (m - NR) / 2>{}, wsoff, wstage);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        constexpr int TN = TAP < 8 ? TAP + 1 : 0;
+        a_addr_tap(std::integral_constant<int, TN>{});
+        const int abase_n = (TAP < 8 ? hb : hb ^ 1) * HBUF, bbase_n = ((ks + 1) & 3) * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NMMA>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            mma_one(I1{}, mc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m < NR) {
+                read_frag(I0{}, mc, abase_n, bbase_n);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (m == NR + 1 && TAP < HPW) {
+                dma_halo(std::integral_constant<int, (TAP < HPW ? TAP : 0)>{}, chunk_c0(last_chunk ? ci : ci + 1), hb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        constexpr int HPREV = (TAP >= 1 && TAP - 1 < HPW) ? NP : 0;
+        constexpr int HCUR = TAP < HPW ? NP : 0;
+        constexpr int N = HPREV + NW + HCUR;
+        static_assert(N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "wait count");
+        if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ablation switches for tools/bench_conv_split.py (rpnet_conv_desc.tune bits 8..: 1 = only the first channel chunk,
+    // 2 = no epilogue): where a launch's time goes besides its K-steps
+    const int dbg = d.tune >> 8;
+    const int nchunks_run = (dbg & 1) ? 1 : kchunks;
+    int ks = 0;
+    for (int ci = 0; ci < nchunks_run; ++ci) {
+        step(std::integral_constant<int, 0>{}, ci, ks + 0);
+        step(std::integral_constant<int, 1>{}, ci, ks + 1);
+        step(std::integral_constant<int, 2>{}, ci, ks + 2);
+        step(std::integral_constant<int, 3>{}, ci, ks + 3);
+        step(std::integral_constant<int, 4>{}, ci, ks + 4);
+        step(std::integral_constant<int, 5>{}, ci, ks + 5);
+        step(std::integral_constant<int, 6>{}, ci, ks + 6);
+        step(std::integral_constant<int, 7>{}, ci, ks + 7);
+        step(std::integral_constant<int, 8>{}, ci, ks + 8);
+        ks += 9;
+    }
+    (void)nsteps;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's DMAs: the epilogue reuses the memory
+    __builtin_amdgcn_s_barrier();
+    if (dbg & 2) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f) d.y0[t] = sacc;
+        return;
+    }
+    conv_epilogue<WM, WN, 2, PatchRows<TW>, false>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
+                                                    li, h, smem);
+}
+
+// launcher for conv_split.hip: fp16 planes (two), 128-wide output tiles, whole (256 / TW) x TW patches
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, hipStream_t s) {
+    const int tiles_m = M / 256, tiles_n = Cout / 128;
+    const int ntiles = tiles_m * tiles_n;
+    if (d->split_planes != 2) {
+        set_error("conv_igemm_split_dma: two fp16 planes only");
+        return RPNET_ERR_ARG;
+    }
+    if (tw == 32)
+        hipLaunchKernelGGL((conv_igemm_split_dma_kernel<32, 2>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_dma_kernel<16, 2>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+    return check_launch("conv_igemm_split_dma");
+}
+
+}  // namespace rpnet

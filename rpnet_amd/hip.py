@@ -45,6 +45,7 @@ _SIGS = {
     "rpnet_pack_conv_weights_split": (ci, [C.POINTER(PackItem), ci, ci, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
+    "rpnet_conv_tile_variant": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
     "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),

@@ -1,0 +1,126 @@
+"""The LDS-DMA patch kernel (rpnet_amd/csrc/conv_split_dma.hip, tile variant 11 of rpnet_conv_fwd: 3x3 forward / input
+gradient on two fp16 planes, four waves, operands by buffer_load ... lds) against
+  * the register-staged 8-wave patch kernel (variant 7): same tiles, same K order, same MFMA sequence per accumulator, same
+    epilogue -> the outputs must be BIT-IDENTICAL (forward, BatchNorm statistics, both input gradients);
+  * the torch fp64 reference of the same layer (1e-3 bar of BASELINE.json; measured ~1e-6).
+Shapes cover both patch widths (W % 32 == 0 -> 8 x 32 patches, else 16 x 16), image borders in every direction, two
+concatenated sources, the nearest x2 up-sampling in the gather, two BatchNorm statistic groups, 128 / 256 / 384 output
+channels and two input-gradient destinations."""
+import copy
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err, rnd
+from tests.test_gpu_ops import _mk_layer, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def RF():
+    from rpnet_amd import functional
+    return functional
+
+
+def _run(RF, monkeypatch, tile, layer, a, b, go, ups, groups):
+    """conv-BN-ReLU of cat([a, b]) (fp16 planes: the sources carry a tensor scale) forward + backward with tile variant
+    `tile` forced; -> (z, da, db, running_var, the variants rpnet_conv_fwd actually chose)"""
+    from rpnet_amd import hip
+    monkeypatch.setitem(RF.TUNE, "tile", tile + 1)
+    chosen = []
+    orig = RF.call
+
+    def spy(name, *args):
+        if name == "rpnet_conv_fwd":
+            chosen.append(hip.query("rpnet_conv_tile_variant", args[0]))
+        return orig(name, *args)
+
+    monkeypatch.setattr(RF, "call", spy)
+    conv, bn = copy.deepcopy(layer[0]).to(DEV), copy.deepcopy(layer[1]).to(DEV).train()
+    ag = nhwc(a).to(DEV).requires_grad_(True)
+    bg = nhwc(b).to(DEV).requires_grad_(True) if b is not None else None
+    bound = max(a.abs().max().item(), b.abs().max().item() if b is not None else 0.0)
+    sc = torch.tensor([2.0 ** (int(torch.ceil(torch.log2(torch.tensor(bound))).item()) - 15)], device=DEV)
+    oa = RF.Operand(ag, scale=sc)
+    ob = RF.Operand(bg, scale=sc) if bg is not None else None
+    z = RF.conv_bn_relu_op(oa, conv, bn, RF.WeightCache(), True, x1=ob, groups=groups, upsample=ups, out_split=False).x
+    z.backward(nhwc(go).to(DEV))
+    torch.cuda.synchronize()
+    monkeypatch.setattr(RF, "call", orig)
+    return z.detach(), ag.grad, (bg.grad if bg is not None else None), bn.running_var.clone(), conv.weight.grad, chosen
+
+
+CASES = [
+    # N, H, W, c0, c1, cout, ups
+    (2, 32, 32, 128, 0, 128, False),     # 8 x 32 patches, 4 per image: top / bottom borders inside every patch column
+    (1, 16, 64, 128, 128, 256, False),   # two sources, two column blocks, patches side by side (left / right borders)
+    (2, 32, 64, 64, 0, 128, True),       # nearest x2 in the gather
+    (3, 16, 48, 128, 128, 128, False),   # W % 32 != 0 -> 16 x 16 patches, odd image count (one statistic group)
+    (2, 16, 16, 256, 0, 384, False),     # one 16 x 16 patch per image, 3 column blocks, 8 channel chunks
+    (4, 8, 32, 64, 0, 128, False),       # two channel chunks (K = 18 steps): little more than prologue and tail of the DMA ring
+]
+
+
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", CASES)
+def test_dma_patch_kernel_bit_identical_and_accurate(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
+    old = RF.conv_math()
+    RF.set_conv_math("f16x2")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(c0 + c1, cout, 3, 91)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(92, N, c0, hs, ws)
+        b = rnd(93, N, c1, hs, ws) if c1 else None
+        go = rnd(94, N, cout, H, W)
+        # fp64 reference
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go.double())
+
+        z7, da7, db7, rv7, dw7, ch7 = _run(RF, monkeypatch, 7, layer, a, b, go, ups, groups)
+        z11, da11, db11, rv11, dw11, ch11 = _run(RF, monkeypatch, 11, layer, a, b, go, ups, groups)
+        # forward launch + input-gradient launch, each on the forced variant (the input gradient only when its output
+        # channels = the layer's input channels come in 128-wide tiles per destination)
+        dgrad_ok = c0 % 128 == 0 and c1 % 128 == 0
+        assert ch7[0] == 7 and ch11[0] == 11 and len(ch11) == 2, (ch7, ch11)
+        assert (ch11[1] == 11) == dgrad_ok and (ch7[1] == 7) == dgrad_ok, (ch7, ch11)
+        assert RF.arith_counts()["conv3x3"].get("f16x2", 0) >= 2
+        assert torch.equal(z7, z11)
+        assert torch.equal(da7, da11)
+        assert torch.equal(rv7, rv11)
+        if c1:
+            assert torch.equal(db7, db11)
+        assert rel_err(nchw(z11), ref) < 1e-3
+        assert rel_err(nchw(da11), ar.grad) < 1e-3
+        if c1:
+            assert rel_err(nchw(db11), br.grad) < 1e-3
+        assert rel_err(dw11, c_ref.weight.grad) < 1e-3
+        assert rel_err(rv11, b_ref.running_var) < 1e-5
+    finally:
+        RF.set_conv_math(old)
+
+
+def test_dma_patch_kernel_repeatable(RF, monkeypatch):
+    """the counted waits of the DMA ring leave two K-steps of loads in flight across every barrier: a misplaced wait shows up
+    as a rare stale tile, so the same launch is repeated and every result compared bit by bit"""
+    old = RF.conv_math()
+    RF.set_conv_math("f16x2")
+    try:
+        layer = _mk_layer(256, 256, 3, 95)
+        a, go = rnd(96, 8, 256, 32, 32), rnd(97, 8, 256, 32, 32)
+        first = _run(RF, monkeypatch, 11, layer, a, None, go, False, 2)
+        for _ in range(5):
+            again = _run(RF, monkeypatch, 11, layer, a, None, go, False, 2)
+            assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+    finally:
+        RF.set_conv_math(old)

@@ -11,7 +11,7 @@ from rpnet_amd.hip import call
 dev = "cuda:0"
 import rpnet_amd.functional as _RF
 if os.environ.get("TILE"):          # force tile variant TILE of the split forward kernels (rpnet_conv_desc.tune)
-    _RF.TUNE["tile"] = int(os.environ["TILE"]) + 1
+    _RF.TUNE["tile"] = int(os.environ["TILE"]) + 1 + 256 * int(os.environ.get("DBG", "0"))   # DBG: ablation bits of variant 11
 PLANES = tuple(int(v) for v in os.environ.get("PLANES", "0,3,2").split(","))
 
 
@@ -42,7 +42,9 @@ def conv(x, pw, co, planes, xs=None):
 
 
 torch.manual_seed(0)
-for (N, H, W, ci, co) in [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]:
+FWD_ONLY = os.environ.get("FWD_ONLY") == "1"      # only the forward speed table
+RELU = os.environ.get("RELU") == "1"              # half of the activations exact zeros, as behind a ReLU (the clock the chip holds depends on the data)
+for (N, H, W, ci, co) in ([] if FWD_ONLY else [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]):
     x = torch.randn(N, H, W, ci, device=dev)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1).permute(0, 2, 3, 1)
@@ -60,6 +62,8 @@ if os.environ.get("SHAPES"):
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 for (N, H, W, ci, co) in SHAPES:
     x = torch.randn(N, H, W, ci, device=dev)
+    if RELU:
+        x = torch.relu(x)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
     pw = PackedWeight(w)
     fl = 2.0 * N * H * W * ci * co * 9
@@ -84,6 +88,8 @@ for (N, H, W, ci, co) in SHAPES:
     line += f"  split3 {a.elapsed_time(b)/10:6.3f} ms"
     print(line, flush=True)
 
+if FWD_ONLY:
+    sys.exit(0)
 # ---- weight gradient: accuracy (fp64 CPU reference) and speed
 from rpnet_amd.functional import _ws
 from rpnet_amd.hip import ptr, query
