@@ -168,10 +168,13 @@ typedef struct rpnet_conv_desc {
                                           caller zeroed; an order-independent atomic max, so the result is deterministic):
                                           the data-dependent bound from which an eval-mode BatchNorm output gets its fp16
                                           tensor scale (rpnet_pow2_scale) — running statistics give no a-priori bound */
-    int tune;                          /* 0: the library picks the tile variant.  Tuning / tests: v + 1 forces variant v of
+    int tune;                          /* 0: the library picks the tile variant.  Tuning / tests, low byte: v + 1 forces variant v of
                                           the split forward kernels (where the shape allows it); 4 in rpnet_conv_wgrad: the
-                                          4-wave layout of the split weight gradient.  Carried here, not in the
-                                          environment: the library keeps no global state */
+                                          4-wave layout of the split weight gradient.  Bits 8-9: ablation switches of the
+                                          LDS-DMA kernel (tools/bench_conv_split.py: 1 = first channel chunk only, 2 = no
+                                          epilogue; results are then meaningless).  Bit 16: the default policy without the
+                                          LDS-DMA kernel (A/B).  Carried here, not in the environment: the library keeps no
+                                          global state */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);

@@ -100,26 +100,55 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
         }
         __builtin_amdgcn_wave_barrier();               // the slab is private to the wave: LDS ops of one wave complete in order
         // ---- slab -> memory: a lane holds 4 consecutive channels of one pixel
+        constexpr int NQ = WN * 4;
+        int orow[NQ];
+        f32x4 v4[NQ];
 #pragma unroll
-        for (int q = 0; q < WN * 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int gidx = q * 64 + lane;            // (row, 4-channel group) of the 32 x (WN * 32) tile
             const int rr = gidx / (WN * 8), c4 = gidx - rr * (WN * 8);
-            const int row = rows(wm * WM * 32 + i * 32 + rr);
-            if (RowMap::kAlwaysValid || row >= 0) {
-                f32x4 v4 = *reinterpret_cast<const f32x4*>(&slab[rr * SW + c4 * 4]);
-                f32x4* p = reinterpret_cast<f32x4*>(dstb + (size_t)row * Cd + cd0 + c4 * 4);
-                if (ROWOPS) {
-                    if (d.out_scale_mode) {
-                        float s = d.out_scale[row];
-                        if (d.out_scale_mode == 2) s = 1.f - s;
-                        v4 *= s;
-                    }
-                    if (d.accumulate) v4 += *p;
-                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v4[0]), fabsf(v4[1]))), fmaxf(fabsf(v4[2]), fabsf(v4[3])));
-                    if (d.y_split) *reinterpret_cast<f32x4*>(&slab[rr * SW + c4 * 4]) = v4;      // the planes below take the final values
-                }
-                *p = v4;
+            orow[q] = rows(wm * WM * 32 + i * 32 + rr);
+            v4[q] = *reinterpret_cast<const f32x4*>(&slab[rr * SW + c4 * 4]);
+        }
+        if (ROWOPS) {
+            // the loads of a tile's row factors / previous values go out together, in front of the arithmetic (the branches
+            // are uniform and sit outside the loops: one wave per SIMD has nothing else to cover a load's latency with)
+            if (d.out_scale_mode) {
+                float sc[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) sc[q] = (RowMap::kAlwaysValid || orow[q] >= 0) ? d.out_scale[orow[q]] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v4[q] *= d.out_scale_mode == 2 ? 1.f - sc[q] : sc[q];
             }
+            if (d.accumulate) {
+                f32x4 prev[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c4 = (q * 64 + lane) % (WN * 8);
+                    prev[q] = (RowMap::kAlwaysValid || orow[q] >= 0) ? *reinterpret_cast<const f32x4*>(dstb + (size_t)orow[q] * Cd + cd0 + c4 * 4)
+                                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v4[q] += prev[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (RowMap::kAlwaysValid || orow[q] >= 0)
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v4[q][0]), fabsf(v4[q][1]))), fmaxf(fabsf(v4[q][2]), fabsf(v4[q][3])));
+            if (d.y_split) {                           // the planes below take the final values
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int gidx = q * 64 + lane;
+                    const int rr = gidx / (WN * 8), c4 = gidx - rr * (WN * 8);
+                    *reinterpret_cast<f32x4*>(&slab[rr * SW + c4 * 4]) = v4[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c4 = (q * 64 + lane) % (WN * 8);
+            if (RowMap::kAlwaysValid || orow[q] >= 0)
+                *reinterpret_cast<f32x4*>(dstb + (size_t)orow[q] * Cd + cd0 + c4 * 4) = v4[q];
         }
         __builtin_amdgcn_wave_barrier();
         if (ROWOPS && d.y_split) {

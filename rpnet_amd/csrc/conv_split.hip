@@ -939,7 +939,10 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     // M = 262144, 767 vs 671 TF on 256 -> 256 at M = 65536 — once its grid fills both block slots of every CU
     if (d->split_planes == 1 && hbn == 128 && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 128) >= 512)
         return 10;
-    if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224) return 7;
+    // 256 x 128 patches, one block per CU: two fp16 planes -> the LDS-DMA kernel (conv_split_dma.hip: +14 ... 20 % over the
+    // register-staged 8-wave kernel on every such layer, same bits); tune bit 16 = the round-2 policy (A/B switch)
+    if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224)
+        return (d->split_planes == 2 && !(d->tune & 0x10000)) ? 11 : 7;
     if (halo4_tw(d)) {
         // 64-wide tiles (twice the blocks) win on every grid this kernel sees — 169 vs 107 TF at M = 4096, 1024 -> 512;
         // 182 vs 160 TF at M = 16384, 256 -> 256 — until the 128-wide grid alone is two full rounds of the machine

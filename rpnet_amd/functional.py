@@ -440,7 +440,9 @@ class WeightCache:
 
 # tuning / test override of the kernel variant, carried by every descriptor (rpnet_conv_desc.tune): 0 = the library's
 # choice, v + 1 = tile variant v of the split forward kernels, 4 (weight gradient) = the 4-wave layout
-TUNE = {"tile": 0, "wgrad": int(os.environ.get("RPNET_TUNE_WGRAD", "0"))}
+# RPNET_CONV_DMA=0: the default tile policy without the LDS-DMA patch kernel (tune bit 16; A/B switch of round 3)
+TUNE = {"tile": int(os.environ.get("RPNET_TUNE_TILE", "0")) + (0 if os.environ.get("RPNET_CONV_DMA", "1") == "1" else 0x10000),
+        "wgrad": int(os.environ.get("RPNET_TUNE_WGRAD", "0"))}
 
 
 def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups=1, ep_scale=None, ep_shift=None,
