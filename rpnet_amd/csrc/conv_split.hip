@@ -888,6 +888,7 @@ static const SplitVariant kSplitVariants[] = {
     {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
     {2, 4, 2, 0, 512},    // 10: 256 x 128 on an image patch with FOUR waves (wave tile 128 x 64), two blocks per CU
     {2, 4, 2, 0, 256},    // 11: 256 x 128 on an image patch, four waves (one per SIMD), operands by LDS-DMA (conv_split_dma.hip)
+    {2, 4, 1, 0, 256},    // 12: 256 x 64 of the same kernel (wave tile 128 x 32)
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -917,13 +918,14 @@ static int halo4_tw(const rpnet_conv_desc* d) {
 }
 
 // conv_split_dma.hip
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, hipStream_t s);
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s);
 
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = (d->tune & 0xff) - 1;      // bits 8..: ablation switches of conv_split_dma.hip
+        if (v == 12 && d->split_planes == 2 && halo_tw(d, Cout)) return v;
         if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2)) && halo_tw(d, Cout) &&
              halo_bn(d, Cout) == 128) ||
             ((v == 8 || v == 9) && halo4_tw(d)))
@@ -941,8 +943,11 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
         return 10;
     // 256 x 128 patches, one block per CU: two fp16 planes -> the LDS-DMA kernel (conv_split_dma.hip: +14 ... 20 % over the
     // register-staged 8-wave kernel on every such layer, same bits); tune bit 16 = the round-2 policy (A/B switch)
-    if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= 224)
-        return (d->split_planes == 2 && !(d->tune & 0x10000)) ? 11 : 7;
+    const bool dma = d->split_planes == 2 && !(d->tune & 0x10000);
+    if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= (dma ? 192 : 224)) return dma ? 11 : 7;
+    // grids too small for that: 256 x 64 tiles of the DMA kernel (twice the blocks; 419 vs 317 TF on 1024 -> 1024 at
+    // M = 4096) from half a machine of blocks upwards
+    if (dma && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 64) >= 128) return 12;
     if (halo4_tw(d)) {
         // 64-wide tiles (twice the blocks) win on every grid this kernel sees — 169 vs 107 TF at M = 4096, 1024 -> 512;
         // 182 vs 160 TF at M = 16384, 256 -> 256 — until the 128-wide grid alone is two full rounds of the machine
@@ -975,7 +980,8 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);
         case 2: return launch_split<2, 1, 2, false>(d, M, Cin, Cout, s);
         case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
-        case 11: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), s);
+        case 11: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
+        case 12: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s);
         case 10:
             return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:

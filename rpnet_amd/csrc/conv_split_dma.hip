@@ -5,8 +5,8 @@
 // 36 % of the wave cycles parked on s_waitcnt / the barrier of every K-step): operand tiles travel HBM -> VGPR -> LDS, so
 // every K-step ends in a barrier BEHIND which the fragment reads of the next step start from cold, and the staging
 // registers (halo waiting for nine taps, weight slab) cap the wave tile at 64 x 64.  Here:
-//   * block = 256 output pixels (a (256 / TW) x TW patch of one image) x 128 output channels, FOUR waves (2 x 2), wave
-//     tile 128 x 64: 12 ds_read_b128 per 24 MFMAs instead of 8 per 12, one wave per SIMD with the whole 512-register file;
+//   * block = 256 output pixels (a (256 / TW) x TW patch of one image) x 128 (WN = 2; 64 with WN = 1) output channels, FOUR
+//     waves (2 x 2), wave tile 128 x 64: 12 ds_read_b128 per 24 MFMAs instead of 8 per 12, one wave per SIMD with the whole 512-register file;
 //   * no staging registers and no ds_write: the input halo of the patch (two buffers: the next channel chunk lands while
 //     the nine taps of the current one are multiplied) and the weight slabs (ring of four K-steps) are written by the
 //     DMA engine.  The LDS image is lane-linear per DMA instruction, so the XOR swizzle of the k-groups that keeps the
@@ -33,17 +33,17 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int TW, int NP>
+template <int TW, int NP, int WN>
 __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
                                                                        const int tiles_n, const int ntiles) {
-    constexpr int BM = 256, BN = 128, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int BM = 256, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
     constexpr int HP = (HALO + 15) / 16;           // 1 KB DMA pieces (16 halo rows of 64 B) per plane
     constexpr int HPW = (HP + 3) / 4;              // piece positions per wave and channel chunk (the last ones may repeat)
     constexpr int A_BYTES = HP * 1024, HBUF = NP * A_BYTES;
     constexpr int B_BYTES = BN * 64, STAGE = NP * B_BYTES;
     constexpr int NS = 4;                          // weight ring: K-steps k .. k+3
-    constexpr int WM = 4, WN = 2;
-    constexpr int NW = 2 * NP;                     // weight DMAs per wave and K-step (32 rows x NP planes)
+    constexpr int WM = 4;
+    constexpr int NW = WN * NP;                    // weight DMAs per wave and K-step (16 WN rows x NP planes)
     static_assert(HPW <= 6, "halo pieces are issued during taps 0 .. HPW-1; the wait counts below assume HPW <= 6");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>())];
     constexpr int WOFF = 2 * HBUF;                 // weight ring behind the two halo buffers
@@ -112,15 +112,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, soff + p * pb1, 0, 0);
         }
     };
-    // weights: this wave moves rows 32 wv .. 32 wv + 31 of every plane of a slab (two pieces each)
-    const int wvoff = (32 * wv + drow) * 64 + dkg16;
+    // weights: this wave moves rows 16 WN wv .. of every plane of a slab (WN pieces each)
+    const int wvoff = (16 * WN * wv + drow) * 64 + dkg16;
     auto dma_w = [&](int tap, int c0, int stage) {
         const int wsoff = ((tap * kchunks + (c0 >> 5)) * Cout + n0) * 64;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (32 * wv + 16 * q) * 64);
+            for (int q = 0; q < WN; ++q) {
+                auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
             }
     };
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     auto dma_w_one = [&](auto ec, const int wsoff, const int stage) {
-        constexpr int e = decltype(ec)::value, p = e >> 1, q = e & 1;
-        auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (32 * wv + 16 * q) * 64);
+        constexpr int e = decltype(ec)::value, p = e / WN, q = e - p * WN;
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
     };
 
@@ -204,8 +204,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         dma_w(2, c0, 2);
     }
     // the halo and the slabs of steps 0 and 1 have landed (slab 2 may still fly): visible to every wave behind the barrier
+    static_assert(NW == 1 || NW == 2 || NW == 4, "weight DMAs per wave and step");
     if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (NW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     a_addr_tap(I0{});
     static_for<NR>([&](auto kc) { read_frag(I0{}, kc, 0, 0); });
@@ -235,8 +237,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
             if constexpr (m < NR) {
                 read_frag(I1{}, mc, abase, bbase);
                 __builtin_amdgcn_sched_barrier(0);
-            } else if constexpr ((m - NR) % 2 == 1 && (m - NR) / 2 < NW) {
-                dma_w_one(std::integral_constant<int, (m - NR) / 2>{}, wsoff, wstage);
+            }
+            // the DMAs of the weight slab behind every second MFMA of the tail of the half step
+            if constexpr (m >= NMMA - 2 * NW && (NMMA - 1 - m) % 2 == 0) {
+                dma_w_one(std::integral_constant<int, NW - 1 - (NMMA - 1 - m) / 2>{}, wsoff, wstage);
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
             if constexpr (m < NR) {
                 read_frag(I0{}, mc, abase_n, bbase_n);
                 __builtin_amdgcn_sched_barrier(0);
-            } else if constexpr (m == NR + 1 && TAP < HPW) {
+            }
+            if constexpr (m == NMMA - 1 && TAP < HPW) {
                 dma_halo(std::integral_constant<int, (TAP < HPW ? TAP : 0)>{}, chunk_c0(last_chunk ? ci : ci + 1), hb ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         constexpr int HPREV = (TAP >= 1 && TAP - 1 < HPW) ? NP : 0;
         constexpr int HCUR = TAP < HPW ? NP : 0;
         constexpr int N = HPREV + NW + HCUR;
-        static_assert(N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "wait count");
+        static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "wait count");
+        if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -303,18 +309,19 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
                                                     li, h, smem);
 }
 
-// launcher for conv_split.hip: fp16 planes (two), 128-wide output tiles, whole (256 / TW) x TW patches
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, hipStream_t s) {
-    const int tiles_m = M / 256, tiles_n = Cout / 128;
+// launcher for conv_split.hip: two fp16 planes, 128- (wn = 2) or 64-wide (wn = 1) output tiles, whole (256 / TW) x TW patches
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s) {
+    const int tiles_m = M / 256, tiles_n = Cout / (64 * wn);
     const int ntiles = tiles_m * tiles_n;
     if (d->split_planes != 2) {
         set_error("conv_igemm_split_dma: two fp16 planes only");
         return RPNET_ERR_ARG;
     }
-    if (tw == 32)
-        hipLaunchKernelGGL((conv_igemm_split_dma_kernel<32, 2>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
-    else
-        hipLaunchKernelGGL((conv_igemm_split_dma_kernel<16, 2>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles);
+#define RPNET_DMA(TWV, WNV) \
+    hipLaunchKernelGGL((conv_igemm_split_dma_kernel<TWV, 2, WNV>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles)
+    if (wn == 2) { if (tw == 32) RPNET_DMA(32, 2); else RPNET_DMA(16, 2); }
+    else { if (tw == 32) RPNET_DMA(32, 1); else RPNET_DMA(16, 1); }
+#undef RPNET_DMA
     return check_launch("conv_igemm_split_dma");
 }
 

@@ -455,6 +455,8 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
 // split-bf16 operands (conv_wgrad_split.hip)
 int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                       hipStream_t s);
+int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
+                          hipStream_t s);
 void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split);
 int conv_wgrad1_split(const rpnet_conv_desc* d, const void* dy, float* part, int M, int Cin, int Cout, int ks, int sps, hipStream_t s);
 
@@ -501,8 +503,14 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
         if (d->split_planes) {   // x0/x1 and dy are split-bf16 planes
             RPNET_REQUIRE(d->split_planes >= 1 && d->split_planes <= 3 && d->in_scale_mode == 0, RPNET_ERR_ARG,
                           "conv_wgrad: split operands take 1 to 3 planes and no in_scale");
-            if (dy)      // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
-                if (int rc = conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s)) return rc;
+            if (dy) {    // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
+                // two fp16 planes: the LDS-DMA kernel (conv_wgrad_split_dma.hip; same partial sums, bit for bit); tune 8 =
+                // the register-staged 12-wave kernel of round 2 (A/B switch), 4 = its 4-wave layout
+                const bool dma = d->split_planes == 2 && d->tune != 8 && d->tune != 4;
+                if (int rc = dma ? conv_wgrad9_split_dma(d, dy, part9, M, Cin, Cout, ks9, sps9, s)
+                                 : conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s))
+                    return rc;
+            }
             if (!dw) return RPNET_OK;       // GEMM phase only: the partial sums stay in the workspace
             RPNET_REQUIRE(d->split_planes == 3 || (d->acc_scale_x && d->acc_scale_dy), RPNET_ERR_ARG,
                           "conv_wgrad: fp16 planes need acc_scale_x and acc_scale_dy");

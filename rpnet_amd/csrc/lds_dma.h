@@ -1,0 +1,43 @@
+// LDS-DMA (buffer_load_dwordx4 ... lds) as inline assembly, hidden from hipcc.
+//
+// Why not __builtin_amdgcn_raw_ptr_buffer_load_lds everywhere: hipcc (ROCm 7.2) tracks a builtin DMA as a pending LDS write and
+// puts `s_waitcnt vmcnt(0)` in front of every later LDS access it cannot prove disjoint.  Plain loads of the one __shared__
+// array pass (conv_split_dma.hip uses the builtin), but ds_read_b64_tr_b16 — an intrinsic without alias information — gets
+// the full drain before EVERY read, which serialises a pipeline whose point is DMAs in flight across barriers
+// (cdna_hip_programming.md §5 "Three .s-level traps", §5.7).  An asm statement is invisible to that bookkeeping: no VGPR
+// destination, so nothing for the compiler to protect; the data is ordered by the kernel's own counted
+// `s_waitcnt vmcnt(N)` + s_barrier (which it needs anyway).
+// M0 (the LDS destination base) is written inside the statement that uses it.
+#pragma once
+#include "common.h"
+
+namespace rpnet {
+
+using srd_t = __attribute__((ext_vector_type(4))) unsigned;
+
+// raw buffer descriptor over `bytes` bytes at p (stride 0, bounds-checked: offsets >= bytes read as zero)
+__device__ __forceinline__ srd_t make_srd(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    return srd_t{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+
+// LDS byte address of a pointer into a __shared__ array
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+// 64 lanes x 16 bytes: lane l reads srd[voff_l + soff .. +16) and the DMA engine writes it to LDS at lds_base + 16 l
+// (lds_base, soff and srd wave-uniform).  Counts on vmcnt; no register result.
+__device__ __forceinline__ void lds_dma16(const srd_t srd, const unsigned lds_base, const int voff, const int soff) {
+    // M0 is not restored: hipcc keeps nothing live in M0 across statements in these kernels (no LDS-DMA builtins, no
+    // ds_*_addtid, no movrel) — checked in the .s: every other M0 write is followed by its own use
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+}
+
+}  // namespace rpnet

@@ -65,6 +65,41 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", CASES + [(2, 32, 32, 64, 0, 64, False), (1, 16, 32, 128, 64, 192, False)])
+def test_dma_patch_kernel_64_wide_tiles(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
+    """variant 12 (256 x 64 tiles of the same kernel: Cout = 64 layers, small grids): other tiles than any register-staged
+    kernel, so the check is the fp64 reference (and the 8-wave / 4-wave patch kernels to 1e-5)"""
+    old = RF.conv_math()
+    RF.set_conv_math("f16x2")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(c0 + c1, cout, 3, 91)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(92, N, c0, hs, ws)
+        b = rnd(93, N, c1, hs, ws) if c1 else None
+        go = rnd(94, N, cout, H, W)
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go.double())
+        z0, da0, db0, rv0, dw0, ch0 = _run(RF, monkeypatch, 9, layer, a, b, go, ups, groups)
+        z, da, db, rv, dw, ch = _run(RF, monkeypatch, 12, layer, a, b, go, ups, groups)
+        assert ch == [12, 12], ch
+        assert rel_err(z, z0) < 1e-5 and rel_err(da, da0) < 1e-5
+        assert rel_err(nchw(z), ref) < 1e-3
+        assert rel_err(nchw(da), ar.grad) < 1e-3
+        if c1:
+            assert rel_err(nchw(db), br.grad) < 1e-3
+        assert rel_err(rv, b_ref.running_var) < 1e-5
+    finally:
+        RF.set_conv_math(old)
+
+
 @pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", CASES)
 def test_dma_patch_kernel_bit_identical_and_accurate(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
     old = RF.conv_math()
@@ -122,5 +157,45 @@ def test_dma_patch_kernel_repeatable(RF, monkeypatch):
         for _ in range(5):
             again = _run(RF, monkeypatch, 11, layer, a, None, go, False, 2)
             assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+    finally:
+        RF.set_conv_math(old)
+
+
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [
+    (2, 32, 32, 128, 0, 128, False),     # power-of-two image, 4 tiles, split-K over 64 K-steps
+    (1, 16, 64, 128, 128, 256, False),   # two sources (a tile lies in one of them)
+    (2, 32, 64, 64, 0, 128, True),       # nearest x2: the x strips come from the half-resolution source
+    (3, 16, 48, 128, 128, 128, False),   # W not a power of two (division path), odd image count
+    (2, 8, 8, 64, 0, 64, False),         # M = 128: four K-steps in all — prologue and tail of the ring only
+    (5, 24, 40, 64, 0, 192, False),      # M = 4800 = 150 K-steps, image rows wider than a K-step and not a multiple of it
+])
+def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
+    """conv_wgrad9_dma_kernel (conv_wgrad_split_dma.hip) against the register-staged 12-wave kernel of round 2 (tune 8): same
+    tiles, split-K plan and order of accumulation -> bit-identical dW; and against the fp64 reference"""
+    old = RF.conv_math()
+    RF.set_conv_math("f16x2")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(c0 + c1, cout, 3, 81)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(82, N, c0, hs, ws)
+        b = rnd(83, N, c1, hs, ws) if c1 else None
+        go = rnd(84, N, cout, H, W)
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go.double())
+        monkeypatch.setitem(RF.TUNE, "wgrad", 8)
+        dw_old = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
+        monkeypatch.setitem(RF.TUNE, "wgrad", 0)
+        dw_new = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
+        assert RF.arith_counts()["wgrad3x3"].get("f16x2", 0) >= 1
+        assert torch.equal(dw_old, dw_new)
+        assert rel_err(dw_new, c_ref.weight.grad) < 1e-3
     finally:
         RF.set_conv_math(old)
