@@ -93,7 +93,9 @@ def make_inputs(seed, B, size, dev, n_shots=1, n_ways=1):
             t(ep["appr_query_labels"]))
 
 
-def step(net, bucket, inp, scaler):
+def step(net, bucket, inp, scaler, exposed=None):
+    """exposed (N > 1): list that receives a (start, end) HIP-event pair around the part of the gradient exchange that is
+    NOT hidden under backward — from the end of backward on the compute stream to the moment the averaged bucket is ready"""
     from rpnet_amd.functional import dice_ce
     si, fg, bg, qi, ql, appr = inp
     bucket.zero()
@@ -103,7 +105,14 @@ def step(net, bucket, inp, scaler):
         loss = loss + dice_ce(v, ql)
     loss = loss + scaler * out["align_loss"]
     loss.backward()
-    bucket.allreduce()
+    if exposed is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        bucket.allreduce()
+        b.record()
+        exposed.append((a, b))
+    else:
+        bucket.allreduce()
     return loss
 
 
@@ -149,24 +158,28 @@ def profile_step(net, bucket, inp, scaler):
     return agg
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+def pmc_traffic(math="f16x2", size=256, batch=8):
+    """HBM bytes per launch of the dominant kernel from the NEWEST committed rocprofv3 PMC passes OF THE SAME ARITHMETIC AND
+    WORKLOAD (profiles/rNN_pmc_traffic[_<math>_<size>].json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
     command, KiB units, read side doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_traffic.py).
-    A PMC pass cannot run inside the timed process, so this is the offline figure (its file named in
-    `traffic_source`) or None."""
+    A PMC pass cannot run inside the timed process, so this is the offline figure (its file named in `traffic_source`)
+    or None when no pass of this arithmetic / size has been committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    pmc_traffic.source = None
+    tag = "" if (math, size, batch) == ("f16x2", 256, 8) else f"_{math}_{size}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic{tag}.json")))
     if not files:
         return None
-    pmc_traffic.source = os.path.basename(files[-1])
     d = json.load(open(files[-1]))
     n = b = 0.0
     for k, v in d.items():
         if "conv_igemm" in k:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-    return round(b / n) if n else None
+    if not n:
+        return None
+    pmc_traffic.source = os.path.basename(files[-1])
+    return round(b / n)
 
 
 def conv_accuracy_probe(dev):
@@ -328,6 +341,46 @@ def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps, threads=Non
     return leg, (P, last, (si, fg, bg, qi, ql, appr))
 
 
+def _cpu_worker(argv):
+    """hidden mode `bench.py --cpu-worker THREADS SIZE T SECONDS INDEX`: one process of the concurrent CPU leg — the
+    oracle's as-written fwd+bwd on its own batch-1 episode, THREADS threads, for about SECONDS; prints one JSON line"""
+    threads, size, T, seconds, index = int(argv[0]), int(argv[1]), int(argv[2]), float(argv[3]), int(argv[4])
+    try:      # a disjoint block of cores per worker where the numbering allows it
+        os.sched_setaffinity(0, set(range(index * threads, (index + 1) * threads)) & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(threads)
+    cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
+    leg, _ = _cpu_leg(cfg, size, T, 1, True, seconds, 64)
+    print(json.dumps({"steps": leg["steps"], "median_s_per_step": leg["median_s_per_step"], "threads": threads}))
+
+
+def _cpu_aggregate_leg(size, T, threads, seconds):
+    """The host's real throughput on this workload: episodes are independent, so floor(hardware threads / 2 / threads)
+    processes of `threads` threads each run the as-written oracle CONCURRENTLY (one episode each); the aggregate is the sum
+    of their rates.  (One process cannot use the host: PyTorch's CPU operators at these sizes get slower beyond ~16 threads.)"""
+    import subprocess
+    nproc = os.cpu_count() or 1
+    procs_n = max(1, nproc // 2 // max(threads, 1))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen(cmd + [str(threads), str(size), str(T), str(seconds), str(i)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=env) for i in range(procs_n)]
+    rates, steps = [], 0
+    for p in procs:
+        out, _ = p.communicate(timeout=60 + 20 * seconds)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            r = json.loads(lines[-1])
+            rates.append(1.0 / r["median_s_per_step"])
+            steps += r["steps"]
+    if not rates:
+        return None
+    return {"value": round(sum(rates), 4), "unit": "pairs/s", "processes": len(rates), "threads_per_process": threads,
+            "cores": len(rates) * threads, "steps_total": steps, "per_process_pairs_per_s": [round(r, 3) for r in rates],
+            "mode": "as-written oracle, one batch-1 episode per process, all processes concurrent"}
+
+
 def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=None, full=False):
     """The CPU oracle fwd+bwd on the host cores, same loss.  `value` = the as-written mode (what "the
     reference CPU path" costs) at batch 1 of the benched size, a bounded sample; `legs` adds the algorithmic mode and
@@ -343,6 +396,16 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
            "nproc": os.cpu_count(), "cpu_model": _cpu_model(),
            "sample": f"{main_leg['steps']} fwd+bwd steps (median) of batch 1 at {size}x{size}, T={T}, oracle as-written mode "
                      f"(reference operator sequence), {main_leg['median_s_per_step']:.2f} s/step", "legs": [main_leg]}
+    # the honest figure: the whole host, not one process of it
+    agg = _cpu_aggregate_leg(size, T, main_leg["threads"], 12.0)
+    if agg is not None and agg["value"] > res["value"]:
+        res["single_process_value"] = res["value"]
+        res["value"], res["cores"] = agg["value"], agg["cores"]
+        res["sample"] = (f"{agg['processes']} concurrent processes x {agg['threads_per_process']} threads, each the as-written oracle "
+                         f"fwd+bwd on its own batch-1 episode at {size}x{size}, T={T} for ~12 s ({agg['steps_total']} steps in all); "
+                         f"aggregate = sum of the processes' rates; one process alone: {main_leg['value']} pairs/s")
+    if agg is not None:
+        res["aggregate_leg"] = agg
     if net is not None:
         mv = lambda a: a.to(dev)  # noqa: E731
         loss = step(net, bucket, ([[mv(si[0][0])]], [[mv(fg[0][0])]], [[mv(bg[0][0])]], [mv(qi[0])], mv(ql), mv(appr)),
@@ -370,6 +433,125 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
     return res
 
 
+def measure(w, world, rank, dev, cfg, steps, warmup, RF):
+    """Times `steps` steps of workload w = dict(ways, shots, size, iters, batch, conv_math) after `warmup` untimed ones
+    (barrier + synchronize on both sides, MAX over ranks), then one extra profiled step (HIP events per C-ABI call,
+    streams serialised).  -> dict with value, ms_per_step, the per-call aggregate, the arithmetic that ran, the model."""
+    from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
+    cfg = dict(cfg)
+    cfg["n_iter_refinement"] = w["iters"]
+    scaler = cfg["align_loss_scaler"]
+    RF.set_conv_math(w["conv_math"])
+    requested = math = RF.conv_math()
+    net = build_model(cfg, dev)
+    broadcast_parameters(net)
+    bucket = FlatGradBucket(net)
+    inp = make_inputs(1234 + rank, w["batch"], w["size"], dev, w["shots"], w["ways"])   # resident in HBM before timing
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(net, bucket, inp, scaler)
+    fence()
+    exposed = [] if world > 1 else None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(net, bucket, inp, scaler, exposed)
+    fence()
+    el = time.perf_counter() - t0
+    if math in ("f16x2", "f16") and not RF.f16_mode():
+        # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
+        # planes: label the line with what ran (`requested` keeps what was asked for)
+        math = "bf16x3"
+    dist_info = None
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        # did the collective library see every rank, and how much of the exchange is NOT hidden under backward
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ex = torch.tensor([sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        dist_info = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (plumbing test, not RCCL)"),
+                     "rccl_ranks_seen": int(round(ones.item())), "world_size": world,
+                     "allreduce_exposed_ms": round(float(ex.item()), 3),
+                     "allreduce_exposed_what": "HIP events on the compute stream from the end of backward to the averaged bucket, mean "
+                                               "over the timed steps, max over ranks; the first two of the three bucket segments go out from "
+                                               "post-accumulate hooks during backward (rpnet_amd/parallel.py)",
+                     "bucket_segments_mb": [round((bucket.bounds[i + 1] - bucket.bounds[i]) * 4 / 1e6, 1)
+                                            for i in range(len(bucket.bounds) - 1)]}
+    assert torch.isfinite(loss).item()
+    # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
+    # issued by rank 0 alone would never complete); only rank 0 reports.
+    RF.reset_arith()
+    agg = profile_step(net, bucket, inp, scaler)
+    arith = RF.arith_counts()          # which arithmetic every conv / correlation launch of that step actually ran
+    return {"value": world * w["batch"] * steps / el, "el": el, "agg": agg, "arith": arith, "math": math, "requested": requested,
+            "net": net, "bucket": bucket, "inp": inp, "scaler": scaler, "cfg": cfg, "dist": dist_info, "fence": fence}
+
+
+CONV_MATH_TEXT = {
+    "f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
+    "bf16x3": "fp32 operands as 3 bf16 planes (exact split), 6 v_mfma_f32_32x32x16_bf16 partial "
+              "products, fp32 accumulate: fp32-equivalent (dropped terms <= 2^-23 |x*y|)",
+    "f16x2": "fp32 operands as 2 fp16 planes of operand / (power-of-two scale from a rigorous bound: "
+             "BatchNorm outputs and gradients, weights), 3 v_mfma_f32_32x32x16_f16 partial products, "
+             "fp32 accumulate (dropped term <= 2^-22 |x*y|; measured error vs fp64 = the fp32 matrix "
+             "instruction's); the local correlation the same way (block-local scale for its window gradients); operands without a bound (eval mode) on 3 bf16 planes",
+    "f16": "REDUCED PRECISION (BASELINE configs[4]): conv / correlation operands as ONE fp16 plane of operand / "
+           "(power-of-two tensor scale), v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 BatchNorm "
+           "statistics, fp32 master weights and gradients; tolerance vs the fp32 reference: "
+           "tests/test_gpu_f16.py (logits 1e-2, Dice 1e-3)"}
+
+
+def roofline_of(m, w, world):
+    """the `roofline` object of a measured workload: the rpnet_conv_fwd launches (forward + input gradient) of the profiled step"""
+    agg, math, value = m["agg"], m["math"], m["value"]
+    products, peak = MATH[math]
+    conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
+    wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
+    achieved = conv[2] / conv[1] / 1e12
+    kern_total = sum(v[1] for v in agg.values())
+    gf_pair = algorithmic_gf_per_pair(w["size"], w["iters"], w["shots"], w["ways"])
+    traffic = pmc_traffic(math, w["size"], w["batch"])
+    return {"bound": "mfma", "kernel": "rpnet_conv_fwd launches (conv forward + dgrad): conv_igemm"
+                                       + ("_kernel" if math == "f32" else "_split*_kernel"),
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_source": getattr(pmc_traffic, "source", None),
+            "peak_basis": "157.3 TF dense fp32 MFMA" if math == "f32" else
+                          "2500 TF dense fp16 MFMA" if math == "f16" else
+                          f"2500 TF dense bf16 / fp16 MFMA / {products} partial products per fp32 multiply-add "
+                          "(achieved counts ALGORITHMIC fp32 FLOPs, not issued MFMA FLOPs)",
+            "issued_mfma_tflops": round(achieved * products, 1),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline pass of the same arithmetic and "
+                            "workload; null when none is committed)",
+            "algorithmic_bytes_per_launch": round(conv[3] / max(conv[0], 1)),
+            "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
+            "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
+            "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
+            "whole_step_frac": round(value / world * gf_pair * 1e9 / (peak * 1e12), 4),
+            "whole_step_tflops": round(value / world * gf_pair / 1e3, 1),
+            "gflop_per_pair": round(gf_pair, 1),
+            "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
+                                  sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
+            "sum_kernel_ms_per_step": round(1e3 * kern_total, 2),
+            "abi_calls_per_step": int(sum(v[0] for v in agg.values())),
+            "note": "per-kernel figures from one extra step with the two HIP streams serialised; "
+                    "value/ms_per_step measured with async weight gradients on"}
+
+
+def workload_text(w, world):
+    ns = argparse.Namespace(**w)
+    return (f"{w['ways']}-way {w['shots']}-shot, {w['size']}x{w['size']}, T={w['iters']}, batch {w['batch']}/GPU "
+            f"({baseline_config(ns, world)}), train mode, align loss on, loss = dice_ce(output)+sum dice_ce(refinement)+align_loss")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,6 +566,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="all CPU legs of BASELINE.md §4 (as-written and algorithmic, B=1 and B=8, and configs[0]); minutes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs[2] / configs[4] legs the default single-GPU command appends (`other_configs`)")
     ap.add_argument("--conv-math", choices=sorted(MATH), default=None,
                     help="arithmetic of the 3x3 convolutions (default: the library's, f16x2 = fp32-equivalent fp16 split; "
                          "f16 = plain fp16 operands, configs[4] only)")
@@ -406,56 +590,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
-    cfg["n_iter_refinement"] = args.iters
-    scaler = cfg["align_loss_scaler"]
-
-    from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
     import rpnet_amd.functional as RF
     RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
-    if args.conv_math:
-        RF.set_conv_math(args.conv_math)
-    requested = math = RF.conv_math()
-    products, peak = MATH[math]
-    net = build_model(cfg, dev)
-    broadcast_parameters(net)
-    bucket = FlatGradBucket(net)
-    inp = make_inputs(1234 + rank, args.batch, args.size, dev, args.shots, args.ways)   # resident in HBM before timing
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(net, bucket, inp, scaler)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(net, bucket, inp, scaler)
-    fence()
-    el = time.perf_counter() - t0
-    if math in ("f16x2", "f16") and not RF.f16_mode():
-        # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
-        # planes: label the line with what ran (`requested` keeps what was asked for, for the restore below)
-        math = "bf16x3"
-        products, peak = MATH[math]
-    if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    assert torch.isfinite(loss).item()
-
-    pairs = world * args.batch * args.steps
-    value = pairs / el
-    gf_pair = algorithmic_gf_per_pair(args.size, args.iters, args.shots, args.ways)
+    w = {"ways": args.ways, "shots": args.shots, "size": args.size, "iters": args.iters, "batch": args.batch,
+         "conv_math": args.conv_math or RF.conv_math()}
+    headline = (args.ways, args.shots, args.size, args.iters, args.batch) == (1, 1, 256, 5, 8) and w["conv_math"] == "f16x2"
+    m = measure(w, world, rank, dev, cfg, args.steps, args.warmup, RF)
+    math, requested, value = m["math"], m["requested"], m["value"]
+    net, bucket, inp, scaler, fence = m["net"], m["bucket"], m["inp"], m["scaler"], m["fence"]
+    cfg = m["cfg"]
 
     result = None
-    # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
-    # issued by rank 0 alone would never complete); only rank 0 reports.
-    RF.reset_arith()
-    agg = profile_step(net, bucket, inp, scaler)
-    arith = RF.arith_counts()          # which arithmetic every conv / correlation launch of that step actually ran
     alt = None
     if world == 1 and not args.no_cpu_baseline:
         # the same step under the other fp32-equivalent convolution arithmetics, for reference
@@ -474,57 +619,21 @@ def main():
             alt[other] = {"value": round(args.batch * 5 / (time.perf_counter() - t1), 3), "unit": "pairs/s", "steps": 5}
         RF.set_conv_math(requested)
     if rank == 0:
-        conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
-        wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
-        achieved = conv[2] / conv[1] / 1e12
-        kern_total = sum(v[1] for v in agg.values())
         result = {
             "metric": f"support/query pairs/sec (fwd+bwd, {args.shots}-shot {args.size}x{args.size}, T={args.iters})",
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * m["el"] / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if math == "f16" else "f32", "data": "synthetic",
-            "conv_math": {"f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
-                          "bf16x3": "fp32 operands as 3 bf16 planes (exact split), 6 v_mfma_f32_32x32x16_bf16 partial "
-                                    "products, fp32 accumulate: fp32-equivalent (dropped terms <= 2^-23 |x*y|)",
-                          "f16x2": "fp32 operands as 2 fp16 planes of operand / (power-of-two scale from a rigorous bound: "
-                                   "BatchNorm outputs and gradients, weights), 3 v_mfma_f32_32x32x16_f16 partial products, "
-                                   "fp32 accumulate (dropped term <= 2^-22 |x*y|; measured error vs fp64 = the fp32 matrix "
-                                   "instruction's); the local correlation the same way (block-local scale for its window gradients); operands without a bound (eval mode) on 3 bf16 planes",
-                          "f16": "REDUCED PRECISION (BASELINE configs[4]): conv / correlation operands as ONE fp16 plane of operand / "
-                                 "(power-of-two tensor scale), v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 BatchNorm "
-                                 "statistics, fp32 master weights and gradients; tolerance vs the fp32 reference: "
-                                 "tests/test_gpu_f16.py (logits 1e-2, Dice 1e-3)"}[math],
-            "config": {"workload": f"{args.ways}-way {args.shots}-shot, {args.size}x{args.size}, T={args.iters}, batch {args.batch}/GPU "
-                                   f"({baseline_config(args, world)}), train mode, align loss on, "
-                                   "loss = dice_ce(output)+sum dice_ce(refinement)+align_loss",
+            "conv_math": CONV_MATH_TEXT[math],
+            "config": {"workload": workload_text(w, world),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_math": math,
                        "conv_math_requested": requested,
-                       "launches_by_arithmetic": arith,
+                       "launches_by_arithmetic": m["arith"],
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
-            "roofline": {"bound": "mfma", "kernel": "rpnet_conv_fwd launches (conv forward + dgrad): conv_igemm"
-                                                    + ("_kernel" if math == "f32" else "_split*_kernel"),
-                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(),
-                         "traffic_source": getattr(pmc_traffic, "source", None),
-                         "peak_basis": "157.3 TF dense fp32 MFMA" if math == "f32" else
-                                       "2500 TF dense fp16 MFMA" if math == "f16" else
-                                       f"2500 TF dense bf16 / fp16 MFMA / {products} partial products per fp32 multiply-add "
-                                       "(achieved counts ALGORITHMIC fp32 FLOPs, not issued MFMA FLOPs)",
-                         "issued_mfma_tflops": round(achieved * products, 1),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, offline pass)",
-                         "algorithmic_bytes_per_launch": round(conv[3] / max(conv[0], 1)),
-                         "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
-                         "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
-                         "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
-                         "whole_step_frac": round(value / world * gf_pair * 1e9 / (peak * 1e12), 4),
-                         "whole_step_tflops": round(value / world * gf_pair / 1e3, 1),
-                         "gflop_per_pair": round(gf_pair, 1),
-                         "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
-                                               sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
-                         "sum_kernel_ms_per_step": round(1e3 * kern_total, 2),
-                         "note": "per-kernel figures from one extra step with the two HIP streams serialised; "
-                                 "value/ms_per_step measured with async weight gradients on"},
+            "roofline": roofline_of(m, w, world),
         }
+        if m["dist"]:
+            result["distributed"] = m["dist"]
         if alt:
             result["alt_math"] = alt
         if world == 1 and not args.no_cpu_baseline and args.ways == 1 and args.shots == 1:
@@ -535,6 +644,23 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters, net=net, bucket=bucket, dev=dev,
                                                   full=args.cpu_baseline_full)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+    if world == 1 and headline and not args.no_other_configs:
+        # the secondary BASELINE configurations that fit one GPU, timed by the same command (3 warm-up + 5 timed steps each,
+        # their own roofline): configs[2] = 5-shot, batch 16; configs[4] = 2-way 512^2, T = 10, one fp16 plane, at its
+        # per-GPU batch of 4 (global batch 32 across 8 GPUs)
+        del net, bucket, inp, m
+        torch.cuda.empty_cache()
+        result["other_configs"] = {}
+        for name, ow in (("configs[2]", {"ways": 1, "shots": 5, "size": 256, "iters": 5, "batch": 16, "conv_math": "f16x2"}),
+                         ("configs[4]", {"ways": 2, "shots": 1, "size": 512, "iters": 10, "batch": 4, "conv_math": "f16"})):
+            om = measure(ow, 1, 0, dev, cfg, 5, 3, RF)
+            result["other_configs"][name] = {
+                "workload": workload_text(ow, 1), "value": round(om["value"], 3), "unit": "pairs/s", "steps": 5, "warmup": 3,
+                "ms_per_step": round(1e3 * om["el"] / 5, 3), "dtype": "f16" if om["math"] == "f16" else "f32",
+                "conv_math": om["math"], "launches_by_arithmetic": om["arith"], "roofline": roofline_of(om, ow, 1)}
+            del om
+            torch.cuda.empty_cache()
+        RF.set_conv_math(requested)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -543,4 +669,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker(sys.argv[2:])
+    else:
+        main()

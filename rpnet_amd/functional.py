@@ -176,7 +176,11 @@ def reset_absmax_pool(device):
 def _absmax_slot(device):
     pool = _ABSMAX.get(device)
     if pool is None or pool[1] >= _ABSMAX_SLOTS:
+        # a fresh pool may be asked for on a side stream (the eval-mode CRE runs w_q there) while the main stream takes the
+        # next slot without waiting: its zero fill must be complete for EVERY stream before the first slot is handed out,
+        # or a later atomic max of another stream could land in front of it
         pool = _ABSMAX[device] = [torch.zeros(_ABSMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        torch.cuda.current_stream(device).synchronize()
     pool[1] += 1
     return pool[0][pool[1] - 1:pool[1]]
 
@@ -412,7 +416,9 @@ class WeightCache:
         self._d.clear()
 
     def get(self, weight, split=None):
-        key = (weight.data_ptr(), weight._version)
+        # the split (channel ranges of the gathered sources) is part of what a pack IS: a layer fetched once without and
+        # once with its ranges must not share one
+        key = (weight.data_ptr(), weight._version, None if split is None else tuple(split))
         pw = self._d.get(key)
         if pw is None:
             pw = PackedWeight(weight.detach(), split)
@@ -446,7 +452,9 @@ TUNE = {"tile": int(os.environ.get("RPNET_TUNE_TILE", "0")) + (0 if os.environ.g
 
 
 def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups=1, ep_scale=None, ep_shift=None,
-          ep_relu=0, out_scale=None, out_mode=0, accumulate=0, co_split=None):
+          ep_relu=0, out_scale=None, out_mode=0, accumulate=0, co_split=None, wgrad=False):
+    """wgrad: the descriptor goes to rpnet_conv_wgrad (its `tune` field then carries TUNE["wgrad"], not the tile variant of
+    the forward kernels: the two entry points read the field differently)"""
     d = ConvDesc()
     d.x0, d.x1 = ptr(x0), ptr(x1)
     d.C0 = x0.shape[-1]
@@ -459,7 +467,7 @@ def _desc(x0, x1, w, bias, in_scale, in_mode, y0, y1, N, H, W, taps, ups, groups
     d.ep_scale, d.ep_shift, d.ep_relu = ptr(ep_scale), ptr(ep_shift), ep_relu
     d.out_scale, d.out_scale_mode, d.accumulate = ptr(out_scale), out_mode if out_scale is not None else 0, accumulate
     d.N, d.H, d.W, d.taps, d.upsample, d.groups = N, H, W, taps, ups, groups
-    d.tune = TUNE["tile"]
+    d.tune = TUNE["wgrad"] if wgrad else TUNE["tile"]
     return d
 
 
@@ -685,13 +693,13 @@ class ConvBnRelu(Function):
             if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)
                 dyp = dys
                 d = _desc(ctx.xs[0], ctx.xs[1], None, None, None, 0, None, None, N, H, W, pw.taps, upsample,
-                          co_split=(cout, 0))
-                d.split_planes, d.tune = np_, TUNE["wgrad"]
+                          co_split=(cout, 0), wgrad=True)
+                d.split_planes = np_
                 if np_ <= 2:
                     d.acc_scale_x, d.acc_scale_dy, d.acc_scale_x1 = ptr(ctx.sx), ptr(sdy), ptr(ctx.sx1)
             else:
                 dyp = dy
-                d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample)
+                d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample, wgrad=True)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             if _direct(weight):
                 dev = y.device
@@ -842,10 +850,10 @@ class ConvRelu(Function):
         dw = torch.empty_like(weight)
         dys = split_bf16(dy, xs.shape[0]) if xs is not None and cout % 32 == 0 else None
         if dys is not None and dilation <= 1 and pw.cin % 64 == 0 and cout % 64 == 0:
-            d = _desc(xs, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            d = _desc(xs, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0, wgrad=True)
             d.split_planes, dyp = xs.shape[0], dys
         else:
-            d = _desc(x, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0)
+            d = _desc(x, None, None, None, None, 0, dy, None, N, H, W, pw.taps, 0, wgrad=True)
             dyp = dy
         d.Co0, d.dilation = cout, dilation
         wb2 = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
@@ -959,7 +967,7 @@ class MaxPool2(Function):
 def maxpool2(op):
     """MaxPool2 on an Operand: the pooled values are a subset of the source's, so its fp16 tensor scale still bounds them"""
     op = as_operand(op)
-    return op.derive(MaxPool2.apply(op.x))
+    return op.derive(MaxPool2.apply(op.values()))
 
 
 def mask_avgpool(mask, scale):
@@ -1009,9 +1017,12 @@ class LocalCorr(Function):
             call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None, None)
             ctx.save_for_backward(f1s, f2s)
         else:
+            # the fp32 kernels read VALUES: a planes-only operand (a 4-byte placeholder behind f1 / f2) must raise here,
+            # not be read out of bounds
+            v1, v2 = o1.values(), o2.values()
             ARITH[("corr", "f32")] += 1
-            call("rpnet_local_corr_fwd", ptr(f1), ptr(f2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
-            ctx.save_for_backward(f1, f2)
+            call("rpnet_local_corr_fwd", ptr(v1), ptr(v2), ptr(corr), B, h, w, Cc, r, CORR_STRIDE)
+            ctx.save_for_backward(v1, v2)
         ctx.r, ctx.np_, ctx.shape = r, np_, tuple(f1.shape)
         return corr, f1.view_as(f1)
 

@@ -162,7 +162,9 @@ class U_Net(Unet_2D):
         pool = RF.maxpool2
         # f16x2 training: pooled, concatenated and masked consumers split the fp32 tensor themselves (one joint tensor
         # scale per convolution), so those producers skip their own operand planes
-        sk = "scale" if (RF.f16_mode() and self.training) else True
+        # (eval mode too: the measured-scale branch of rpnet_bn... emits only the scale — the planes of x1..x4, d5 and the
+        # up-convolution outputs would be written and never read)
+        sk = "scale" if RF.f16_mode() else True
         # x1 and x2 feed nothing but their pool (:442-448; x3 and x4 are also skip connections): in training the pooled
         # tensor comes out of the block's last BatchNorm + ReLU pass (p1 / p2 are then already pooled) unless a mask
         # channel is concatenated behind the pool
@@ -288,7 +290,7 @@ class ContextCorrelationEncoder(nn.Module):
         # fm1 / fm2 feed the correlation and (fm1) the 1x1 convolution, both of which read fp16 planes in f16x2 / f16
         # training: their fp32 form is then never written (RF.conv_bn_relu_op(z_unused); a consumer that wanted the
         # values would raise)
-        zu = _ZSKIP and sp == "corr" and RF._CORR16 and RF._CONV1X1_SPLIT
+        zu = _ZSKIP and sp == "corr" and RF._CORR16 and RF._CONV1X1_SPLIT and self.w_k[0].weight.shape[0] % 128 == 0
 
         def w_k():
             return RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask,

@@ -52,7 +52,8 @@ def oracle_step(cfg, inputs, dtype=torch.float32, input_scale=1.0, noise=None):
     from oracle import rpnet_oracle as O
     si, fg, bg, qi, ql, appr = inputs
     P = {}
-    for k, v in O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True).items():
+    for k, v in O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True,
+                                mask_feature_map=cfg.get("mask_feature_map", False)).items():
         t = v.detach().to(dtype) if v.is_floating_point() else v.detach().clone()
         P[k] = t.clone().requires_grad_(v.requires_grad)
     c = lambda t: t.to(dtype)  # noqa: E731

@@ -117,3 +117,51 @@ def test_bench_two_ranks_on_one_gpu():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    # what a multi-GPU line must carry so that "did the collective library see N ranks" can be answered from the line
+    dinfo = res["distributed"]
+    assert dinfo["rccl_ranks_seen"] == 2 and dinfo["world_size"] == 2 and dinfo["backend"].startswith("gloo")
+    assert dinfo["allreduce_exposed_ms"] >= 0 and len(dinfo["bucket_segments_mb"]) == 3
+
+
+def _train_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rpnet_amd.modules as RM
+    from tests.helpers import load_cfg
+    from train_rpnet import train
+    RM._F16_MIN_PIXELS = 0
+    cfg = load_cfg(2)
+    torch.manual_seed(rank)          # different seeds: only the broadcast makes the replicas equal
+    net, hist = train(cfg, steps=4, batch=2, size=64, dev=torch.device("cuda:0"), lr=1e-3, log_every=0, seed=7)
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().flatten() for p in net.parameters()]).cpu().numpy()
+    q.put((rank, hist, flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_driver_on_one_gpu():
+    """train_rpnet.py under two ranks (gloo, both on the one GPU): four Adam steps on per-rank episodes with the flat-bucket
+    exchange -> both replicas hold bit-identical parameters afterwards (and they moved), the per-rank losses differ
+    (different episodes)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, h0, f0), (_, h1, f1) = res
+    f0, f1 = torch.from_numpy(f0), torch.from_numpy(f1)
+    assert torch.equal(f0, f1)
+    assert all(map(lambda v: v == v, h0 + h1)) and h0 != h1
+    from rpnet_amd.modules import RP_Net
+    from tests.helpers import load_cfg
+    torch.manual_seed(0)             # rank 0's initial parameters (what the broadcast replicated)
+    ref = RP_Net(cfg={"align": True, "backbone": "UNet"}, backbone_cfg=load_cfg(2))
+    start = torch.cat([p.detach().flatten() for p in ref.parameters()])
+    assert float((f0 - start).abs().max()) > 1e-4       # the optimizer stepped (Adam, lr 1e-3, four steps)

@@ -276,6 +276,104 @@ def test_f16_two_way_vs_fp32_oracle(f16_single, size, B, T):
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
 
 
+F16_YARD_EPS = (5e-4, 1.5e-3, 5e-3)     # relative input perturbations: 2^-11 (one fp16 rounding of the image) and two steps up
+
+
+@pytest.mark.parametrize("size,B,T", [(64, 2, 3), (128, 1, 3)])
+def test_f16_gradients_vs_perturbation_yardstick(f16_single, size, B, T):
+    """Gradients of the one-plane fp16 step with the yardstick of tests/test_gpu_model.py::test_gradients_vs_fp64_yardstick
+    at fp16 scale: the reference point is the fp32 CPU oracle (2-way, composed from the reference's pieces); the yardstick is
+    how far the ORACLE's own gradients move (relative L2 per tensor, maximum over four draws) when every image pixel is
+    perturbed by eps relative, with eps the smallest of F16_YARD_EPS (starting at 2^-11, one fp16 rounding) whose median
+    effect on the oracle's logits is at least a third of the fp16 path's own forward deviation — i.e. a perturbation that
+    disturbs the forward pass no more than fp16 operands do.  Requirement: every gradient tensor of the fp16 step lies
+    within 3 yardsticks of the oracle's.  (The round-2 test only asked for cosine > 0.9.)"""
+    from oracle import rpnet_oracle as O
+    from tests.helpers import episode_tensors, load_cfg, oracle_step, rel_err
+    from tests.test_gpu_model import build, total_loss
+    RF = f16_single
+    cfg = load_cfg(T)
+    inputs, _ = episode_tensors(66 + size, B, size, "cpu", n_shots=1, n_ways=2)
+    si, fg, bg, qi, ql, appr = inputs
+    g0, l0, o0 = oracle_step(cfg, inputs)
+    net = build(cfg, True)
+    mv = lambda t: t.to(DEV)  # noqa: E731
+    out = net([[mv(s) for s in w] for w in si], [[mv(s) for s in w] for w in fg], [[mv(s) for s in w] for w in bg],
+              [mv(qi[0])], appr_query_labels=mv(appr))
+    total_loss(out, mv(ql), cfg["align_loss_scaler"]).backward()
+    assert set(RF.arith_counts()["conv3x3"]) == {"f16"}
+    fwd16 = rel_err(out["refinement"][0].detach(), o0["refinement"][0].detach())
+    assert fwd16 <= F16_LOGIT_TOL
+    for eps in F16_YARD_EPS:
+        yard, moves = {}, []
+        for draw in range(4):
+            gp, _, op = oracle_step(cfg, inputs, noise=(300 + draw, eps))
+            moves.append(rel_err(op["refinement"][0].detach(), o0["refinement"][0].detach()))
+            for n, v in gp.items():
+                nrm = float(g0[n].norm())
+                if nrm >= 1e-4:
+                    yard[n] = max(yard.get(n, 0.0), float((v - g0[n]).norm()) / nrm)
+        mid = sorted(moves)[len(moves) // 2]
+        if mid >= fwd16 / 3.0:
+            break
+    assert mid <= 3.0 * fwd16 or eps == F16_YARD_EPS[0], (eps, mid, fwd16)     # not inflated either
+    report = []
+    for n, p in net.named_parameters():
+        if p.grad is None or n not in yard:
+            continue
+        e = float((p.grad.double().cpu() - g0[n].double()).norm() / g0[n].double().norm())
+        report.append((e / yard[n], n, e, yard[n]))
+    report.sort(reverse=True)
+    print(f"f16 gradients at {size}^2: eps {eps:g}, forward deviation {fwd16:.1e} (perturbed oracle {mid:.1e}); worst err / yardstick",
+          [(round(r, 2), n, f"{a:.1e}", f"{b:.1e}") for r, n, a, b in report[:3]])
+    for ratio, n, e, y in report:
+        assert e <= 3.0 * y, f"{n}: fp16 step {e:.2e} from the oracle's gradient, yardstick (eps = {eps:g}) {y:.2e}"
+
+
+def test_f16x2_two_way_512_vs_fp32_oracle(RF):
+    """configs[4]'s image size and class count under the fp32-EQUIVALENT arithmetic against the CPU oracle itself (2-way 1-shot,
+    512x512, batch 1, T = 2; oracle in algorithmic mode: the all-pairs correlation of the as-written mode is a 1 GB tensor per
+    call here): logits of both iterations (the second teacher-forced with the oracle's mask), Dice, loss at the fp32 bar.
+    test_config5_full_size_f16 uses the f16x2 step as the yardstick of the fp16 tolerance at full size: this pins that
+    yardstick to the reference's arithmetic at the same size."""
+    from oracle import rpnet_oracle as O
+    from rpnet_amd import modules as RM
+    from tests.helpers import episode_tensors, load_cfg, rel_err
+    from tests.test_gpu_model import build, total_loss
+    old, old_min = RF.conv_math(), RM._F16_MIN_PIXELS
+    RF.set_conv_math("f16x2")
+    RM._F16_MIN_PIXELS = 0
+    try:
+        T, B, size = 2, 1, 512
+        cfg = load_cfg(T)
+        (si, fg, bg, qi, ql, appr), _ = episode_tensors(577, B, size, "cpu", n_shots=1, n_ways=2)
+        P = O.seeded_params()
+        with torch.no_grad():
+            ref = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True, as_written=False)
+            ref_loss = O.total_loss(ref, ql, cfg["align_loss_scaler"])
+        net = build(cfg, True)
+        net.forced_masks = _teacher_masks(ref["refinement"], T)
+        mv = lambda t: t.to(DEV)  # noqa: E731
+        RF.reset_arith()
+        with torch.no_grad():
+            out = net([[mv(s) for s in w] for w in si], [[mv(s) for s in w] for w in fg], [[mv(s) for s in w] for w in bg],
+                      [mv(qi[0])], appr_query_labels=mv(appr))
+            loss = total_loss(out, mv(ql), cfg["align_loss_scaler"])
+        counts = RF.arith_counts()
+        assert set(counts["conv3x3"]) == {"f16x2"} and set(counts["corr"]) == {"f16x2"}, counts
+        assert out["output"].shape == (B, 3, size, size)
+        for i in range(T):
+            got, want = out["refinement"][i].cpu(), ref["refinement"][i]
+            assert rel_err(got, want) < 1e-3, f"logits, iteration {i}: {rel_err(got, want):.2e}"
+            assert float((_pred(got) != _pred(want)).float().mean()) <= 2e-5          # <= 5 of 262144 pixels on the threshold
+            (d_g, f_g), (d_r, f_r) = _dice(got, ql), _dice(want, ql)
+            assert abs(d_g - d_r) <= 1e-3 and abs(f_g - f_r) <= 1e-3
+        assert abs(loss.item() - ref_loss.item()) <= 1e-3 * abs(ref_loss.item())
+    finally:
+        RM._F16_MIN_PIXELS = old_min
+        RF.set_conv_math(old)
+
+
 def test_f16_dice_at_config1_shape(f16_single):
     """configs[1]'s shape (1-way 1-shot, 256x256, T=5, batch 8), FREE-RUNNING, one fp16 plane against the fp32-equivalent
     arithmetic (f16x2, itself held to the reference's golden vectors at this size): Dice and foreground fraction of
@@ -348,8 +446,8 @@ def test_config5_full_size_f16(f16_single):
         (d_g, f_g), (d_r, f_r) = _dice(got, ql), _dice(want, ql)
         assert abs(d_g - d_r) <= F16_DICE_TOL and abs(f_g - f_r) <= F16_DICE_TOL, (i, d_g, d_r, f_g, f_r)
     assert abs(tf_loss.item() - ref_loss.item()) <= 1e-2 * abs(ref_loss.item())
-    # gradients against the fp32-equivalent step: same direction (conditioned by the ReLU / max-pool switches, which fp16
-    # operands flip for ~1e-3 of the activations: 12-25 % relative L2 per encoder tensor, measured)
+    # gradients against the fp32-equivalent step at FULL size: a sanity check of direction only (an oracle run of this size does
+    # not fit a test); the bound with a yardstick is test_f16_gradients_vs_perturbation_yardstick at 64^2 / 128^2
     g16 = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
     for n, p in ref_net.named_parameters():
         if p.grad is not None and p.grad.norm() > 1e-6:

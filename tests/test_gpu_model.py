@@ -74,6 +74,37 @@ def conv_math(request):
     RF.set_conv_math(old)
 
 
+YARD_EPS = 4e-7      # relative input perturbation of the yardstick: moves the fp64 forward as much as the HIP path deviates
+YARD_FLOOR = 5e-5    # relative L2: fp32 round-off of reductions over ~1e5 terms, where the yardstick itself is at round-off level
+_YARD_CACHE = {}     # tag -> fp64 oracle results (shared by the three arithmetics and by the two tests that use them)
+
+
+def _yardstick(tag, g):
+    """(fp64 gradients, fp64 loss, fp64 logits of iteration 0, {parameter: yardstick}, forward movements of the draws) of
+    fixture `tag`: the CPU oracle in FLOAT64 on the fixture's inputs, and how far ITS gradients move (relative L2, maximum
+    over the draws) when every image pixel is perturbed by YARD_EPS relative.  Six draws at 64^2 / 128^2, two at 256^2
+    (each is one fp64 forward + backward on the host)."""
+    from tests.helpers import oracle_step
+    if tag not in _YARD_CACHE:
+        size, B, T, _, seed = (int(v) for v in g["meta"])
+        cfg = load_cfg(T)
+        mfm = tag.rsplit("_", 1)[1] if tag.count("_") == 2 else None
+        if mfm:
+            cfg["mask_feature_map"] = mfm
+        cpu_inputs, _ = episode_tensors(seed, B, size)
+        g64, l64, o64 = oracle_step(cfg, cpu_inputs, dtype=torch.float64)
+        yard, fwd_moves = {}, []
+        for draw in range(6 if size < 256 else 2):
+            gp, _, op = oracle_step(cfg, cpu_inputs, dtype=torch.float64, noise=(100 + draw, YARD_EPS))
+            fwd_moves.append(rel_err(op["refinement"][0].detach(), o64["refinement"][0].detach()))
+            for n, v in gp.items():
+                nrm = float(g64[n].norm())
+                if nrm >= 1e-4:
+                    yard[n] = max(yard.get(n, 0.0), float((v - g64[n]).norm()) / nrm)
+        _YARD_CACHE[tag] = (g64, l64, o64["refinement"][0].detach(), yard, fwd_moves)
+    return _YARD_CACHE[tag]
+
+
 @pytest.mark.parametrize("tag", ["m64_train", "m64_eval", "m128_train", "m256_train", "m64_train_x", "m64_train_x2", "m64_train_x3"])
 def test_model_vs_golden(golden, tag, conv_math):
     g = golden(tag)
@@ -137,20 +168,24 @@ def test_model_vs_golden(golden, tag, conv_math):
             if ref < 1e-4:          # conv biases in front of train-mode BN: analytically zero
                 assert gr.abs().max() < 1e-4
                 continue
-            # Gradient NORMS and the first 32 elements against the reference's fixtures; the element-wise L2 comparison of
-            # every tensor with a reproducible yardstick (the fp64 oracle, err_HIP <= 3 err_fp32-oracle) is
-            # test_gradients_vs_fp64_yardstick, the conditioning behind it tests/test_oracle_conditioning.py (the fp32
-            # oracle itself sits 1e-3 from fp64 on the encoder weights and moves by 2e-3 under a 2e-6 input perturbation):
-            # the encoder bounds here are 5 x those measured movements, the smooth CRE block is held to 1e-3 (norms) / 4e-3 (heads).
+            # Gradient NORMS against the reference's fixtures.  The encoder gradients are conditioned by ReLU / max-pool /
+            # threshold switches (tests/test_oracle_conditioning.py), so their bound is not a constant but the measured
+            # conditioning of THIS episode: the reference's fp32 gradients and the HIP path's each lie within 3 yardsticks of
+            # the fp64 oracle's (test_gradients_vs_fp64_yardstick holds the HIP path to that, element-wise), hence their norms
+            # within 6 of each other.  The smooth CRE block is held to 1e-3 (norms) and 4e-3 (first 32 elements).
             enc = n.startswith("encoder.")
             e = abs(gr.double().norm().item() - ref) / ref
             worst = max(worst, e)
-            assert e < (1e-2 if enc else 1e-3), f"grad norm {n}: rel {e:.2e}"
+            if enc:
+                y = _yardstick(tag, g)[3][n]
+                assert e <= 6.0 * y + 1e-6, f"grad norm {n}: rel {e:.2e}, yardstick {y:.2e}"
+                continue
+            assert e < 1e-3, f"grad norm {n}: rel {e:.2e}"
             k = min(32, gr.numel())
             hd = torch.from_numpy(head[:k])
             he = (gr.flatten()[:k].cpu() - hd).abs().max() / (hd.abs().max() + 1e-12)
             # (CRE heads: 32 elements of a BatchNorm gamma / first filter; measured <= 2.6e-3 over the seven fixtures x three arithmetics)
-            assert he < (5e-2 if enc else 4e-3), f"grad head {n}: rel {he:.2e}"
+            assert he < 4e-3, f"grad head {n}: rel {he:.2e}"
         sd = net.state_dict()
         for k in g:
             if k.startswith("sd."):
@@ -546,18 +581,13 @@ def test_graphed_eval_matches_eager(fp16_planes):
     assert set(RF.arith_counts()["conv3x3"]) == {"f16x2" if fp16_planes else "bf16x3"}
 
 
-YARD_EPS = 4e-7      # relative input perturbation of the yardstick: moves the fp64 forward as much as the HIP path deviates
-YARD_DRAWS = 6
-_YARD_CACHE = {}     # tag -> fp64 oracle results (shared by the three arithmetics)
-
-
-@pytest.mark.parametrize("tag", ["m64_train", "m128_train"])
+@pytest.mark.parametrize("tag", ["m64_train", "m128_train", "m256_train"])
 def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
     """Backward parity with a reproducible yardstick instead of a loose constant.  Reference point: the CPU oracle in
     FLOAT64 on the same inputs.  Yardstick: how far the fp64 oracle's OWN gradients move when every image pixel is
     perturbed by YARD_EPS = 4e-7 relative (which moves the fp64 logits by 3e-6 .. 7e-6: the size of the HIP path's forward
     deviation from fp64 — both asserted below, so the yardstick is neither inflated nor starved) —
-    the maximum over YARD_DRAWS independent draws, per parameter tensor, relative L2.  Requirement: the HIP gradient is
+    the maximum over six independent draws (two at 256^2, the headline image size), per parameter tensor, relative L2.  Requirement: the HIP gradient is
     no further from the fp64 gradient than 3 x that movement.
     Why a perturbation and not "the fp32 oracle's distance to fp64": the distance is made of DISCRETE events — a
     pre-activation within the forward error of zero takes the other side of its ReLU (or max-pool / arg-max) — each
@@ -565,23 +595,10 @@ def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
     deviation enters at a single BatchNorm beta).  Whether an implementation hits such an event on a given episode is
     chance proportional to its forward error; the perturbation draws sample exactly that chance at the HIP path's error
     level (tests/test_oracle_conditioning.py is the CPU-only statement of the same sensitivity)."""
-    from tests.helpers import oracle_step
     g = golden(tag)
     size, B, T, _, seed = (int(v) for v in g["meta"])
     cfg = load_cfg(T)
-    cpu_inputs, _ = episode_tensors(seed, B, size)
-    if tag not in _YARD_CACHE:
-        g64, l64, o64 = oracle_step(cfg, cpu_inputs, dtype=torch.float64)
-        yard, fwd_moves = {}, []
-        for draw in range(YARD_DRAWS):
-            gp, _, op = oracle_step(cfg, cpu_inputs, dtype=torch.float64, noise=(100 + draw, YARD_EPS))
-            fwd_moves.append(rel_err(op["refinement"][0].detach(), o64["refinement"][0].detach()))
-            for n, v in gp.items():
-                nrm = float(g64[n].norm())
-                if nrm >= 1e-4:
-                    yard[n] = max(yard.get(n, 0.0), float((v - g64[n]).norm()) / nrm)
-        _YARD_CACHE[tag] = (g64, l64, o64["refinement"][0].detach(), yard, fwd_moves)
-    g64, l64, logits64, yard, fwd_moves = _YARD_CACHE[tag]
+    g64, l64, logits64, yard, fwd_moves = _yardstick(tag, g)
     net = build(cfg, True)
     (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV)
     out = net(si, fg, bg, qi, appr_query_labels=appr)
@@ -607,8 +624,11 @@ def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
     report.sort(reverse=True)
     print(f"{tag} [{conv_math}]: forward deviation {fwd_hip:.1e} (perturbed fp64: {max(fwd_moves):.1e}); worst err_HIP / yardstick:",
           [(round(r, 2), n, f"{a:.1e}", f"{b:.1e}") for r, n, a, b in report[:3]], "median ratio", round(report[len(report) // 2][0], 2))
+    # + YARD_FLOOR: where the function is smooth (the CRE's 1x1 block: yardstick = the perturbation's own 3e-6) what remains is
+    # fp32 round-off of the reductions themselves — a BatchNorm beta gradient at 256^2 is a sum of B h w T = 41 000 fp32 terms,
+    # sqrt(41 000) x 6e-8 = 1.2e-5 relative; measured 2.5e-5 on cre.q.1.bias with yardstick 5e-6 — not conditioning
     for ratio, n, e_hip, y in report:
-        assert e_hip <= 3.0 * y, f"{n}: HIP {e_hip:.2e} from the fp64 gradient, yardstick (fp64 oracle under a {YARD_EPS} input perturbation) {y:.2e}"
+        assert e_hip <= 3.0 * y + YARD_FLOOR, f"{n}: HIP {e_hip:.2e} from the fp64 gradient, yardstick (fp64 oracle under a {YARD_EPS} input perturbation) {y:.2e}"
 
 
 @pytest.mark.parametrize("tag", ["cb", "up"])

@@ -10,7 +10,7 @@ real data is wired in (§8f.4).  One process per GPU; gradients are exchanged th
 bucket (RCCL all-reduce); BatchNorm statistics stay per rank like the reference (no SyncBN).
 
     python train_rpnet.py --yaml yamls/example.yml --steps 100
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_rpnet.py --steps 100
+    tools/launch_ddp.sh 8 train --steps 100        (= python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 ...)
 """
 import argparse
 import os
@@ -103,12 +103,16 @@ def main():
     a = ap.parse_args()
     config, _ = load_yaml(a.yaml)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RPNET_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; gloo for one-GPU plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     train(config, a.steps, a.batch or config["batch_size"], a.size, dev, lr=a.lr, out_dir=a.out_dir or config.get("out_dir"))
     if world > 1:
         dist.destroy_process_group()
