@@ -261,12 +261,30 @@ def eval_leg(net, cfg, dev, size, RF):
                 finally:
                     RF.call = orig
                     RM._CRE_STREAMS = cre_streams
+            # the same call replayed from a HIP graph (rpnet_amd.graph.GraphedEval: the serving form; packs and folded BatchNorm
+            # affines are then made once, outside the replay)
+            from rpnet_amd.graph import GraphedEval
+            frozen = net.freeze_packs
+            try:
+                ge = GraphedEval(net)
+                for _ in range(3):
+                    ge(si, fg, bg, qi, appr_query_labels=appr)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    ge(si, fg, bg, qi, appr_query_labels=appr)
+                torch.cuda.synchronize()
+                ms_graph = (time.perf_counter() - t0) / n * 1e3
+            finally:
+                net.freeze_packs = frozen
+                net._cache.clear()
             fl = sum(r[0] for r in recs)
             tt = sum(r[2].elapsed_time(r[3]) for r in recs) * 1e-3
             planes = max((r[1] for r in recs if r[0] > 1e9), default=0)
             math = {0: "f32", 1: "f16", 2: "f16x2", 3: "bf16x3"}[planes]
             peak = MATH[math][1]
-            out["calls"].append({"batch": B, "ms_per_call": round(ms, 3), "value": round(B / ms * 1e3, 1), "unit": "pairs/s (forward)",
+            out["calls"].append({"batch": B, "ms_per_call": round(ms, 3), "ms_per_call_graph_replay": round(ms_graph, 3),
+                                 "value": round(B / ms * 1e3, 1), "unit": "pairs/s (forward)",
                                  "conv_math": math, "launches_by_arithmetic": RF.arith_counts(),
                                  "roofline": {"bound": "mfma", "kernel": "rpnet_conv_fwd launches", "achieved": round(fl / tt / 1e12, 2),
                                               "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / peak, 4),
@@ -274,6 +292,9 @@ def eval_leg(net, cfg, dev, size, RF):
     finally:
         net.num_iter = old_T
         net.train(was_training)
+    # eval-mode fp16 planes run on scales predicted from the previous call (rpnet_amd.functional.pred_*): how many calls did,
+    # and how many had to be redone on measured scales because a layer's maximum outgrew its prediction
+    out["fp16_scale_prediction"] = RF.pred_stats()
     return out
 
 

@@ -84,6 +84,12 @@ int rpnet_pack_conv_weight(const float* w, float* wp, float* wd, int cout, int c
 int rpnet_split_bf16(const float* x, const float* scale, int scale_mode, void* out, size_t rows, int C, int planes,
                      rpnet_stream_t stream);
 /* *s_out = the power-of-two tensor scale for a tensor bounded by *bound (maps the bound to <= 2^15); see out_absmax */
+/* Predicted fp16 tensor scales for eval-mode layers (running statistics give no a-priori bound, net/modules.py:48): slot i of
+ * `measured` holds max |output| of layer launch i of the call that just ended (rpnet_conv_desc.out_absmax).  For i < n:
+ * if check != 0 and measured[i] > bound[i] (the bound the call RAN with), *violations is incremented — the caller must redo
+ * the call on measured scales; then bound[i] = pow2ceil(measured[i] * safety), scale[i] = bound[i] * 2^-15 for the next call. */
+int rpnet_predict_scales(const float* measured, float* bound, float* scale, int n, float safety, int check, int* violations,
+                         rpnet_stream_t stream);
 int rpnet_pow2_scale(const float* bound, float* s_out, rpnet_stream_t stream);
 int rpnet_split_f16(const float* x, const float* mask, int mask_mode, const float* s_a, const float* s_b, float* s_out,
                     void* out, size_t rows, int C, int planes /* 2, or 1: plain fp16 (RPNET_CONV_MATH=f16) */,
@@ -175,6 +181,11 @@ typedef struct rpnet_conv_desc {
                                           epilogue; results are then meaningless).  Bit 16: the default policy without the
                                           LDS-DMA kernel (A/B).  Carried here, not in the environment: the library keeps no
                                           global state */
+    const float* y_split_scale;        /* optional with y_split and split_out_planes 2 / 1: the planes are fp16 planes of output / *y_split_scale
+                                          (a power-of-two tensor scale the CALLER predicted, e.g. from the layer's maximum in the
+                                          previous call: rpnet_predict_scales; out_absmax of the same launch is the check).
+                                          NULL: the planes of the unscaled output (three bf16 planes, or fp16 planes of values the
+                                          caller knows to be <= 2^15) */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);

@@ -76,6 +76,7 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
     float amax = 0.f;
     unsigned short* ys = reinterpret_cast<unsigned short*>(d.y_split);
     const size_t yplane = (size_t)M * Cout;
+    const float ysinv = (ROWOPS && d.y_split && d.y_split_scale) ? 1.f / *d.y_split_scale : 1.f;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         // ---- MFMA layout -> slab: column-wise work
@@ -162,7 +163,7 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
                 if (RowMap::kAlwaysValid || row >= 0) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8]);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(&slab[rr * SW + cg * 8 + 4]);
-                    const float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
                     const size_t o = (size_t)row * Cout + colbase + cg * 8;
                     if (d.split_out_planes == 3) {
                         u32x4 pl[3];
@@ -170,10 +171,19 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
 #pragma unroll
                         for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(ys + p * yplane + o) = pl[p];
                     } else {
-                        u32x4 pl[2];
-                        split8<2>(v8, pl);
+                        // fp16 planes of output / scale (a predicted power-of-two tensor scale: exact)
 #pragma unroll
-                        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * yplane + o) = pl[p];
+                        for (int k = 0; k < 8; ++k) v8[k] *= ysinv;
+                        if (d.split_out_planes == 2) {
+                            u32x4 pl[2];
+                            split8<2>(v8, pl);
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * yplane + o) = pl[p];
+                        } else {
+                            u32x4 pl[1];
+                            split8<1>(v8, pl);
+                            *reinterpret_cast<u32x4*>(ys + o) = pl[0];
+                        }
                     }
                 }
             }

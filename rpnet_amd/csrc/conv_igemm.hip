@@ -266,8 +266,10 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
     RPNET_REQUIRE(!d->stats_partial || rpnet_conv_stats_blocks(d) > 0, RPNET_ERR_SHAPE,
                   "conv_fwd: statistic groups do not split into whole tiles; use rpnet_bn_stats");
     RPNET_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), RPNET_ERR_SHAPE, "conv_fwd: odd size with upsample");
-    RPNET_REQUIRE(!d->y_split || (d->Co1 == 0 && (d->split_out_planes == 2 || d->split_out_planes == 3)), RPNET_ERR_ARG,
-                  "conv_fwd: y_split needs a single destination and 2 or 3 planes");
+    RPNET_REQUIRE(!d->y_split || (d->Co1 == 0 && d->split_out_planes >= 1 && d->split_out_planes <= 3), RPNET_ERR_ARG,
+                  "conv_fwd: y_split needs a single destination and 1 to 3 planes");
+    RPNET_REQUIRE(!d->y_split || d->split_out_planes == 3 || d->y_split_scale, RPNET_ERR_ARG,
+                  "conv_fwd: fp16 output planes (split_out_planes 1 / 2) need y_split_scale");
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
     RPNET_REQUIRE((size_t)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) &&
                       (size_t)d->taps * Cin * Cout * 4 < (1UL << 31),

@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 
 __global__ void pow2_scale_kernel(const float* __restrict__ bound, float* __restrict__ s_out) { *s_out = pow2_scale(*bound); }
 
+__global__ __launch_bounds__(256) void predict_scales_kernel(const float* __restrict__ measured, float* __restrict__ bound,
+                                                              float* __restrict__ scale, const int n, const float safety,
+                                                              const int check, int* __restrict__ violations) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float m = measured[i];
+    if (check && m > bound[i]) atomicAdd(violations, 1);
+    const float s = pow2_scale(m * safety);
+    scale[i] = s;
+    bound[i] = s * 32768.f;
+}
+
 // power-of-two row scales of the fp16 weight planes: t[cout] over (cin, tap), u[gathered cin row] over (cout, tap)
 __device__ __forceinline__ void weight_row_scale_block(const int b, const float* __restrict__ w, float* __restrict__ t,
                                                        float* __restrict__ u, int cout, int cin_w, int taps, int off0, int split,
@@ -889,6 +901,7 @@ static const SplitVariant kSplitVariants[] = {
     {2, 4, 2, 0, 512},    // 10: 256 x 128 on an image patch with FOUR waves (wave tile 128 x 64), two blocks per CU
     {2, 4, 2, 0, 256},    // 11: 256 x 128 on an image patch, four waves (one per SIMD), operands by LDS-DMA (conv_split_dma.hip)
     {2, 4, 1, 0, 256},    // 12: 256 x 64 of the same kernel (wave tile 128 x 32)
+    {2, 4, 2, 0, 256},    // 13: 256 x 128 of the same kernel on ONE fp16 plane, 64 channels per K-step
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -926,6 +939,8 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = (d->tune & 0xff) - 1;      // bits 8..: ablation switches of conv_split_dma.hip
         if (v == 12 && d->split_planes == 2 && halo_tw(d, Cout)) return v;
+        if (v == 13 && d->split_planes == 1 && halo_tw(d, Cout) && halo_bn(d, Cout) == 128 && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0)
+            return v;
         if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2)) && halo_tw(d, Cout) &&
              halo_bn(d, Cout) == 128) ||
             ((v == 8 || v == 9) && halo4_tw(d)))
@@ -939,6 +954,10 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     // one fp16 plane: a third of the MFMAs per staged byte, so the LDS fragment reads limit the 8-wave patch kernel; the
     // 4-wave form of it (wave tile 128 x 64, two blocks per CU) reads 25 % less per MFMA: 598 vs 531 TF on 128 -> 128 at
     // M = 262144, 767 vs 671 TF on 256 -> 256 at M = 65536 — once its grid fills both block slots of every CU
+    // (round 3: where channel counts come in multiples of 64 the LDS-DMA kernel takes these layers — variant 13)
+    if (d->split_planes == 1 && !(d->tune & 0x10000) && hbn == 128 && halo_tw(d, Cout) && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 &&
+        (long)(M / 256) * (Cout / 128) >= 192)
+        return 13;
     if (d->split_planes == 1 && hbn == 128 && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 128) >= 512)
         return 10;
     // 256 x 128 patches, one block per CU: two fp16 planes -> the LDS-DMA kernel (conv_split_dma.hip: +14 ... 20 % over the
@@ -982,6 +1001,7 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 3: return launch_split<2, 1, 1, false>(d, M, Cin, Cout, s);
         case 11: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
         case 12: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s);
+        case 13: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
         case 10:
             return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:
@@ -1011,6 +1031,17 @@ extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mo
     hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
                        (unsigned short*)out, n8, C / 8, rows * (size_t)C);
     return check_launch("split_bf16");
+}
+
+extern "C" int rpnet_predict_scales(const float* measured, float* bound, float* scale, int n, float safety, int check, int* violations,
+                                    rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(measured && bound && scale && (!check || violations), RPNET_ERR_ARG, "predict_scales: null pointer");
+    RPNET_REQUIRE(n >= 0 && safety >= 1.f, RPNET_ERR_ARG, "predict_scales: n %d safety %g", n, (double)safety);
+    if (n == 0) return RPNET_OK;
+    hipLaunchKernelGGL(predict_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, measured, bound, scale, n, safety,
+                       check, violations);
+    return check_launch("predict_scales");
 }
 
 extern "C" int rpnet_pow2_scale(const float* bound, float* s_out, rpnet_stream_t stream) {

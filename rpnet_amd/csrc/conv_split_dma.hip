@@ -33,7 +33,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int TW, int NP, int WN>
+// K64: ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]) in the same LDS geometry — a K-step is one tap of 64
+// channels, whose two 32-channel halves take the places of the two planes (NP stays 2 for every byte count): half p of the
+// halo / weight slab comes from channels +32 p of the single plane, and the products are the diagonal ones (half p of the
+// pixels x half p of the weights): 32 MFMAs per wave and step for the same 24 fragment reads.
+template <int TW, int NP, int WN, bool K64 = false>
 __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
                                                                        const int tiles_n, const int ntiles) {
     constexpr int BM = 256, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
@@ -64,10 +68,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     const int n = tm / ppi, prem = tm - n * ppi;
     const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
 
-    const int kchunks = Cin >> 5;
+    constexpr int CSH = K64 ? 6 : 5;               // channels per K-step: 64 (one plane, two halves) or 32 (per plane)
+    const int kchunks = Cin >> CSH;
     const int nsteps = 9 * kchunks;
     const int rot = (int)(blockIdx.x % (unsigned)kchunks);
-    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << 5; };
+    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << CSH; };
 
     const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
     const size_t planew = (size_t)9 * Cin * Cout;
@@ -76,9 +81,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     const unsigned short* wq = reinterpret_cast<const unsigned short*>(d.w);
     // one descriptor per tensor over all its planes (the plane is part of the scalar offset): 12 SGPRs instead of 36
     const int pb0 = (int)(plane0 * 2), pb1 = (int)((d.x1 ? plane1 : plane0) * 2), pbw = (int)(planew * 2);
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p), (short)0, NP * pb0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x1p), (short)0, NP * pb1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), (short)0, NP * pbw, 0x00020000);
+    constexpr int NPM = K64 ? 1 : NP;              // planes in memory
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p), (short)0, NPM * pb0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x1p), (short)0, NPM * pb1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), (short)0, NPM * pbw, 0x00020000);
+    // scalar offset of plane / half p inside a source and inside the weights (K64: the next 32 channels = 64 bytes further in a
+    // pixel's row; the next 32-channel weight slab Cout rows of 64 bytes further)
+    const int ps0 = K64 ? 64 : pb0, ps1 = K64 ? 64 : pb1, psw = K64 ? Cout * 64 : pbw;
 
     // DMA lane geometry: lane l of a 1 KB piece writes the 16 bytes at piece + 16 l = row (l >> 2), slot (l & 3); the slot
     // holds k-group (slot ^ ((row >> 2) & 3)), and pieces start at multiples of 16 rows, so the k-group is a lane constant
@@ -108,20 +117,20 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + p * A_BYTES + hpos[i] * 1024);
-            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, soff + p * pb0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, soff + p * pb1, 0, 0);
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, soff + p * ps0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, soff + p * ps1, 0, 0);
         }
     };
     // weights: this wave moves rows 16 WN wv .. of every plane of a slab (WN pieces each)
     const int wvoff = (16 * WN * wv + drow) * 64 + dkg16;
     auto dma_w = [&](int tap, int c0, int stage) {
-        const int wsoff = ((tap * kchunks + (c0 >> 5)) * Cout + n0) * 64;
+        const int wsoff = ((tap * (Cin >> 5) + (c0 >> 5)) * Cout + n0) * 64;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int q = 0; q < WN; ++q) {
                 auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * psw, 0, 0);
             }
     };
 
@@ -161,13 +170,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
             aaddr[i] = hr * 64 + 16 * (h ^ ((hr >> 2) & 3));
         }
     };
-    constexpr int NR = NP * (WM + WN), NMMA = nprod<NP>() * WM * WN;
+    constexpr int NPROD = K64 ? 2 : nprod<NP>();
+    constexpr int NR = NP * (WM + WN), NMMA = NPROD * WM * WN;
+    static_assert(NR <= NMMA, "one fragment read of the next slice behind each MFMA of this one");
     // read k of a slice, in order of first use: plane order of A = (NP-1 .. 0), of B = (0 .. NP-1); per plane pair: A tile 0,
     // the B tiles, the other A tiles
     auto read_frag = [&](auto sc, auto kc, const int abase, const int bbase) {
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
         constexpr int grp = k / (WM + WN), r = k - grp * (WM + WN);      // grp-th plane pair
-        constexpr int pa = NP - 1 - grp, pb = grp;
+        constexpr int pa = K64 ? grp : NP - 1 - grp, pb = grp;
         if constexpr (r == 0 || r > WN) {
             constexpr int i = r == 0 ? 0 : r - WN;
             af[s][pa][i] = *reinterpret_cast<const bf16x8*>(smem + abase + (aaddr[i] ^ (32 * s)) + pa * A_BYTES);
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     auto mma_one = [&](auto sc, auto mc) {
         constexpr int s = decltype(sc)::value, m = decltype(mc)::value;
         constexpr int q = m / (WM * WN), ij = m - q * (WM * WN), i = ij / WN, j = ij - i * WN;
-        constexpr int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
+        constexpr int pa = K64 ? q : prod_a<NP>(q), pb = K64 ? q : prod_b<NP>(q);
         acc[i][j] = mma16<NP>(af[s][pa][i], bfr[s][pb][j], acc[i][j]);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     auto dma_w_one = [&](auto ec, const int wsoff, const int stage) {
         constexpr int e = decltype(ec)::value, p = e / WN, q = e - p * WN;
         auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * psw, 0, 0);
     };
 
     // ---- prologue: halo of chunk 0, weight slabs of steps 0, 1, 2
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         // the tail of the last chunk re-fetches valid data into buffers nobody reads again (uniform DMA counts)
         constexpr int t3 = TAP + 3 < 9 ? TAP + 3 : TAP - 6;
         const int c3 = chunk_c0((TAP + 3 < 9 || last_chunk) ? ci : ci + 1);
-        const int wsoff = ((t3 * kchunks + (c3 >> 5)) * Cout + n0) * 64;
+        const int wsoff = ((t3 * (Cin >> 5) + (c3 >> 5)) * Cout + n0) * 64;
         const int wstage = (ks + 3) & 3;
         const int abase = hb * HBUF, bbase = (ks & 3) * STAGE;
         static_for<NMMA>([&](auto mc) {
@@ -309,18 +320,26 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
                                                     li, h, smem);
 }
 
-// launcher for conv_split.hip: two fp16 planes, 128- (wn = 2) or 64-wide (wn = 1) output tiles, whole (256 / TW) x TW patches
+// launcher for conv_split.hip: two fp16 planes in 128- (wn = 2) or 64-wide (wn = 1) output tiles, or one fp16 plane in 64-channel
+// K-steps (128-wide tiles); whole (256 / TW) x TW patches
 int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s) {
     const int tiles_m = M / 256, tiles_n = Cout / (64 * wn);
     const int ntiles = tiles_m * tiles_n;
-    if (d->split_planes != 2) {
-        set_error("conv_igemm_split_dma: two fp16 planes only");
+#define RPNET_DMA(TWV, WNV, K64V) \
+    hipLaunchKernelGGL((conv_igemm_split_dma_kernel<TWV, 2, WNV, K64V>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles)
+    if (d->split_planes == 1) {
+        if (wn != 2 || Cin % 64 || d->C0 % 64) {
+            set_error("conv_igemm_split_dma: one plane needs 128-wide tiles and channel counts in multiples of 64 per source");
+            return RPNET_ERR_ARG;
+        }
+        if (tw == 32) RPNET_DMA(32, 2, true); else RPNET_DMA(16, 2, true);
+    } else if (d->split_planes == 2) {
+        if (wn == 2) { if (tw == 32) RPNET_DMA(32, 2, false); else RPNET_DMA(16, 2, false); }
+        else { if (tw == 32) RPNET_DMA(32, 1, false); else RPNET_DMA(16, 1, false); }
+    } else {
+        set_error("conv_igemm_split_dma: fp16 planes only");
         return RPNET_ERR_ARG;
     }
-#define RPNET_DMA(TWV, WNV) \
-    hipLaunchKernelGGL((conv_igemm_split_dma_kernel<TWV, 2, WNV>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles)
-    if (wn == 2) { if (tw == 32) RPNET_DMA(32, 2); else RPNET_DMA(16, 2); }
-    else { if (tw == 32) RPNET_DMA(32, 1); else RPNET_DMA(16, 1); }
 #undef RPNET_DMA
     return check_launch("conv_igemm_split_dma");
 }

@@ -185,6 +185,105 @@ def _absmax_slot(device):
     return pool[0][pool[1] - 1:pool[1]]
 
 
+# ---- predicted fp16 scales of eval-mode layers (round 3).  Running statistics give no a-priori bound of an eval-mode
+# BatchNorm output, so round 2 MEASURED every layer's maximum (out_absmax) and made the fp16 planes in a second pass over the
+# tensor — one extra pass per layer and a launch-to-launch dependency, which is why small calls (the reference driver's
+# batch of 2 slices) stayed on three bf16 planes.  Now: slot i of the absmax pool belongs to the same layer launch in every
+# call of the same shape, so the maxima of the PREVIOUS call (x PRED_SAFETY, rounded up to a power of two) predict this
+# call's bounds; the conv epilogue writes the fp16 planes of output / predicted scale directly (rpnet_conv_desc.y_split_scale)
+# while out_absmax still measures the truth.  pred_end() compares: a maximum above its predicted bound (fp16 would have
+# overflowed or lost its top bit) makes the caller redo the call on measured scales — counted in pred_stats().
+PRED_SAFETY = float(os.environ.get("RPNET_EVAL_PRED_SAFETY", "4"))
+_EVAL_PREDICT = os.environ.get("RPNET_EVAL_PREDICT", "1") == "1"
+_PRED = {}
+
+
+def _pred_state(device):
+    st = _PRED.get(device)
+    if st is None:
+        st = _PRED[device] = {"scale": torch.zeros(_ABSMAX_SLOTS, device=device), "bound": torch.zeros(_ABSMAX_SLOTS, device=device),
+                              "viol": torch.zeros(1, device=device, dtype=torch.int32), "key": None, "n": 0, "active": False,
+                              "calls": 0, "predicted_calls": 0, "violations": 0, "pending": False}
+    return st
+
+
+def pred_ready(device, key):
+    """does a history of this call shape exist (the previous eval call on this device had the same key)"""
+    st = _PRED.get(device)
+    return _EVAL_PREDICT and st is not None and st["key"] == key and st["n"] > 0
+
+
+def pred_begin(device, key, allow=True):
+    """start of an eval-mode forward on fp16 planes (after reset_absmax_pool): predicted scales are used when the previous
+    call had this key and `allow` (False: the redo after a violation)"""
+    st = _pred_state(device)
+    st["active"] = bool(allow and pred_ready(device, key))
+    st["calls"] += 1
+    st["predicted_calls"] += int(st["active"])
+    return st["active"]
+
+
+def pred_scale(device):
+    """the predicted scale (device scalar) of the absmax slot handed out last, or None when this call measures"""
+    st = _PRED.get(device)
+    pool = _ABSMAX.get(device)
+    if st is None or not st["active"] or pool is None or pool[1] > st["n"]:
+        return None
+    return st["scale"][pool[1] - 1:pool[1]]
+
+
+def pred_end(device, key):
+    """end of that forward: one launch compares the measured maxima with the bounds the call ran with (when it ran on
+    predictions) and turns them into the next call's predictions.  Returns True when the call must be redone on measured
+    scales (a maximum exceeded its predicted bound).  Inside a stream capture the comparison is recorded but not read:
+    pred_check_pending() reads it after the replay."""
+    st = _pred_state(device)
+    pool = _ABSMAX.get(device)
+    n = pool[1] if pool is not None else 0
+    ran_predicted = st["active"]
+    if ran_predicted and n != st["n"]:
+        raise RuntimeError(f"rpnet_amd: an eval call of key {key} took {n} absmax slots, its predecessor {st['n']}")
+    st["active"] = False
+    if n == 0:
+        st["key"], st["n"] = None, 0
+        return False
+    if ran_predicted:
+        st["viol"].zero_()
+    call("rpnet_predict_scales", ptr(pool[0]), ptr(st["bound"]), ptr(st["scale"]), n, PRED_SAFETY, 1 if ran_predicted else 0,
+         ptr(st["viol"]))
+    st["key"], st["n"] = key, n
+    if not ran_predicted:
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        st["pending"] = True
+        return False
+    bad = int(st["viol"].item()) > 0
+    st["violations"] += int(bad)
+    if bad:
+        st["key"], st["n"] = None, 0         # the redo measures and rebuilds the history
+    return bad
+
+
+def pred_check_pending(device):
+    """after replaying a captured eval forward that ran on predicted scales: did a maximum exceed its bound"""
+    st = _PRED.get(device)
+    if st is None or not st["pending"]:
+        return False
+    bad = int(st["viol"].item()) > 0
+    st["violations"] += int(bad)
+    return bad
+
+
+def pred_stats(device=None):
+    """{calls, predicted_calls, violations} of the eval-mode fp16 prediction (all devices summed when device is None)"""
+    out = {"calls": 0, "predicted_calls": 0, "violations": 0}
+    for dv, st in _PRED.items():
+        if device is None or dv == device:
+            for k in out:
+                out[k] += st[k]
+    return out
+
+
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
@@ -507,8 +606,10 @@ class ConvBnRelu(Function):
             # correlation consumer, the planes) follow from it; an output that wants neither keeps the plain path.
             want16 = f16_mode() and cout % 32 == 0 and bool(out_split) and (_CORR16 or out_split != "corr")
             mx = _absmax_slot(x0.device) if want16 else None
+            sp = pred_scale(x0.device) if want16 else None      # predicted scale of this launch (None: this call measures)
             np_out = _MATH["planes"] if (out_split in (True, "corr") and cout % 32 == 0 and not first and not want16) else 0
             zs = torch.empty((np_out, N, H, W, cout), device=x0.device, dtype=torch.bfloat16) if np_out else None
+            z16 = None
             if first:
                 call("rpnet_conv1_fwd", ptr(x0), ptr(weight), ptr(bias), ptr(z), ptr(scale), ptr(shift), N, H, W, cout, ptr(mx),
                      None, 1)
@@ -527,6 +628,11 @@ class ConvBnRelu(Function):
                               pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                     d.split_planes = np_
                 d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)
+                if sp is not None and out_split in (True, "corr"):
+                    # the fp16 planes of output / predicted scale straight out of the epilogue: no second pass over z
+                    fpo = _MATH["f16_planes"]
+                    z16 = torch.empty((fpo, N, H, W, cout), device=x0.device, dtype=torch.float16)
+                    d.y_split, d.split_out_planes, d.y_split_scale = ptr(z16), fpo, ptr(sp)
                 _cconv("rpnet_conv_fwd", d)
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
@@ -534,7 +640,14 @@ class ConvBnRelu(Function):
                 _cconv("rpnet_conv_fwd", d)
             if zs is not None:
                 produced["pbf"] = zs      # written by the conv epilogue: no separate split pass in eval mode
-            if want16:
+            if want16 and sp is not None:
+                if z16 is not None:
+                    produced["p16"], produced["scale"] = z16, sp
+                elif out_split in (True, "corr"):   # (first layer / fp32 kernels: a split pass, but no wait for the measured maximum)
+                    produced["p16"], produced["scale"] = split_f16(z, sp, want_scale=False)[0], sp
+                else:
+                    produced["scale"] = sp
+            elif want16:
                 if out_split in (True, "corr"):     # planes and scale from the measured bound in one launch
                     produced["p16"], produced["scale"] = split_f16(z, mx, a_is_bound=True)
                 else:

@@ -50,4 +50,15 @@ class GraphedEval:
         for dst, src in zip(static, args):
             dst.copy_(src)
         g.replay()
+        from . import functional as RF
+        if RF.pred_check_pending(args[0].device):
+            # the captured forward runs on fp16 scales predicted from the previous call (RF.pred_*); a maximum above its
+            # predicted bound invalidates this replay: redo the call eagerly on measured scales (the replay has already
+            # turned the new maxima into the next replay's predictions)
+            self.net._pred_redo = True
+            try:
+                with torch.no_grad():
+                    return self.net(supp_imgs, fore_mask, back_mask, qry_imgs, appr_query_labels=appr_query_labels)
+            finally:
+                self.net._pred_redo = False
         return out

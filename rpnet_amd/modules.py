@@ -397,10 +397,16 @@ class RP_Net(nn.Module):
         supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
         qry = qry_imgs[0].float()
         ns = supp.shape[0]
-        thr = _F16_MIN_PIXELS if (self.training or not _F16_MIN_PIXELS_EVAL or not _F16_MIN_PIXELS) else _F16_MIN_PIXELS_EVAL
+        # eval mode: with predicted scales (RF.pred_*: the previous call's maxima) the fp16 planes cost no extra pass, so they
+        # pay from the training threshold on; RPNET_EVAL_PREDICT=0 keeps round 2's measured scales and their higher threshold
+        thr = _F16_MIN_PIXELS if (self.training or not _F16_MIN_PIXELS_EVAL or not _F16_MIN_PIXELS or RF._EVAL_PREDICT) else _F16_MIN_PIXELS_EVAL
         RF.set_f16_active((ns + B) * H * W >= thr)      # f16x2 mode: fp16 planes only where they pay
+        pred_key = None
         if RF.f16_mode():
             RF.reset_absmax_pool(supp.device)       # measured fp16 scales (eval-mode layers, the correlation): one fill per forward
+            if not self.training and not torch.is_grad_enabled() and RF._EVAL_PREDICT:
+                pred_key = (id(self), RF.conv_math(), ns, B, H, W, self.num_iter, n_ways, n_shots, self.forced_masks is not None)
+                RF.pred_begin(supp.device, pred_key, allow=not getattr(self, "_pred_redo", False))
         planes = RF.pack_planes()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
@@ -478,6 +484,14 @@ class RP_Net(nn.Module):
         align_loss = 0
         if self.config["align"] and self.training:
             align_loss = self.alignLoss(inter, pred, supp_fts, fore, back)
+        if pred_key is not None and RF.pred_end(supp.device, pred_key):
+            # a layer's maximum exceeded the bound predicted from the previous call: redo this call on measured scales
+            self._pred_redo = True
+            try:
+                return self.forward(supp_imgs, fore_mask, back_mask, qry_imgs, registration_field, grid, query_labels,
+                                    appr_query_labels)
+            finally:
+                self._pred_redo = False
         return {"output": output, "align_loss": align_loss, "refinement": refinement}
 
     def _pack_weights(self):

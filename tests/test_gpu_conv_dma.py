@@ -199,3 +199,45 @@ def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W
         assert rel_err(dw_new, c_ref.weight.grad) < 1e-3
     finally:
         RF.set_conv_math(old)
+
+
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [
+    (2, 32, 32, 128, 0, 128, False),
+    (1, 16, 64, 128, 128, 256, False),   # two sources
+    (2, 32, 64, 64, 0, 128, True),       # nearest x2, ONE 64-channel K chunk
+    (3, 16, 48, 128, 128, 128, False),   # 16 x 16 patches
+])
+def test_dma_patch_kernel_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
+    """variant 13: the LDS-DMA kernel on ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]; a K-step = one tap of 64
+    channels whose halves sit where the two planes of f16x2 do).  Same products as the 4-wave one-plane kernel (variant 10)
+    in another order: equal to fp32 summation round-off; and within the f16 tolerance of the fp64 reference."""
+    old = RF.conv_math()
+    RF.set_conv_math("f16")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(c0 + c1, cout, 3, 71)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(72, N, c0, hs, ws)
+        b = rnd(73, N, c1, hs, ws) if c1 else None
+        go = rnd(74, N, cout, H, W)
+        z0, da0, db0, rv0, dw0, ch0 = _run(RF, monkeypatch, 10, layer, a, b, go, ups, groups)
+        z, da, db, rv, dw, ch = _run(RF, monkeypatch, 13, layer, a, b, go, ups, groups)
+        dgrad_ok = c0 % 128 == 0 and c1 % 128 == 0
+        assert ch[0] == 13 and (ch[1] == 13) == dgrad_ok, ch
+        assert RF.arith_counts()["conv3x3"].get("f16", 0) >= 2
+        # (the input gradient passes the BatchNorm backward, whose dy leaves as ONE fp16 plane: a forward difference of one
+        # fp32 ulp flips some of those roundings, each worth 2^-11 of an element — 3e-5 of the tensor's maximum measured)
+        assert rel_err(z, z0) < 1e-5 and rel_err(da, da0) < 2e-4 and rel_err(rv, rv0) < 1e-5
+        if c1:
+            assert rel_err(db, db0) < 2e-4
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        assert rel_err(nchw(z), ref) < 1e-2          # fp16 operands (F16_LOGIT_TOL class): measured ~2e-3
+    finally:
+        RF.set_conv_math(old)

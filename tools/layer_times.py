@@ -8,10 +8,18 @@ from rpnet_amd import hip
 import rpnet_amd.functional as RF
 from rpnet_amd.parallel import FlatGradBucket
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-cfg = yaml.load(open("yamls/example.yml"), Loader=yaml.FullLoader); cfg["n_iter_refinement"] = 5
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("batch", type=int, nargs="?", default=8); ap.add_argument("--size", type=int, default=256)
+ap.add_argument("--iters", type=int, default=5); ap.add_argument("--shots", type=int, default=1)
+ap.add_argument("--ways", type=int, default=1); ap.add_argument("--conv-math", default=None)
+a_ = ap.parse_args()
+B = a_.batch
+cfg = yaml.load(open("yamls/example.yml"), Loader=yaml.FullLoader); cfg["n_iter_refinement"] = a_.iters
 dev = torch.device("cuda", 0)
-net = bench.build_model(cfg, dev); bucket = FlatGradBucket(net); inp = bench.make_inputs(1234, B, 256, dev)
+if a_.conv_math:
+    RF.set_conv_math(a_.conv_math)
+net = bench.build_model(cfg, dev); bucket = FlatGradBucket(net); inp = bench.make_inputs(1234, B, a_.size, dev, a_.shots, a_.ways)
 for _ in range(2): bench.step(net, bucket, inp, 1.0)
 torch.cuda.synchronize()
 rec = []; orig = hip.call
