@@ -62,3 +62,67 @@ class GraphedEval:
             finally:
                 self.net._pred_redo = False
         return out
+
+
+class GraphedTrainStep:
+    """One training step (forward, loss, backward into the flat gradient bucket) captured into a HIP graph and replayed.
+
+    The step of this network is ~470 kernel launches behind ~330 C-ABI calls and a Python autograd graph: the host needs
+    10-11 ms to enqueue what the GPU runs in ~19 ms (tools/cpu_overhead.py) — no bound today, but every kernel speed-up
+    eats the margin.  All shapes are static per (batch, H, W, T), the library neither allocates nor synchronises, the
+    weight packs are made by kernels inside the step (so a replay re-packs the CURRENT weights), and the side streams of
+    the asynchronous weight gradients fork from / join the capturing stream through events — so the whole step captures.
+    Usage:
+        g = GraphedTrainStep(net, bucket, loss_fn)          # loss_fn(out, labels) -> scalar tensor
+        loss = g(supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels)   # replays; gradients in bucket.flat
+    Inputs are copied into static buffers; the returned loss is a static tensor (clone it to keep it).  Single process
+    only: with a process group the bucket's all-reduce is issued by the caller after the replay (bucket.allreduce())."""
+
+    def __init__(self, net, bucket, loss_fn, warmup=2):
+        self.net, self.bucket, self.loss_fn, self.warmup = net, bucket, loss_fn, warmup
+        self._graphs = {}
+
+    @staticmethod
+    def _flat(nested):
+        return [t for way in nested for t in way]
+
+    def _run(self, st):
+        si, fg, bg, qi, ql, appr = st
+        self.bucket.zero()
+        out = self.net(si, fg, bg, qi, appr_query_labels=appr)
+        loss = self.loss_fn(out, ql)
+        loss.backward()
+        from . import functional as RF
+        RF.join_side_streams()           # the weight gradients of the side streams land before the graph ends
+        return loss.detach()
+
+    def _capture(self, key, args):
+        si, fg, bg, qi, ql, appr = args
+        st = ([[t.clone() for t in way] for way in si], [[t.clone() for t in way] for way in fg],
+              [[t.clone() for t in way] for way in bg], [t.clone() for t in qi], ql.clone(), appr.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                        # warm-up outside capture (allocator, lazy init)
+            for _ in range(self.warmup):
+                self._run(st)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._run(st)
+        self._graphs[key] = (g, st, loss)
+        return self._graphs[key]
+
+    def __call__(self, supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels):
+        args = (supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels)
+        key = (len(supp_imgs), len(supp_imgs[0]), tuple(qry_imgs[0].shape), self.net.num_iter)
+        g, st, loss = self._graphs.get(key) or self._capture(key, args)
+        for dn, sn in zip(st[:3], args[:3]):
+            for dw, sw in zip(dn, sn):
+                for d, s in zip(dw, sw):
+                    d.copy_(s)
+        st[3][0].copy_(qry_imgs[0])
+        st[4].copy_(labels)
+        st[5].copy_(appr_query_labels)
+        g.replay()
+        return loss

@@ -10,11 +10,12 @@
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int MODE, int NT = 512>
+template <int MODE, int NT = 512, bool ZERO = false>
 __global__ __launch_bounds__(NT, 1) void probe(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[64 * 1024];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    for (int e = t; e < 64 * 1024 / 4; e += NT) reinterpret_cast<float*>(smem)[e] = 0.001f * (e & 255);
+    // ZERO: all-zero operands (what the chip clocks a pure MFMA stream at depends on the data: DVFS)
+    for (int e = t; e < 64 * 1024 / 4; e += NT) reinterpret_cast<float*>(smem)[e] = ZERO ? 0.f : 0.001f * (e & 255);
     __syncthreads();
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -81,22 +82,26 @@ __global__ __launch_bounds__(NT, 1) void probe(float* out, int iters) {
     if (s == 123.456f) out[0] = s;
 }
 
-template <int MODE, int NT = 512>
+template <int MODE, int NT = 512, bool ZERO = false>
 void run(const char* name, int iters) {
     float* out; hipMalloc(&out, 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((probe<MODE, NT>), dim3(256), dim3(NT), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe<MODE, NT, ZERO>), dim3(256), dim3(NT), 0, 0, out, iters);
     hipEventRecord(a);
-    hipLaunchKernelGGL((probe<MODE, NT>), dim3(256), dim3(NT), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe<MODE, NT, ZERO>), dim3(256), dim3(NT), 0, 0, out, iters);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double per_it_ns = ms * 1e6 / iters;
-    printf("%-52s %8.1f ns per slice-iteration  (MFMA-only ideal at 2.4 GHz: %.1f ns)\n", name, per_it_ns, 12 * (NT / 256) * 32 / 2.4);
+    const double ideal = 12 * (NT / 256) * 32 / 2.4;
+    printf("%-52s %8.1f ns per slice-iteration  (MFMA-only ideal at 2.4 GHz: %.1f ns; MFMA-equivalent clock %.2f GHz)\n", name, per_it_ns,
+           ideal, 2.4 * ideal / per_it_ns);
 }
 
 int main() {
     const int iters = 20000;
+    run<0, 512, true>("MFMAs only, ALL-ZERO operands (2 waves/SIMD)", iters);
     run<0>("MFMAs only (12 per wave, 2 waves/SIMD)", iters);
+    run<0, 256, true>("1 wave/SIMD: MFMAs only, ALL-ZERO operands", iters);
     run<1>("ds_read_b128 only (8 per wave)", iters);
     run<2>("reads then MFMAs (compiler order)", iters);
     run<3>("double-buffered, reads between MFMAs", iters);

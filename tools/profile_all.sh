@@ -3,13 +3,13 @@
 # the bench lines of the same tree.  Run on the GPU box through gpurun:   bash tools/profile_all.sh r02
 # Raw outputs stay in gpurun_out/prof_<tag>/raw (scratch, deleted at the end); the summaries made by tools/*.py land
 # in gpurun_out/prof_<tag>/ and are copied into profiles/<tag>_* by hand.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$TAG
 R=$O/raw
 rm -rf $O; mkdir -p $R
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-S="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+S="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
 db() { find $1 -name "*.db" | head -1; }
 csvc() { find $1 -name "*counter_collection.csv" | head -1; }
 RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_serial -o t -- $B > $R/trace_serial.log 2>&1
@@ -21,14 +21,19 @@ RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/
 python tools/pmc_traffic.py $(csvc $R/pmc_fetch) $(csvc $R/pmc_write) $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.txt
 RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/pmc_mfma -o p --output-format csv -- $S > $R/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $(csvc $R/pmc_mfma) $O/${TAG}_pmc_mfma_busy.json > $O/${TAG}_pmc_mfma_busy.txt
+RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $R/pmc_sq -o p --output-format csv -- $S > $R/pmc_sq.log 2>&1
+python tools/pmc_sq.py $(csvc $R/pmc_sq) $O/${TAG}_pmc_sq_wave_cycles.json > $O/${TAG}_pmc_sq_wave_cycles.txt
+# the clock a chip-wide MFMA stream holds on zero / dense operands, and whether fragment reads hide under it
+./tools/probe/lds_mfma_probe > $O/${TAG}_lds_mfma_probe.txt 2>&1
+# host enqueue cost and launch counts of the headline step
+python tools/cpu_overhead.py 2>/dev/null | grep -v Warning > $O/${TAG}_cpu_overhead.txt
 # configs[4] (one fp16 plane, 2-way 512^2 T=10 batch 4): kernel trace of the same command as its bench line
 C5="python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
 RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_c5) $O/${TAG}_bench_c5_f16_kernel_stats.csv
 # the bench lines themselves (default incl. CPU baseline and eval leg; configs[4]; configs[2]; two gloo ranks on the one GPU)
 python bench.py > $O/${TAG}_bench_final.json 2> $R/bench_final.err
-python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_c5_f16.json 2> $R/bench_c5.err
-python bench.py --batch 16 --shots 5 --steps 5 --no-cpu-baseline > $O/${TAG}_bench_c3_5shot.json 2> $R/bench_c3.err
+# (configs[2] / configs[4] are part of the default line since round 3: other_configs)
 RPNET_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_2ranks_gloo_one_gpu.json 2> $R/bench_2r.err
 tail -2 $R/*.log | cut -c1-160
 rm -rf $R
