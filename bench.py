@@ -639,6 +639,32 @@ def main():
             fence()
             alt[other] = {"value": round(args.batch * 5 / (time.perf_counter() - t1), 3), "unit": "pairs/s", "steps": 5}
         RF.set_conv_math(requested)
+    graph_leg = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the same step replayed from a HIP graph (rpnet_amd.graph.GraphedTrainStep): the host then enqueues ONE launch per step
+        from rpnet_amd.functional import dice_ce
+        from rpnet_amd.graph import GraphedTrainStep
+
+        def loss_fn(out, ql):
+            loss = dice_ce(out["output"], ql)
+            for v in out["refinement"].values():
+                loss = loss + dice_ce(v, ql)
+            return loss + scaler * out["align_loss"]
+        gts = GraphedTrainStep(net, bucket, loss_fn)
+        for _ in range(2):
+            gts(*inp[:4], inp[4], inp[5])
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            gts(*inp[:4], inp[4], inp[5])
+        t_enq = time.perf_counter() - t1
+        fence()
+        t_all = time.perf_counter() - t1
+        graph_leg = {"value": round(args.batch * 10 / t_all, 3), "unit": "pairs/s", "steps": 10, "ms_per_step": round(t_all * 100, 3),
+                     "host_enqueue_ms_per_step": round(t_enq * 100, 3),
+                     "what": "the timed step captured once into a HIP graph and replayed (bit-identical gradients: "
+                             "tests/test_gpu_model.py::test_graphed_train_step_matches_eager); `value` above is the eager step"}
+        del gts
     if rank == 0:
         result = {
             "metric": f"support/query pairs/sec (fwd+bwd, {args.shots}-shot {args.size}x{args.size}, T={args.iters})",
@@ -655,6 +681,8 @@ def main():
         }
         if m["dist"]:
             result["distributed"] = m["dist"]
+        if graph_leg:
+            result["graph_replay"] = graph_leg
         if alt:
             result["alt_math"] = alt
         if world == 1 and not args.no_cpu_baseline and args.ways == 1 and args.shots == 1:

@@ -135,11 +135,14 @@ __global__ void corr_transpose_kernel(const float* __restrict__ dcorr, float* __
 // 4 + 2R shifted feature pixels once and does 4 * K * 4 FMAs.  64 channels per LDS stage.
 constexpr int BC = 64;          // channels per stage (backward)
 constexpr int BSTR = BC + 4;    // padded feature row
-template <int R, int SIGN>
+// BCT: channels per stage — 64, or 32 for radius 6 / 7 whose halo (20^2 / 22^2 pixels) would not fit the LDS beside the window
+// gradients at 64 (half of the threads then only help staging)
+template <int R, int SIGN, int BCT = 64>
 __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __restrict__ g, const float* __restrict__ fo,
                                                               float* __restrict__ df, int h, int w, int C, int cstride,
                                                               float inv_sqrt_c, const float* __restrict__ add) {
     constexpr int K = 2 * R + 1, HT = CT + 2 * R, NX = 4 + 2 * R, KA = (K + 3) & ~3;
+    constexpr int BC = BCT, BSTR = BCT + 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* fs = sm;                   // [HT*HT][BSTR]
     float* gs = sm + HT * HT * BSTR;  // [64][K][KA]
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __rest
     for (int c0 = 0; c0 < C; c0 += BC) {
         __syncthreads();
         for (int e = t; e < HT * HT * (BC / 4); e += 256) {
-            const int c4 = e & 15, hp = e >> 4;
+            const int c4 = e % (BC / 4), hp = e / (BC / 4);
             const int hy = hp / HT, hx = hp - hy * HT;
             const int y = ty0 + hy - R, x = tx0 + hx - R;
             const bool ok = y >= 0 && y < h && x >= 0 && x < w;
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256) void local_corr_bwd_kernel(const float* __rest
                 *reinterpret_cast<const f32x4*>(fb + ((size_t)yc * w + xc) * C + c0 + c4 * 4) * (ok ? 1.f : 0.f);
         }
         __syncthreads();
+        if (cg * 4 >= BC) continue;          // BCT = 32: channel groups 8 .. 15 have nothing to compute (uniform per wave)
         f32x4 acc[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -210,6 +214,8 @@ static int corr_fwd_launch(const float* f1, const float* f2, float* corr, int B,
     const size_t need_out = (size_t)64 * cstride * sizeof(float);
     if (need_out > lds) lds = need_out;
     const int tiles = cdiv(h, CT) * cdiv(w, CT);
+    if (lds > 64 * 1024)      // radius 6 / 7: > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_fwd_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((local_corr_fwd_kernel<R>), dim3(tiles, B), dim3(256), lds, s, f1, f2, corr, h, w, C, cstride,
                        1.0f / sqrtf((float)C));
     return check_launch("local_corr_fwd");
@@ -234,14 +240,16 @@ int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, i
         case 3: { constexpr int RR = 3; __VA_ARGS__; } break;         \
         case 4: { constexpr int RR = 4; __VA_ARGS__; } break;         \
         case 5: { constexpr int RR = 5; __VA_ARGS__; } break;         \
-        default: rpnet::set_error("local_corr: radius %d not in 1..5", R_); return RPNET_ERR_SHAPE; \
+        case 6: { constexpr int RR = 6; __VA_ARGS__; } break;         \
+        case 7: { constexpr int RR = 7; __VA_ARGS__; } break;         \
+        default: rpnet::set_error("local_corr: radius %d not in 1..7", R_); return RPNET_ERR_SHAPE; \
     }
 
 extern "C" int rpnet_local_corr_fwd(const float* f1, const float* f2, float* corr, int B, int h, int w, int C, int r,
                                     int cstride, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1 && f2 && corr, RPNET_ERR_ARG, "local_corr_fwd: null pointer");
-    RPNET_REQUIRE(C % CC == 0 && cstride >= (2 * r + 1) * (2 * r + 1) && cstride <= 160, RPNET_ERR_SHAPE,
+    RPNET_REQUIRE(C % CC == 0 && cstride >= (2 * r + 1) * (2 * r + 1) && cstride <= 256, RPNET_ERR_SHAPE,
                   "local_corr_fwd: C=%d (multiple of 32) cstride=%d", C, cstride);
     int rc = 0;
     RPNET_CORR_DISPATCH(r, rc = corr_fwd_launch<RR>(f1, f2, corr, B, h, w, C, cstride, (hipStream_t)stream));
@@ -270,13 +278,14 @@ extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const floa
     if (nb > 16384) nb = 16384;
     RPNET_CORR_DISPATCH(r, {
         constexpr int K = 2 * RR + 1, HT = CT + 2 * RR, KA = (K + 3) & ~3;
-        const size_t lds = (size_t)(HT * HT * BSTR + 64 * K * KA) * sizeof(float);
+        constexpr int BCT = RR <= 5 ? 64 : 32;
+        const size_t lds = (size_t)(HT * HT * (BCT + 4) + 64 * K * KA) * sizeof(float);
         // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc, df1_add);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, 1, BCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, -1, BCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1, BCT>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc, df1_add);
         hipLaunchKernelGGL((corr_transpose_kernel<RR>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
-        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc, (const float*)nullptr);
+        hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1, BCT>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc, (const float*)nullptr);
     });
     return check_launch("local_corr_bwd");
 }

@@ -1095,6 +1095,13 @@ def mask_avgpool(mask, scale):
 CORR_STRIDE = 128  # (2*5+1)^2 = 121 window channels padded to a GEMM-friendly 128
 
 
+def corr_stride(r):
+    """channel stride of the correlation output for radius r: (2 r + 1)^2 window channels padded to a multiple of 64 (128 up
+    to the yaml's radius 5; 192 / 256 for radius 6 / 7, which run on the fp32 window kernels)"""
+    kk = (2 * r + 1) ** 2
+    return CORR_STRIDE if kk <= CORR_STRIDE else (kk + 63) // 64 * 64
+
+
 class LocalCorr(Function):
     """Correlation(fm1, fm2, r) (net/rp_net.py:153-181), NHWC, output [B,h,w,128] (zero padded).  With the split
     arithmetic on (and r = 5, C % 128 == 0) it runs on the bf16 matrix pipe from the split planes of fm1 / fm2.
@@ -1108,6 +1115,7 @@ class LocalCorr(Function):
         its consumer (the 1x1 convolution) reads planes"""
         ctx.set_materialize_grads(False)
         B, h, w, Cc = f1.shape
+        CORR_STRIDE = corr_stride(r)          # (shadows the module constant: every launch below takes this radius' stride)
         corr = _empty((B, h, w, CORR_STRIDE), f1)
         np_ = _MATH["planes"] if (r == 5 and Cc % 128 == 0) else 0
         o1, o2 = ops if ops is not None else (Operand(f1), Operand(f2))
@@ -1149,6 +1157,7 @@ class LocalCorr(Function):
             return d_alias, None, None, None, None
         add = d_alias.contiguous() if d_alias is not None else None
         df1, df2 = _empty(ctx.shape, dcorr), _empty(ctx.shape, dcorr)
+        CORR_STRIDE = corr_stride(ctx.r)
         wb = query("rpnet_local_corr_bwd_workspace_bytes", B, h, w, CORR_STRIDE)
         ws = _ws(wb, dcorr)
         ARITH[("corr_bwd", _PLANE_NAME[ctx.np_])] += 1

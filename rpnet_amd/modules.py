@@ -42,11 +42,37 @@ def _to_nchw(x):
     return x.permute(0, 3, 1, 2)
 
 
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(ch) as the reference builds it — getattr(nn, normalization_type)(ch_out), net/modules.py:48,51,68 with
+    unet_normalize_type: InstanceNorm2d — i.e. affine=False, track_running_stats=False: per-image, per-channel statistics in
+    train AND eval mode, no parameters and no state_dict entries.  Runs on the BatchNorm kernels with ONE STATISTIC GROUP PER
+    IMAGE, gamma = 1, beta = 0 (non-persistent buffers; the running-statistic buffers exist only because the kernels
+    update them and are never read)."""
+    instance = True
+
+    def __init__(self, ch):
+        super().__init__()
+        self.num_features = ch
+        for name, val in (("weight", torch.ones(ch)), ("bias", torch.zeros(ch)), ("running_mean", torch.zeros(ch)),
+                          ("running_var", torch.ones(ch)), ("num_batches_tracked", torch.zeros((), dtype=torch.long))):
+            self.register_buffer(name, val, persistent=False)
+
+
 def _norm(normalization_type, ch):
+    if normalization_type == "InstanceNorm2d":
+        return InstanceNorm2d(ch)
     if normalization_type != "BatchNorm2d":
-        raise NotImplementedError(f"unet_normalize_type={normalization_type!r}: only BatchNorm2d "
-                                  "(yamls/example.yml:41) has HIP kernels")
+        raise NotImplementedError(f"unet_normalize_type={normalization_type!r}: BatchNorm2d (yamls/example.yml:41) and "
+                                  "InstanceNorm2d have HIP kernels")
     return nn.BatchNorm2d(ch)
+
+
+def _norm_mode(norm, training, groups, x):
+    """(training flag, statistic groups) a conv + norm + ReLU layer runs with: an instance norm always takes the statistics of
+    its own input, one group per image"""
+    if getattr(norm, "instance", False):
+        return True, x.shape[0]
+    return training, groups
 
 
 class conv_block(nn.Module):
@@ -67,7 +93,7 @@ class conv_block(nn.Module):
         (RF.conv_bn_relu_op); split: channel ranges of the first layer's packed weight when its sources are padded
         (RF.PackedWeight); pool: return MaxPool2d(2, 2) of the block's output instead of the output — the caller needs
         nothing else of it, and the single consumer of the pooled tensor is an unmasked single-source 3x3 convolution"""
-        t = self.training
+        t, groups = _norm_mode(self.conv[1], self.training, groups, x0)
         # the first layer's output feeds the second convolution and nothing else: on fp16 planes its fp32 form is not written
         x = RF.conv_bn_relu_op(x0, self.conv[0], self.conv[1], cache, t, x1=x1, groups=groups, z_unused=_ZSKIP, split=split)
         if pool:
@@ -92,8 +118,8 @@ class up_conv(nn.Module):
             _norm(normalization_type, ch_out), nn.ReLU(inplace=True))
 
     def forward_nhwc(self, x, cache, groups=1, out_split=True):
-        return RF.conv_bn_relu_op(x, self.up[1], self.up[2], cache, self.training, groups=groups, upsample=True,
-                                  out_split=out_split)
+        t, groups = _norm_mode(self.up[2], self.training, groups, x)
+        return RF.conv_bn_relu_op(x, self.up[1], self.up[2], cache, t, groups=groups, upsample=True, out_split=out_split)
 
     def forward(self, x):
         return _to_nchw(self.forward_nhwc(_to_nhwc(x), RF.WeightCache()).x)
@@ -275,8 +301,9 @@ class ContextCorrelationEncoder(nn.Module):
         self.w_context = cbr(in_channels * 2, in_channels, 1)
         self.q = cbr(in_channels + (self.radius * 2 + 1) ** 2, num_feat, 1)
         self.out = cbr(2 * in_channels, num_feat, 1)
-        if (2 * self.radius + 1) ** 2 > RF.CORR_STRIDE:
-            raise NotImplementedError("mask_refinement_correlation_radius > 5")
+        if not 1 <= self.radius <= 7:
+            raise NotImplementedError("mask_refinement_correlation_radius outside 1..7 (the window kernels hold 2 r + 1 <= 15 "
+                                      "vertical offsets per block; the yaml ships 5)")
 
     def forward_masked(self, fts, mask, cache, fts_scale=None):
         """cre(fts*mask, fts*(1-mask)) with the mask multiply fused into the conv gather
@@ -320,7 +347,7 @@ class ContextCorrelationEncoder(nn.Module):
     def _tail(self, fm1, fm2, cache):
         corr, fm1b = RF.local_corr(fm1, fm2, self.radius)     # fm1b: alias of fm1, gradient fan-in fused (RF.LocalCorr)
         kk = (2 * self.radius + 1) ** 2
-        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.CORR_STRIDE),
+        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.corr_stride(self.radius)),
                                out_split=False)
 
     def forward(self, fm1, fm2):

@@ -733,3 +733,34 @@ def test_eval_fp16_planes_on_predicted_scales():
     finally:
         RM._F16_MIN_PIXELS = old_min
         RF.set_conv_math(old)
+
+
+def test_graphed_train_step_matches_eager():
+    """rpnet_amd.graph.GraphedTrainStep: the whole training step (forward, harness loss, backward with the weight gradients on
+    side streams, into the flat bucket) captured into a HIP graph — loss and every gradient bit-identical to the eager step,
+    also on a second episode copied into the static inputs (the replay re-packs weights and re-measures nothing stale)."""
+    import rpnet_amd.functional as RF
+    from rpnet_amd.graph import GraphedTrainStep
+    from rpnet_amd.parallel import FlatGradBucket
+    cfg = load_cfg(2)
+    net = build(cfg, True)
+    bucket = FlatGradBucket(net)
+    RF.set_async_wgrad(True)
+    try:
+        g = GraphedTrainStep(net, bucket, lambda out, ql: total_loss(out, ql, cfg["align_loss_scaler"]))
+        for seed in (71, 72):
+            (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, 4, 128, DEV)
+            loss_g = g(si, fg, bg, qi, ql, appr).clone()
+            torch.cuda.synchronize()
+            grads_g = bucket.flat.clone()
+            bucket.zero()
+            out = net(si, fg, bg, qi, appr_query_labels=appr)
+            loss_e = total_loss(out, ql, cfg["align_loss_scaler"])
+            loss_e.backward()
+            bucket.allreduce()
+            torch.cuda.synchronize()
+            assert torch.equal(loss_g, loss_e.detach()) and grads_g.abs().max() > 0
+            assert torch.equal(grads_g, bucket.flat)
+        assert len(g._graphs) == 1
+    finally:
+        RF.set_async_wgrad(False)

@@ -402,7 +402,8 @@ def test_mask_avgpool_and_threshold(RF):
         assert (got - ref).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("dims", [(2, 64, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5), (3, 128, 11, 13, 5)])
+@pytest.mark.parametrize("dims", [(2, 64, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5), (3, 128, 11, 13, 5),
+                                  (1, 64, 16, 20, 6), (2, 128, 12, 9, 7)])    # radius 6 / 7: window strides 192 / 256
 def test_local_correlation(RF, conv_math, dims):
     """r = 5 with C % 128 == 0 runs on the bf16 matrix pipe under the split arithmetics (corr_split.hip: ragged
     tiles, image borders), everything else on the VALU kernels (corr.hip); same 1e-4 bar (2e-4 for two planes)."""
@@ -415,8 +416,10 @@ def test_local_correlation(RF, conv_math, dims):
     g1, g2 = torch.autograd.grad(ref, [f1, f2], go)
     a, bb = nhwc(f1.detach()).to(DEV).requires_grad_(True), nhwc(f2.detach()).to(DEV).requires_grad_(True)
     out, a_alias = RF.LocalCorr.apply(a, bb, r)
-    assert out.shape[-1] == 128 and out[..., kk:].abs().max() == 0      # zero padded window channels
-    gop = torch.zeros(b, h, w, 128)
+    stride = RF.corr_stride(r)
+    assert stride == (128 if r <= 5 else 192 if r == 6 else 256)
+    assert out.shape[-1] == stride and out[..., kk:].abs().max() == 0      # zero padded window channels
+    gop = torch.zeros(b, h, w, stride)
     gop[..., :kk] = go.permute(0, 2, 3, 1)
     # the second output is an alias of f1 for its other consumer: its gradient is summed into df1 by the kernel's store
     g_alias = rnd(14, b, h, w, c)
@@ -638,3 +641,44 @@ def test_conv1x1_over_corr_and_features(RF, conv_math):
     assert rel_err(nchw(xg.grad), xr.grad) < 5e-4
     assert rel_err(mods[4].weight.grad, ref_mods[4].weight.grad) < 5e-4
     assert rel_err(mods[5].weight.grad, ref_mods[5].weight.grad) < 5e-4 and rel_err(mods[0].weight.grad, ref_mods[0].weight.grad) < 5e-4
+
+
+@pytest.mark.parametrize("kind", ["conv_block", "up_conv"])
+def test_instance_norm_blocks(RF, conv_math, kind):
+    """unet_normalize_type: InstanceNorm2d (the reference builds getattr(nn, normalization_type)(ch_out), net/modules.py:48,51,68:
+    affine = False, no running statistics, per-image statistics in train AND eval mode) on the BatchNorm kernels with one
+    statistic group per image: outputs and gradients against torch's own InstanceNorm2d modules, train and eval mode, and the
+    state_dict carries the convolution entries only, like the reference's."""
+    import torch.nn as nn
+    from rpnet_amd.modules import conv_block, up_conv
+    torch.manual_seed(5)
+    if kind == "conv_block":
+        m = conv_block(64, 128, "InstanceNorm2d")
+        ref = nn.Sequential(nn.Conv2d(64, 128, 3, padding=1), nn.InstanceNorm2d(128), nn.ReLU(), nn.Conv2d(128, 128, 3, padding=1),
+                            nn.InstanceNorm2d(128), nn.ReLU())
+        pairs = [(m.conv[0], ref[0]), (m.conv[3], ref[3])]
+    else:
+        m = up_conv(128, 64, "InstanceNorm2d")
+        ref = nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(128, 64, 3, padding=1), nn.InstanceNorm2d(64), nn.ReLU())
+        pairs = [(m.up[1], ref[1])]
+    for mine, theirs in pairs:
+        theirs.load_state_dict(mine.state_dict())
+    assert sorted(m.state_dict()) == sorted(("conv." if kind == "conv_block" else "up.") + k for k in ref.state_dict())
+    x = rnd(21, 3, 64 if kind == "conv_block" else 128, 16, 16)
+    go = rnd(22, 3, 128 if kind == "conv_block" else 64, *((16, 16) if kind == "conv_block" else (32, 32)))
+    m = m.to(DEV)
+    for training in (True, False):
+        m.train(training)
+        ref.train(training)
+        xr = x.clone().requires_grad_(True)
+        want = ref(xr)
+        want.backward(go)
+        xg = x.to(DEV).requires_grad_(True)
+        got = m(xg)
+        got.backward(go.to(DEV))
+        assert rel_err(got, want) < TOL, training
+        assert rel_err(xg.grad, xr.grad) < TOL
+        for mine, theirs in pairs:
+            assert rel_err(mine.weight.grad, theirs.weight.grad) < TOL
+            mine.weight.grad = None
+            theirs.weight.grad = None
