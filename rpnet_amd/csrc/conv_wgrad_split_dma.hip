@@ -37,18 +37,25 @@ __device__ __forceinline__ void static_for_w(F&& f) {
     }
 }
 
-template <int NP, bool POW2>
+// FAST: power-of-two images at least a K-step wide, no up-sampling (25 of the 27 weight-gradient launches of the step): the
+// addressing of a step collapses to a handful of scalar instructions (below).  POW2 (without FAST): shifts instead of divisions.
+template <int NP, bool POW2, bool FAST>
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                   float* __restrict__ partial, const int M, const int Cin,
                                                                   const int Cout, const int tiles, const int tiles_n,
                                                                   const int ksplit, const int steps_per_split, const int lw,
                                                                   const int lh) {
     constexpr int BK = 32, RB = 128;                               // pixels per K-step, bytes per LDS row (64 channels)
-    constexpr int A_PLANE = 3 * BK * RB;                           // [3 ky][32 pixel] rows: 12 KB
-    constexpr int B_ROWS = 40, ZROW = 40, B_PLANE = 48 * RB;       // 5 pieces of 8 rows + the zero row: 6 KB
-    constexpr int STAGE = NP * (A_PLANE + B_PLANE);                // 36 KB (NP = 2)
+    constexpr int A_PLANE = 3 * BK * RB, A_STAGE = NP * A_PLANE;   // [3 ky][32 pixel] rows: 12 KB per plane
+    constexpr int ZROW = 40, B_PLANE = 48 * RB, B_STAGE = NP * B_PLANE;   // 5 pieces of 8 rows + the zero row: 6 KB per plane
     constexpr int NS = 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+    // LDS: [4 stages of x strips: 96 KB][4 stages of dy tiles: 48 KB].  The stage of a K-step is a COMPILE-TIME constant (the
+    // loop is unrolled by four), so every fragment read is a lane-constant address register + an immediate offset: the x
+    // reads go through two base registers (stages 0-1 / 2-3: immediates stay below 64 KB), the dy reads through the twelve
+    // (slice, tap column, row half) registers that also carry the image-border redirects.
+    constexpr int BOFF = NS * A_STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BOFF + NS * B_STAGE];
+    static_assert(NP == 2, "two fp16 planes (one plane has 9 MFMAs per slice for 12 fragment reads: another schedule)");
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     const int cm0 = tm * 64, n0 = tn * 64;
 
     const int H = d.H, W = d.W, HW = H * W;
-    const int ups = d.upsample;
+    const int ups = FAST ? 0 : d.upsample;
     const int Hs = H >> ups, Ws = W >> ups;
     const unsigned short* src; int Cs, cc;
     if (cm0 < d.C0) { src = reinterpret_cast<const unsigned short*>(d.x0); Cs = d.C0; cc = cm0; }
@@ -82,69 +89,86 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     // one descriptor per tensor over all its planes (the plane is part of the scalar offset)
     const srd_t rsx = make_srd(src, NP * pbx), rsy = make_srd(dy, NP * pby);
     const unsigned lds0 = lds_addr(smem);
+    const unsigned ldsw = lds0 + 8 * wv * RB;                       // this wave's 8 rows inside a strip / dy piece wv
+    const unsigned lds4 = lds0 + 32 * RB;                           // dy piece 4 (wave 0)
 
     // DMA lane geometry: lane l of a 1 KB piece writes 16 bytes at piece + 16 l = row (l >> 3), 16-byte slot (l & 7); the
     // slot belongs to the 64-byte half (l >> 2) & 1, which holds the SOURCE half ^ bit 1 of the row (pieces start at
     // multiples of 8 rows)
     const int drow = lane >> 3;
     const int dcol = ((((lane >> 2) & 1) ^ ((lane >> 4) & 1)) << 6) | ((lane & 3) << 4);       // source byte offset inside the row
-    // x strips: this wave moves rows 8 wv .. 8 wv + 7 of each of the three strips (every plane); dy: piece wv, wave 0 also
-    // the fifth piece (rows 32 .. 39)
-    auto dma_x = [&](auto kyc, const int st, const int stage) {
-        constexpr int kyi = decltype(kyc)::value;
-        const int q = st * BK + 8 * wv + drow + (kyi - 1) * W;
-        int pix, yq;
-        if (POW2) {      // (n Hs + (y >> ups)) Ws + (x >> ups): the pixel itself without up-sampling
-            yq = (q >> lw) & (H - 1);
-            pix = ((q >> (lw + lh)) * Hs + (yq >> ups)) * Ws + ((q & (W - 1)) >> ups);
+    const int xlane = (drow >> ups) * (Cs * 2) + dcol;              // per-lane part of an x source address (POW2)
+    const int Cs2 = Cs * 2, wcs = W * Cs2;
+    // x strips: this wave moves rows 8 wv .. 8 wv + 7 of each of the three strips (every plane).  POW2: the 8 pixels of a
+    // piece lie in one image row, so validity and source pixel are wave-uniform (scalar unit; the lane part is a constant)
+    auto dma_x = [&](auto kyc, auto stagec, const int st) {
+        constexpr int kyi = decltype(kyc)::value, stage = decltype(stagec)::value;
+        constexpr int DST = stage * A_STAGE + kyi * BK * RB;
+        int voff, soff;
+        if constexpr (FAST) {
+            const int qb0 = st * BK + 8 * wv;                         // centre-row pixel of the piece; source = qb0 + (ky - 1) W
+            const int yc = (qb0 >> lw) & (H - 1);
+            const bool ok = kyi == 1 || (kyi == 0 ? yc >= 1 : yc <= H - 2);
+            soff = qb0 * Cs2 + cc * 2 + (kyi - 1) * wcs;
+            soff = ok ? soff : 0;
+            voff = ok ? xlane : (int)0x80000000;
+        } else if constexpr (POW2) {
+            const int qb = st * BK + 8 * wv + (kyi - 1) * W;
+            const int yq = (qb >> lw) & (H - 1);
+            const bool ok = (unsigned)qb < (unsigned)M && (unsigned)(yq - (kyi - 1)) < (unsigned)H;
+            const int pixb = ((qb >> (lw + lh)) * Hs + (yq >> ups)) * Ws + ((qb & (W - 1)) >> ups);
+            soff = ok ? pixb * Cs2 + cc * 2 : 0;
+            voff = ok ? xlane : (int)0x80000000;
         } else {
+            const int q = st * BK + 8 * wv + drow + (kyi - 1) * W;
             const int n = q / HW, rem = q - n * HW;
-            yq = rem / W;
+            const int yq = rem / W;
             const int xq = rem - yq * W;
-            pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+            const int pix = (n * Hs + (yq >> ups)) * Ws + (xq >> ups);
+            const bool ok = (unsigned)q < (unsigned)M && (unsigned)(yq - (kyi - 1)) < (unsigned)H;
+            voff = ok ? pix * Cs2 + dcol : (int)0x80000000;
+            soff = cc * 2;
         }
-        const int yp = yq - (kyi - 1);                     // image row of the dy pixel this source row pairs with
-        const bool ok = (unsigned)q < (unsigned)M && (unsigned)yp < (unsigned)H;
-        const int voff = ok ? pix * (Cs * 2) + dcol : (int)0x80000000;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            lds_dma16(rsx, lds0 + stage * STAGE + p * A_PLANE + (kyi * BK + 8 * wv) * RB, voff, cc * 2 + p * pbx);
+        lds_dma16_at<DST>(rsx, ldsw, voff, soff);
+        lds_dma16_at<DST + A_PLANE>(rsx, ldsw, voff, soff + pbx);
+    };
+    // dy: piece wv (rows 8 wv ..), wave 0 also the fifth piece (rows 32 .. 39); pixels before 0 or past M read as zeros (an
+    // offset beyond num_records; the planes share one descriptor, so the bound is checked here)
+    const int ylane = drow * (Cout * 2) + dcol, ylane_m1 = ylane - Cout * 2;       // (lane 0 of ylane_m1 is negative: out of range)
+    auto dma_y = [&](auto stagec, const bool fifth, const int st) {
+        constexpr int stage = decltype(stagec)::value;
+        constexpr int DST = BOFF + stage * B_STAGE;
+        const int rowb = st * BK - 1 + (fifth ? 32 : 8 * wv);       // first pixel of the piece (uniform): -1 for step 0, piece 0
+        const bool neg = rowb < 0;
+        const int soff = (neg ? 0 : rowb) * (Cout * 2) + n0 * 2;
+        int voff = neg ? ylane_m1 : ylane;
+        voff = rowb + drow < M ? voff : (int)0x80000000;
+        if (fifth) {
+            lds_dma16_at<DST>(rsy, lds4, voff, soff);
+            lds_dma16_at<DST + B_PLANE>(rsy, lds4, voff, soff + pby);
+        } else {
+            lds_dma16_at<DST>(rsy, ldsw, voff, soff);
+            lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff, soff + pby);
         }
     };
-    auto dma_y = [&](const int piece, const int st, const int stage) {
-        // pixels before 0 or past M read as zeros (an offset beyond num_records; the planes share one descriptor, so the
-        // bound is checked here)
-        const int pixrow = st * BK - 1 + 8 * piece + drow;
-        const int voff = (unsigned)pixrow < (unsigned)M ? pixrow * (Cout * 2) + dcol : (int)0x80000000;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            lds_dma16(rsy, lds0 + stage * STAGE + NP * A_PLANE + p * B_PLANE + 8 * piece * RB, voff, n0 * 2 + p * pby);
-        }
-    };
-    auto dma_step = [&](const int st, const int stage) {
-        dma_x(std::integral_constant<int, 0>{}, st, stage);
-        dma_x(std::integral_constant<int, 1>{}, st, stage);
-        dma_x(std::integral_constant<int, 2>{}, st, stage);
-        dma_y(wv, st, stage);
-        if (wv == 0) dma_y(4, st, stage);
+    auto dma_step = [&](auto stagec, const int st) {
+        dma_x(std::integral_constant<int, 0>{}, stagec, st);
+        dma_x(std::integral_constant<int, 1>{}, stagec, st);
+        dma_x(std::integral_constant<int, 2>{}, stagec, st);
+        dma_y(stagec, false, st);
+        if (wv == 0) dma_y(stagec, true, st);
     };
     // wave 0 issues (3 + 2) NP DMAs per step, the others (3 + 1) NP: "everything but the last step's" as a wait count
     auto wait_all_but_one_step = [&]() {
-        if (wv == 0) {
-            if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
+        if (wv == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
-    static_assert(NP == 2, "two fp16 planes (one plane has 9 MFMAs per slice for 12 fragment reads: another schedule)");
 
     // the zero row of every dy plane of every stage (the DMA never writes it)
     if (t < NS * NP * 8) {
         const u32x4 zero = {0u, 0u, 0u, 0u};
         const int pl = t >> 3;
-        *reinterpret_cast<u32x4*>(smem + (pl / NP) * STAGE + NP * A_PLANE + (pl % NP) * B_PLANE + ZROW * RB + (t & 7) * 16) = zero;
+        *reinterpret_cast<u32x4*>(smem + BOFF + (pl / NP) * B_STAGE + (pl % NP) * B_PLANE + ZROW * RB + (t & 7) * 16) = zero;
     }
 
     f32x16 acc[9];
@@ -160,46 +184,65 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     const int cbyte = (16 * (g & 1) + 4 * (L & 3)) * 2;               // inside the wave's 64-byte half
     // x: strip rows ky 32 + 16 s + krow (+ 4): bit 1 of the row index is that of krow
     const int a_off = krow * RB + (((wm ^ ((krow >> 1) & 1)) << 6) | cbyte);
+    const unsigned char* const aptr0 = smem + a_off;
+    const unsigned char* const aptr1 = smem + a_off + 2 * A_STAGE;
     // dy: tile row of pixel q for tap kx is (q - p0) + 2 - kx: bit 1 of the row index depends on the shift
     int b_off[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int r = krow + 2 - kx;
-        b_off[kx] = r * RB + (((wn ^ ((r >> 1) & 1)) << 6) | cbyte);
+        b_off[kx] = BOFF + r * RB + (((wn ^ ((r >> 1) & 1)) << 6) | cbyte);
     }
-    const int b_zero = ZROW * RB + ((wn << 6) | cbyte);
-    auto tr = [&](int byte_off) -> s16x4 {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(smem + byte_off));
+    const int b_zero = BOFF + ZROW * RB + ((wn << 6) | cbyte);
+    auto tr = [&](const unsigned char* p) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
     };
 
     // fragment double buffer [slice parity]: af[ky][plane], bf[kx][plane]; a fragment = two transposing reads (rows krow.. and
     // krow + 4..).  Read k of a slice in order of first use (products l*h, h*l, h*h: the l plane of x and the h plane of dy
     // first): per plane pair x(ky 0), dy(kx 0..2), x(ky 1), x(ky 2) — two reads each.
     s16x4 afr[2][3][NP][2], bfr[2][3][NP][2];
-    int bsel[2][3][2];          // [slice][kx][row half]: byte offset of the dy read inside a plane (tile row or the zero row)
+    // [slice][kx][row half]: address of the dy read inside plane 0 of stage 0 (tile row or the zero row)
+    const unsigned char* bsel[2][3][2];
+    const unsigned char* bconst[2][3][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bsel[s2][kx][e] = bconst[s2][kx][e] = smem + b_off[kx] + (16 * s2 + 4 * e) * RB;
+    const unsigned char* const bzero = smem + b_zero;
+    const bool lane_first = krow == 0, lane_last = krow == 11;       // tile rows 0 (slice 0, half 0) and 31 (slice 1, half 1)
     auto b_addr = [&](auto sc, const int st) {
         constexpr int s = decltype(sc)::value;
+        if constexpr (FAST) {
+            // a step's 32 pixels lie in one image row: only its first pixel can lack a left neighbour, only its last a right one
+            const int x0 = (st * BK) & (W - 1);
+            if constexpr (s == 0) bsel[0][2][0] = (x0 == 0 && lane_first) ? bzero : bconst[0][2][0];           // kx = +1: dy[q - 1]
+            else bsel[1][0][1] = (x0 == W - BK && lane_last) ? bzero : bconst[1][0][1];                        // kx = -1: dy[q + 1]
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = 16 * s + 4 * e + krow;
-            const int q = st * BK + row;
-            const int ox = POW2 ? (q & (W - 1)) : (q % W);
-            bsel[s][0][e] = ox <= W - 2 ? b_off[0] + (16 * s + 4 * e) * RB : b_zero;     // kx = -1: dy[q + 1]
-            bsel[s][1][e] = b_off[1] + (16 * s + 4 * e) * RB;                            // kx =  0: dy[q]
-            bsel[s][2][e] = ox >= 1 ? b_off[2] + (16 * s + 4 * e) * RB : b_zero;         // kx = +1: dy[q - 1]
+            for (int e = 0; e < 2; ++e) {
+                const int row = 16 * s + 4 * e + krow;
+                const int q = st * BK + row;
+                const int ox = POW2 ? (q & (W - 1)) : (q % W);
+                bsel[s][0][e] = ox <= W - 2 ? bconst[s][0][e] : bzero;     // kx = -1: dy[q + 1]
+                bsel[s][2][e] = ox >= 1 ? bconst[s][2][e] : bzero;         // kx = +1: dy[q - 1]
+            }
         }
     };
     constexpr int NR = NP * 12, NMMA = nprod<NP>() * 9;
-    auto read_frag = [&](auto sc, auto kc, const int sbase) {
-        constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
+    auto read_frag = [&](auto sc, auto kc, auto stagec) {
+        constexpr int s = decltype(sc)::value, k = decltype(kc)::value, stage = decltype(stagec)::value;
         constexpr int grp = k / 12, r = (k - grp * 12) >> 1, e = k & 1;      // plane pair, fragment of the pair, row half
         constexpr int pa = NP - 1 - grp, pb = grp;
         if constexpr (r == 0 || r >= 4) {
             constexpr int ky = r == 0 ? 0 : r - 3;
-            afr[s][ky][pa][e] = tr(sbase + pa * A_PLANE + (ky * BK + 16 * s + 4 * e) * RB + a_off);
+            constexpr int off = (stage & 1) * A_STAGE + pa * A_PLANE + (ky * BK + 16 * s + 4 * e) * RB;
+            afr[s][ky][pa][e] = tr((stage >> 1 ? aptr1 : aptr0) + off);
         } else {
             constexpr int kx = r - 1;
-            bfr[s][kx][pb][e] = tr(sbase + NP * A_PLANE + pb * B_PLANE + bsel[s][kx][e]);
+            bfr[s][kx][pb][e] = tr(bsel[s][kx][e] + (stage * B_STAGE + pb * B_PLANE));
         }
     };
     auto frag = [](const s16x4 lo, const s16x4 hi) {
@@ -217,17 +260,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     if (s_begin < s_end) {
         // clamp: the tail re-fetches the last step into stages nobody reads again (uniform DMA counts per wave)
         auto stc = [&](int st) { return st < s_end ? st : s_end - 1; };
-        dma_step(s_begin, 0);
-        dma_step(stc(s_begin + 1), 1);
-        dma_step(stc(s_begin + 2), 2);
+        dma_step(std::integral_constant<int, 0>{}, s_begin);
+        dma_step(std::integral_constant<int, 1>{}, stc(s_begin + 1));
+        dma_step(std::integral_constant<int, 2>{}, stc(s_begin + 2));
         wait_all_but_one_step();                       // steps 0 and 1 have landed (this wave's part); zero rows written
         __builtin_amdgcn_s_barrier();
         b_addr(I0{}, s_begin);
-        static_for_w<NR>([&](auto kc) { read_frag(I0{}, kc, 0); });
-        for (int st = s_begin; st < s_end; ++st) {
-            const int rel = st - s_begin;
-            const int sbase = (rel & 3) * STAGE, sbase_n = ((rel + 1) & 3) * STAGE;
-            const int dstage = (rel + 3) & 3, dst_step = stc(st + 3);
+        static_for_w<NR>([&](auto kc) { read_frag(I0{}, kc, I0{}); });
+        // one K-step on stage K (compile time): Ring of four stages: the DMAs of step st + 3 go to stage K + 3
+        auto step = [&](auto kc4, const int st) {
+            constexpr int K = decltype(kc4)::value;
+            using SK = std::integral_constant<int, K>;
+            using SN = std::integral_constant<int, (K + 1) & 3>;
+            using SD = std::integral_constant<int, (K + 3) & 3>;
+            const int dst_step = stc(st + 3);
             // first half: MFMAs of slice 0 | reads of slice 1 | the x strips of step st + 3
             b_addr(I1{}, st);
             __builtin_amdgcn_sched_barrier(0);
@@ -236,11 +282,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
                 mma_one(I0{}, mc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m < NR) {
-                    read_frag(I1{}, mc, sbase);
+                    read_frag(I1{}, mc, SK{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (m == 3 || m == 9 || m == 15) {
-                    dma_x(std::integral_constant<int, (m - 3) / 6>{}, dst_step, dstage);
+                    dma_x(std::integral_constant<int, (m - 3) / 6>{}, SD{}, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -252,20 +298,29 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
                 mma_one(I1{}, mc);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m < NR) {
-                    read_frag(I0{}, mc, sbase_n);
+                    read_frag(I0{}, mc, SN{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (m == 5) {
-                    dma_y(wv, dst_step, dstage);
+                    dma_y(SD{}, false, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (m == 11) {
-                    if (wv == 0) dma_y(4, dst_step, dstage);
+                    if (wv == 0) dma_y(SD{}, true, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
             wait_all_but_one_step();                   // this wave's part of step st + 2 has landed
             __builtin_amdgcn_s_barrier();
+        };
+        for (int st = s_begin; st < s_end; st += 4) {
+            step(std::integral_constant<int, 0>{}, st);
+            if (st + 1 >= s_end) break;
+            step(std::integral_constant<int, 1>{}, st + 1);
+            if (st + 2 >= s_end) break;
+            step(std::integral_constant<int, 2>{}, st + 2);
+            if (st + 3 >= s_end) break;
+            step(std::integral_constant<int, 3>{}, st + 3);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's DMAs: the epilogue reuses the memory
         __builtin_amdgcn_s_barrier();
@@ -304,10 +359,11 @@ int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9
     const int lw = ilog2d(d->W), lh = ilog2d(d->H);
     const bool p2 = lw >= 0 && lh >= 0;
     const unsigned short* dys = (const unsigned short*)dy;
-#define RPNET_W9D(NPL, P2)                                                                                                 \
-    hipLaunchKernelGGL((conv_wgrad9_dma_kernel<NPL, P2>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, \
+    const bool fast = p2 && d->W >= 32 && !d->upsample;
+#define RPNET_W9D(NPL, P2, FA)                                                                                                 \
+    hipLaunchKernelGGL((conv_wgrad9_dma_kernel<NPL, P2, FA>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, \
                        tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0)
-    if (d->split_planes == 2) { if (p2) RPNET_W9D(2, true); else RPNET_W9D(2, false); }
+    if (d->split_planes == 2) { if (fast) RPNET_W9D(2, true, true); else if (p2) RPNET_W9D(2, true, false); else RPNET_W9D(2, false, false); }
     else {
         set_error("conv_wgrad9_split_dma: two fp16 planes only");
         return RPNET_ERR_ARG;

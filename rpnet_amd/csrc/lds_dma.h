@@ -40,4 +40,16 @@ __device__ __forceinline__ void lds_dma16(const srd_t srd, const unsigned lds_ba
         : "memory");
 }
 
+// the same with the LDS destination as scalar base + compile-time offset (one s_add into M0 instead of an add and a move)
+template <int OFF>
+__device__ __forceinline__ void lds_dma16_at(const srd_t srd, const unsigned lds_base, const int voff, const int soff) {
+    asm volatile(
+        "s_add_u32 m0, %0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(lds_base), "v"(voff), "s"(srd), "s"(soff), "n"(OFF)
+        : "memory", "scc");
+}
+
 }  // namespace rpnet
