@@ -74,6 +74,20 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
         }
     }
     float amax = 0.f;
+    // the per-row factors of ALL the wave's tiles are fetched up front (they do not depend on the accumulators): one exposed
+    // load latency per launch instead of one per 32-row tile
+    constexpr int NQA = WN * 4;
+    float sc_all[ROWOPS ? WM : 1][NQA];
+    if (ROWOPS && d.out_scale_mode) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int q = 0; q < NQA; ++q) {
+                const int row = rows(wm * WM * 32 + i * 32 + (q * 64 + lane) / (WN * 8));
+                const float f = (RowMap::kAlwaysValid || row >= 0) ? d.out_scale[row] : 0.f;
+                sc_all[i][q] = d.out_scale_mode == 2 ? 1.f - f : f;
+            }
+    }
     unsigned short* ys = reinterpret_cast<unsigned short*>(d.y_split);
     const size_t yplane = (size_t)M * Cout;
     const float ysinv = (ROWOPS && d.y_split && d.y_split_scale) ? 1.f / *d.y_split_scale : 1.f;
@@ -115,11 +129,8 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
             // the loads of a tile's row factors / previous values go out together, in front of the arithmetic (the branches
             // are uniform and sit outside the loops: one wave per SIMD has nothing else to cover a load's latency with)
             if (d.out_scale_mode) {
-                float sc[NQ];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) sc[q] = (RowMap::kAlwaysValid || orow[q] >= 0) ? d.out_scale[orow[q]] : 0.f;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) v4[q] *= d.out_scale_mode == 2 ? 1.f - sc[q] : sc[q];
+                for (int q = 0; q < NQ; ++q) v4[q] *= sc_all[ROWOPS ? i : 0][q];
             }
             if (d.accumulate) {
                 f32x4 prev[NQ];

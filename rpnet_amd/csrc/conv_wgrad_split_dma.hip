@@ -357,7 +357,9 @@ int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9
                           hipStream_t s) {
     const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;
     const int lw = ilog2d(d->W), lh = ilog2d(d->H);
-    const bool p2 = lw >= 0 && lh >= 0;
+    // POW2: the scalar addressing needs the 8 pixels of a DMA piece in ONE image row (W a power of two >= 8); narrower images
+    // (the 4 x 4 level of a 64 x 64 episode) take the per-lane path
+    const bool p2 = lw >= 3 && lh >= 0;
     const unsigned short* dys = (const unsigned short*)dy;
     const bool fast = p2 && d->W >= 32 && !d->upsample;
 #define RPNET_W9D(NPL, P2, FA)                                                                                                 \

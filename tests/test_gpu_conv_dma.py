@@ -167,6 +167,8 @@ def test_dma_patch_kernel_repeatable(RF, monkeypatch):
     (2, 32, 64, 64, 0, 128, True),       # nearest x2: the x strips come from the half-resolution source
     (3, 16, 48, 128, 128, 128, False),   # W not a power of two (division path), odd image count
     (2, 8, 8, 64, 0, 64, False),         # M = 128: four K-steps in all — prologue and tail of the ring only
+    (4, 4, 4, 128, 0, 64, False),        # image rows of 4 pixels (the deepest level of a 64 x 64 episode): a DMA piece spans two rows
+    (2, 4, 8, 64, 0, 64, False),         # H != W, rows of exactly one piece
     (5, 24, 40, 64, 0, 192, False),      # M = 4800 = 150 K-steps, image rows wider than a K-step and not a multiple of it
 ])
 def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
