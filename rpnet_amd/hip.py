@@ -127,7 +127,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+try:        # the raw handle of the current stream without building a torch.cuda.Stream object (10 us -> 0.5 us per C-ABI call)
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:      # a torch build without the private accessors
+    _raw_stream = None
+
+
 def stream():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
