@@ -186,6 +186,11 @@ typedef struct rpnet_conv_desc {
                                           previous call: rpnet_predict_scales; out_absmax of the same launch is the check).
                                           NULL: the planes of the unscaled output (three bf16 planes, or fp16 planes of values the
                                           caller knows to be <= 2^15) */
+    void* splitk_ws;                   /* optional workspace of rpnet_conv_splitk_workspace_bytes(d) bytes: lets rpnet_conv_fwd cut the */
+    size_t splitk_ws_bytes;            /* K range (input channels) of a launch whose grid would leave more than half of the CUs idle
+                                          (eval-mode calls at batch 2: M = 8192 ... 1024) into 2 ... 8 parts computed by separate blocks
+                                          (fp32 partial outputs in the workspace) and summed, in a fixed order, by a second launch that
+                                          does the epilogue (bias, ep_*, out_absmax, y_split).  NULL / too small: one block per tile */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
@@ -196,6 +201,10 @@ int rpnet_conv_stats_blocks(const rpnet_conv_desc* d);
  * fp32 operands): 0-3 plain split implicit GEMM, 7 the 8-wave patch kernel, 8-10 the 4-wave patch kernels, 11 the LDS-DMA
  * patch kernel (conv_split_dma.hip).  Tests use it to assert that a forced variant actually ran. */
 int rpnet_conv_tile_variant(const rpnet_conv_desc* d);
+/* bytes of rpnet_conv_desc.splitk_ws with which rpnet_conv_fwd would split the K range of this launch (0: it would not — the
+ * grid fills the machine, or the descriptor asks for an epilogue feature the reduce launch does not have: batch statistics,
+ * BatchNorm-backward sums, accumulate, per-row output scales, a second output tensor) */
+size_t rpnet_conv_splitk_workspace_bytes(const rpnet_conv_desc* d);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dW[cout][cin][kh][kw] = sum_pixels A[pixel+tap][cin] * dy[pixel][cout], A gathered

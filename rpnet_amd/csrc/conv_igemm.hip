@@ -211,6 +211,7 @@ static int launch_igemm(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipS
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout);
 int split_tile_rows(int variant, int* wave_rows);
 int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s);
+size_t conv_splitk_bytes(const rpnet_conv_desc* d, int M, int Cin, int Cout);
 
 }  // namespace rpnet
 
@@ -252,6 +253,11 @@ extern "C" int rpnet_conv_stats_blocks(const rpnet_conv_desc* d) {
 extern "C" int rpnet_conv_tile_variant(const rpnet_conv_desc* d) {
     if (!d || !d->split_planes) return -1;
     return rpnet::choose_tile_split(d, d->N * d->H * d->W, d->Co0 + d->Co1);
+}
+
+extern "C" size_t rpnet_conv_splitk_workspace_bytes(const rpnet_conv_desc* d) {
+    if (!d || !d->split_planes || d->taps != 9) return 0;
+    return rpnet::conv_splitk_bytes(d, d->N * d->H * d->W, d->C0 + d->C1, d->Co0 + d->Co1);
 }
 
 extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {

@@ -931,7 +931,8 @@ static int halo4_tw(const rpnet_conv_desc* d) {
 }
 
 // conv_split_dma.hip
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s);
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts = 1);
+int conv_splitk_parts(const rpnet_conv_desc* d, int M, int Cin, int Cout);
 
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
@@ -993,7 +994,23 @@ int split_tile_rows(int variant, int* wave_rows) {
     return 32 * v.wgm * v.wm;
 }
 
+// split K (conv_split_dma.hip) when the caller lent a workspace and the launch is one of the half-empty ones
+static int splitk_parts_for(const rpnet_conv_desc* d, int M, int Cin, int Cout) {
+    if (!halo_tw(d, Cout)) return 1;
+    return conv_splitk_parts(d, M, Cin, Cout);
+}
+
+size_t conv_splitk_bytes(const rpnet_conv_desc* d, int M, int Cin, int Cout) {
+    const int parts = splitk_parts_for(d, M, Cin, Cout);
+    return parts > 1 ? (size_t)parts * M * Cout * sizeof(float) : 0;
+}
+
 int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream_t s) {
+    if (d->splitk_ws) {
+        const int parts = splitk_parts_for(d, M, Cin, Cout);
+        if (parts > 1 && d->splitk_ws_bytes >= (size_t)parts * M * Cout * sizeof(float))
+            return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s, parts);
+    }
     switch (choose_tile_split(d, M, Cout)) {
         case 0: return launch_split<2, 2, 2, false>(d, M, Cin, Cout, s);
         case 1: return launch_split<2, 2, 1, false>(d, M, Cin, Cout, s);

@@ -39,7 +39,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // pixels x half p of the weights): 32 MFMAs per wave and step for the same 24 fragment reads.
 template <int TW, int NP, int WN, bool K64 = false>
 __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
-                                                                       const int tiles_n, const int ntiles) {
+                                                                       const int tiles_n, const int ntiles, const int kshift) {
     constexpr int BM = 256, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
     constexpr int HP = (HALO + 15) / 16;           // 1 KB DMA pieces (16 halo rows of 64 B) per plane
     constexpr int HPW = (HP + 3) / 4;              // piece positions per wave and channel chunk (the last ones may repeat)
@@ -69,10 +69,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
 
     constexpr int CSH = K64 ? 6 : 5;               // channels per K-step: 64 (one plane, two halves) or 32 (per plane)
-    const int kchunks = Cin >> CSH;
+    // split K (kshift > 0: grid.y = 2^kshift parts, conv_fwd_split_dma below): part blockIdx.y multiplies the channel chunks
+    // [cbase, cbase + kchunks) and leaves its tile as rows + blockIdx.y * M of the fp32 workspace d.y0 points to
+    const int kchunks = (Cin >> CSH) >> kshift;
+    const int cbase = (int)blockIdx.y * kchunks;
     const int nsteps = 9 * kchunks;
     const int rot = (int)(blockIdx.x % (unsigned)kchunks);
-    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << CSH; };
+    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return (cbase + c) << CSH; };
 
     const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
     const size_t planew = (size_t)9 * Cin * Cout;
@@ -316,17 +319,120 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         if (sacc == 123.456f) d.y0[t] = sacc;
         return;
     }
-    conv_epilogue<WM, WN, 2, PatchRows<TW>, false>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0, W}, d.N * HW, Cout, HW, n0, tm, wm, wn,
-                                                    li, h, smem);
+    conv_epilogue<WM, WN, 2, PatchRows<TW>, false>(d, acc, PatchRows<TW>{(n * H + y0) * W + x0 + (int)blockIdx.y * d.N * HW, W},
+                                                    d.N * HW, Cout, HW, n0, tm, wm, wn, li, h, smem);
+}
+
+// Sum of the split-K parts and the epilogue the parts left out: y = relu((sum_s part_s + bias) * ep_scale + ep_shift), max |y|,
+// y as fp16 / bf16 planes.  A thread owns 8 consecutive channels of a pixel; the parts are added in index order (the result
+// does not depend on the grid).  HBM-bound: (S + 1) x 4 bytes per element in, 4 + 2 planes out.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ ws, const int S, const size_t MC, const int Cout,
+                                                                 const float* __restrict__ bias, const float* __restrict__ ep_scale,
+                                                                 const float* __restrict__ ep_shift, const int relu, float* __restrict__ y,
+                                                                 unsigned short* __restrict__ ys, const int planes,
+                                                                 const float* __restrict__ ysc, float* __restrict__ out_absmax) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (i * 8 < MC) {
+        const int col = (int)((i * 8) % (size_t)Cout);
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + i * 8), b = *reinterpret_cast<const f32x4*>(ws + i * 8 + 4);
+        for (int s = 1; s < S; ++s) {
+            a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * MC + i * 8);
+            b += *reinterpret_cast<const f32x4*>(ws + (size_t)s * MC + i * 8 + 4);
+        }
+        float v8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (bias) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] += bias[col + k];
+        }
+        if (ep_scale) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v8[k] = v8[k] * ep_scale[col + k] + ep_shift[col + k];
+                if (relu) v8[k] = fmaxf(v8[k], 0.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 8) = f32x4{v8[0], v8[1], v8[2], v8[3]};
+        *reinterpret_cast<f32x4*>(y + i * 8 + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v8[k]));
+        if (ys) {
+            if (planes == 3) {
+                u32x4 pl[3];
+                split8<3>(v8, pl);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(ys + p * MC + i * 8) = pl[p];
+            } else {
+                const float ysinv = 1.f / *ysc;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v8[k] *= ysinv;
+                if (planes == 2) {
+                    u32x4 pl[2];
+                    split8<2>(v8, pl);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(ys + p * MC + i * 8) = pl[p];
+                } else {
+                    u32x4 pl[1];
+                    split8<1>(v8, pl);
+                    *reinterpret_cast<u32x4*>(ys + i * 8) = pl[0];
+                }
+            }
+        }
+    }
+    if (out_absmax) {
+        __shared__ float wave_max[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+            if (amax > __hip_atomic_load(out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned*>(out_absmax), __float_as_uint(amax));
+        }
+    }
+}
+
+// Parts (a power of two, 1 = no split) into which conv_fwd_split_dma cuts the K range of this launch, given a workspace
+// (rpnet_conv_desc.splitk_ws): launches whose 256 x 64 tiles cover half of the CUs or fewer — the eval-mode calls at batch 2:
+// M = 8192 (the 22 CRE convolutions of a T = 10 call), 4096, 1024 — when the epilogue is one the reduce launch has.
+int conv_splitk_parts(const rpnet_conv_desc* d, int M, int Cin, int Cout) {
+    if (d->split_planes != 2 || d->tune != 0 || d->taps != 9 || d->dilation > 1 || Cin < 128 || M % 256) return 1;
+    if (d->stats_partial || d->bnb_partial || d->bnb_y || d->accumulate || d->out_scale_mode || d->Co1 || d->y1 || d->acc_scale_x1 ||
+        d->groups > 1)
+        return 1;
+    const long tiles = (long)(M / 256) * (Cout / 64);
+    const int kchunks = Cin >> 5;
+    // measured (tools/eval_layers.py, batch 2): a quarter of a machine of tiles or fewer always gains (1024 -> 1024 at M = 1024:
+    // 205 -> 70 us in four parts; 512 -> 1024: 103 -> 58 us); half a machine gains only where K is long (1024 -> 512 at
+    // M = 4096: 136 -> 117 us in two parts) and loses where the second launch and the partial tiles outweigh half of a short
+    // K loop (256 -> 256 at M = 8192: 50 -> 60 us; 512 -> 512 at M = 4096: 75 -> 79 us)
+    if (tiles > 128 || (tiles > 64 && kchunks < 32)) return 1;
+    int parts = 1;
+    while (parts < 8 && tiles * parts * 2 <= 256 && kchunks % (parts * 2) == 0 && kchunks / (parts * 2) >= 2) parts *= 2;
+    return parts;
 }
 
 // launcher for conv_split.hip: two fp16 planes in 128- (wn = 2) or 64-wide (wn = 1) output tiles, or one fp16 plane in 64-channel
-// K-steps (128-wide tiles); whole (256 / TW) x TW patches
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s) {
+// K-steps (128-wide tiles); whole (256 / TW) x TW patches.  parts > 1 (two planes, wn = 1): split K, see above
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts) {
     const int tiles_m = M / 256, tiles_n = Cout / (64 * wn);
     const int ntiles = tiles_m * tiles_n;
+    rpnet_conv_desc dp = *d;
+    int kshift = 0;
+    if (parts > 1) {
+        if (d->split_planes != 2 || wn != 1 || (size_t)parts * M * Cout * sizeof(float) > d->splitk_ws_bytes || !d->splitk_ws) {
+            set_error("conv_igemm_split_dma: split K needs two planes, 64-wide tiles and the workspace");
+            return RPNET_ERR_WORKSPACE;
+        }
+        while ((1 << kshift) < parts) ++kshift;
+        // the parts: scaled accumulators only (the fp16 scales are powers of two, so scaling each part is exact)
+        dp.y0 = (float*)d->splitk_ws;
+        dp.bias = nullptr; dp.ep_scale = nullptr; dp.ep_shift = nullptr; dp.ep_relu = 0;
+        dp.out_absmax = nullptr; dp.y_split = nullptr; dp.split_out_planes = 0; dp.y_split_scale = nullptr;
+    }
 #define RPNET_DMA(TWV, WNV, K64V) \
-    hipLaunchKernelGGL((conv_igemm_split_dma_kernel<TWV, 2, WNV, K64V>), dim3(ntiles), dim3(256), 0, s, *d, Cin, Cout, tiles_n, ntiles)
+    hipLaunchKernelGGL((conv_igemm_split_dma_kernel<TWV, 2, WNV, K64V>), dim3(ntiles, parts), dim3(256), 0, s, dp, Cin, Cout, tiles_n, ntiles, kshift)
     if (d->split_planes == 1) {
         if (wn != 2 || Cin % 64 || d->C0 % 64) {
             set_error("conv_igemm_split_dma: one plane needs 128-wide tiles and channel counts in multiples of 64 per source");
@@ -341,6 +447,12 @@ int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int t
         return RPNET_ERR_ARG;
     }
 #undef RPNET_DMA
+    if (parts > 1) {
+        const size_t MC = (size_t)M * Cout;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((MC / 8 + 255) / 256)), dim3(256), 0, s, (const float*)d->splitk_ws, parts, MC,
+                           Cout, d->bias, d->ep_scale, d->ep_shift, d->ep_relu, d->y0, (unsigned short*)d->y_split, d->split_out_planes,
+                           d->y_split_scale, d->out_absmax);
+    }
     return check_launch("conv_igemm_split_dma");
 }
 

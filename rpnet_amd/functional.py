@@ -345,6 +345,8 @@ class BnRef:
 # the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
 # launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
 _BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
+# A/B switch: split K for the eval-mode 3x3 convolutions whose grid covers half of the CUs or fewer
+_EVAL_SPLITK = os.environ.get("RPNET_EVAL_SPLITK", "1") == "1"
 # A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
 _POOL_FUSE = os.environ.get("RPNET_POOL_FUSE", "1") == "1"
 # A/B switch: the BatchNorm-backward apply pass of Conv1.conv.0 inside its direct weight gradient (rpnet_conv1_wgrad_bn)
@@ -633,6 +635,13 @@ class ConvBnRelu(Function):
                     fpo = _MATH["f16_planes"]
                     z16 = torch.empty((fpo, N, H, W, cout), device=x0.device, dtype=torch.float16)
                     d.y_split, d.split_out_planes, d.y_split_scale = ptr(z16), fpo, ptr(sp)
+                if _EVAL_SPLITK and d.split_planes == 2 and pw.taps == 9 and N * H * W * cout <= 128 * 256 * 64:
+                    # a grid that would leave half of the CUs idle (batch-2 calls): lend the workspace that lets the launch
+                    # cut its K range into parts (rpnet_conv_desc.splitk_ws)
+                    nb = query("rpnet_conv_splitk_workspace_bytes", C.byref(d))
+                    if nb:
+                        d._ws = _ws(nb, x0)
+                        d.splitk_ws, d.splitk_ws_bytes = ptr(d._ws), nb
                 _cconv("rpnet_conv_fwd", d)
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
                 ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("bnb_y", vp), ("bnb_stats", vp), ("bnb_partial", vp), ("bnb_pmax", vp), ("bnb_groups", ci),
-                ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci), ("y_split_scale", vp)]
+                ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci), ("y_split_scale", vp), ("splitk_ws", vp), ("splitk_ws_bytes", cs)]
 
 
 PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
@@ -46,6 +46,7 @@ _SIGS = {
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_conv_tile_variant": (ci, [C.POINTER(ConvDesc)]),
+    "rpnet_conv_splitk_workspace_bytes": (cs, [C.POINTER(ConvDesc)]),
     "rpnet_bn_stats_from_partial": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp]),
     "rpnet_conv_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci, ci, ci]),
     "rpnet_conv_wgrad": (ci, [C.POINTER(ConvDesc), vp, vp, ci, ci, ci, ci, vp, cs, vp]),

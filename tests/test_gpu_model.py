@@ -735,6 +735,50 @@ def test_eval_fp16_planes_on_predicted_scales():
         RF.set_conv_math(old)
 
 
+def test_eval_split_k_matches_one_block_per_tile():
+    """Eval-mode calls at batch 2: the 3x3 convolutions whose 256 x 64 tiles cover half of the CUs or fewer cut their K range
+    into parts (rpnet_conv_desc.splitk_ws: fp32 partial tiles, summed in a fixed order by a second launch that does the
+    epilogue — bias, folded BatchNorm, ReLU, max |output|, the fp16 planes on the predicted scale).  Same results as one
+    block per tile up to the order of the fp32 sums, on measured (first call) and predicted (later calls) scales."""
+    from rpnet_amd import functional as RF
+    from rpnet_amd import modules as RM
+    old, old_min, old_sk = RF.conv_math(), RM._F16_MIN_PIXELS, RF._EVAL_SPLITK
+    RM._F16_MIN_PIXELS = 0
+    RF.set_conv_math("f16x2")
+    try:
+        cfg = load_cfg(3)
+        outs, used = {}, {}
+        for on in (False, True):
+            RF._EVAL_SPLITK = on
+            net = build(cfg, False)
+            lent = []
+            orig = RF.call
+
+            def spy(name, *args):
+                if name == "rpnet_conv_fwd":
+                    lent.append(int(bool(args[0]._obj.splitk_ws)))
+                return orig(name, *args)
+
+            RF.call = spy
+            try:
+                res = []
+                for seed in (41, 42, 43):
+                    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, 2, 128, DEV)
+                    with torch.no_grad():
+                        o = net(si, fg, bg, qi, appr_query_labels=appr)
+                    res.append([o["output"].clone()] + [o["refinement"][i].clone() for i in sorted(o["refinement"])])
+            finally:
+                RF.call = orig
+            outs[on], used[on] = res, sum(lent)
+        assert used[False] == 0 and used[True] >= 3 * 8, used       # 128^2 at batch 2: the CRE convolutions (M = 2048) and the deep levels
+        for a, b in zip(outs[True], outs[False]):
+            for x, y in zip(a, b):
+                assert rel_err(x, y) < 2e-5
+    finally:
+        RM._F16_MIN_PIXELS, RF._EVAL_SPLITK = old_min, old_sk
+        RF.set_conv_math(old)
+
+
 def test_graphed_train_step_matches_eager():
     """rpnet_amd.graph.GraphedTrainStep: the whole training step (forward, harness loss, backward with the weight gradients on
     side streams, into the flat bucket) captured into a HIP graph — loss and every gradient bit-identical to the eager step,
