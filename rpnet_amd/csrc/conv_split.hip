@@ -902,6 +902,7 @@ static const SplitVariant kSplitVariants[] = {
     {2, 4, 2, 0, 256},    // 11: 256 x 128 on an image patch, four waves (one per SIMD), operands by LDS-DMA (conv_split_dma.hip)
     {2, 4, 1, 0, 256},    // 12: 256 x 64 of the same kernel (wave tile 128 x 32)
     {2, 4, 2, 0, 256},    // 13: 256 x 128 of the same kernel on ONE fp16 plane, 64 channels per K-step
+    {2, 2, 1, 0, 256},    // 14: 128 x 64 of the same kernel (wave tile 64 x 32): grids that 256 x 64 tiles leave half empty
 };
 constexpr int kNumSplitVariants = sizeof(kSplitVariants) / sizeof(kSplitVariants[0]);
 
@@ -931,7 +932,7 @@ static int halo4_tw(const rpnet_conv_desc* d) {
 }
 
 // conv_split_dma.hip
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts = 1);
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts = 1, int bm = 256);
 int conv_splitk_parts(const rpnet_conv_desc* d, int M, int Cin, int Cout);
 
 // same rule as conv_igemm.hip: fewest idle block slots
@@ -939,7 +940,7 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = (d->tune & 0xff) - 1;      // bits 8..: ablation switches of conv_split_dma.hip
-        if (v == 12 && d->split_planes == 2 && halo_tw(d, Cout)) return v;
+        if ((v == 12 || v == 14) && d->split_planes == 2 && halo_tw(d, Cout)) return v;
         if (v == 13 && d->split_planes == 1 && halo_tw(d, Cout) && halo_bn(d, Cout) == 128 && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0)
             return v;
         if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2)) && halo_tw(d, Cout) &&
@@ -968,6 +969,10 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     // grids too small for that: 256 x 64 tiles of the DMA kernel (twice the blocks; 419 vs 317 TF on 1024 -> 1024 at
     // M = 4096) from half a machine of blocks upwards
     if (dma && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 64) >= 128) return 12;
+    // (variant 14, 128 x 64 tiles of the same kernel, is NOT chosen for exactly half a machine of those — the CRE convolutions
+    // of an eval-mode call at batch 2, 256 -> 256 at M = 8192: alone it is faster (29 vs 40 us back to back, 49 vs 57 us
+    // in the call's kernel trace), but the call replayed from its HIP graph got slower, 3.02 -> 3.17 ms on one box, three
+    // alternations — 256 busy CUs at a lower MFMA rate per CU against 128; reachable through `tune` and tested)
     if (halo4_tw(d)) {
         // 64-wide tiles (twice the blocks) win on every grid this kernel sees — 169 vs 107 TF at M = 4096, 1024 -> 512;
         // 182 vs 160 TF at M = 16384, 256 -> 256 — until the 128-wide grid alone is two full rounds of the machine
@@ -1019,6 +1024,7 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 11: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
         case 12: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s);
         case 13: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
+        case 14: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s, 1, 128);
         case 10:
             return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:

@@ -37,16 +37,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 // channels, whose two 32-channel halves take the places of the two planes (NP stays 2 for every byte count): half p of the
 // halo / weight slab comes from channels +32 p of the single plane, and the products are the diagonal ones (half p of the
 // pixels x half p of the weights): 32 MFMAs per wave and step for the same 24 fragment reads.
-template <int TW, int NP, int WN, bool K64 = false>
+// WM = 2: 128-pixel patches (wave tile 64 x 32 WN) for grids that 256-pixel patches leave half empty — the CRE convolutions of
+// an eval-mode call at batch 2 (M = 8192: 128 tiles of 256 x 64) — at six MFMAs per six fragment reads and half step.
+template <int TW, int NP, int WN, bool K64 = false, int WM = 4>
 __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpnet_conv_desc d, const int Cin, const int Cout,
                                                                        const int tiles_n, const int ntiles, const int kshift) {
-    constexpr int BM = 256, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
+    constexpr int BM = 64 * WM, BN = 64 * WN, TH = BM / TW, PW = TW + 2, HALO = (TH + 2) * PW;
     constexpr int HP = (HALO + 15) / 16;           // 1 KB DMA pieces (16 halo rows of 64 B) per plane
     constexpr int HPW = (HP + 3) / 4;              // piece positions per wave and channel chunk (the last ones may repeat)
     constexpr int A_BYTES = HP * 1024, HBUF = NP * A_BYTES;
     constexpr int B_BYTES = BN * 64, STAGE = NP * B_BYTES;
     constexpr int NS = 4;                          // weight ring: K-steps k .. k+3
-    constexpr int WM = 4;
     constexpr int NW = WN * NP;                    // weight DMAs per wave and K-step (16 WN rows x NP planes)
     static_assert(HPW <= 6, "halo pieces are issued during taps 0 .. HPW-1; the wait counts below assume HPW <= 6");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>())];
@@ -415,8 +416,8 @@ int conv_splitk_parts(const rpnet_conv_desc* d, int M, int Cin, int Cout) {
 
 // launcher for conv_split.hip: two fp16 planes in 128- (wn = 2) or 64-wide (wn = 1) output tiles, or one fp16 plane in 64-channel
 // K-steps (128-wide tiles); whole (256 / TW) x TW patches.  parts > 1 (two planes, wn = 1): split K, see above
-int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts) {
-    const int tiles_m = M / 256, tiles_n = Cout / (64 * wn);
+int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts, int bm) {
+    const int tiles_m = M / bm, tiles_n = Cout / (64 * wn);
     const int ntiles = tiles_m * tiles_n;
     rpnet_conv_desc dp = *d;
     int kshift = 0;
@@ -439,6 +440,15 @@ int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int t
             return RPNET_ERR_ARG;
         }
         if (tw == 32) RPNET_DMA(32, 2, true); else RPNET_DMA(16, 2, true);
+    } else if (d->split_planes == 2 && bm == 128) {
+        if (wn != 1 || parts != 1) {
+            set_error("conv_igemm_split_dma: 128-pixel patches come in 64-wide tiles, unsplit");
+            return RPNET_ERR_ARG;
+        }
+        if (tw == 32)
+            hipLaunchKernelGGL((conv_igemm_split_dma_kernel<32, 2, 1, false, 2>), dim3(ntiles, 1), dim3(256), 0, s, dp, Cin, Cout, tiles_n, ntiles, 0);
+        else
+            hipLaunchKernelGGL((conv_igemm_split_dma_kernel<16, 2, 1, false, 2>), dim3(ntiles, 1), dim3(256), 0, s, dp, Cin, Cout, tiles_n, ntiles, 0);
     } else if (d->split_planes == 2) {
         if (wn == 2) { if (tw == 32) RPNET_DMA(32, 2, false); else RPNET_DMA(16, 2, false); }
         else { if (tw == 32) RPNET_DMA(32, 1, false); else RPNET_DMA(16, 1, false); }

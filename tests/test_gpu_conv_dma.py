@@ -65,10 +65,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [12, 14])
 @pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", CASES + [(2, 32, 32, 64, 0, 64, False), (1, 16, 32, 128, 64, 192, False)])
-def test_dma_patch_kernel_64_wide_tiles(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
-    """variant 12 (256 x 64 tiles of the same kernel: Cout = 64 layers, small grids): other tiles than any register-staged
-    kernel, so the check is the fp64 reference (and the 8-wave / 4-wave patch kernels to 1e-5)"""
+def test_dma_patch_kernel_64_wide_tiles(RF, monkeypatch, N, H, W, c0, c1, cout, ups, variant):
+    """variants 12 / 14 (256 x 64 and 128 x 64 tiles of the same kernel: Cout = 64 layers, small grids): other tiles than any
+    register-staged kernel, so the check is the fp64 reference (and the 8-wave / 4-wave patch kernels to 1e-5)"""
     old = RF.conv_math()
     RF.set_conv_math("f16x2")
     try:
@@ -88,8 +89,8 @@ def test_dma_patch_kernel_64_wide_tiles(RF, monkeypatch, N, H, W, c0, c1, cout, 
         ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
         ref.backward(go.double())
         z0, da0, db0, rv0, dw0, ch0 = _run(RF, monkeypatch, 9, layer, a, b, go, ups, groups)
-        z, da, db, rv, dw, ch = _run(RF, monkeypatch, 12, layer, a, b, go, ups, groups)
-        assert ch == [12, 12], ch
+        z, da, db, rv, dw, ch = _run(RF, monkeypatch, variant, layer, a, b, go, ups, groups)
+        assert ch == [variant, variant], ch
         assert rel_err(z, z0) < 1e-5 and rel_err(da, da0) < 1e-5
         assert rel_err(nchw(z), ref) < 1e-3
         assert rel_err(nchw(da), ar.grad) < 1e-3
