@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
     if (out_absmax) {      // max |corr| of the launch (as rpnet_conv_desc.out_absmax): the bound its fp16 planes are scaled by
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(out_absmax), __float_as_uint(amax));
+        if (lane == 0 && amax > __hip_atomic_load(out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(out_absmax), __float_as_uint(amax));
     }
 }
 
