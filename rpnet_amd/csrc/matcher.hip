@@ -326,6 +326,40 @@ __global__ void softmax_thresh_pool_kernel(const float* __restrict__ logits, flo
     mask[i] = acc / (float)(s * s);
 }
 
+// the same for s = 4 (the model's feature scale) and W % 4 == 0: the K x 4 row quads of a thread's window are loaded up
+// front as 16-byte vectors (the generic loop above waits for its loads 16 times in a row: 12 us for 8192 threads, 3 us here);
+// same arithmetic per pixel, same summation order
+template <int KT>
+__global__ __launch_bounds__(256) void softmax_thresh_pool4_kernel(const float* __restrict__ logits, float* __restrict__ mask, int B,
+                                                                   int K, int H, int W, int soft) {
+    const int h = H / 4, w = W / 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * h * w) return;
+    const int x = i % w, y = (i / w) % h, b = i / (w * h);
+    const size_t plane = (size_t)H * W;
+    const float* base = logits + (size_t)b * K * plane + (size_t)(y * 4) * W + x * 4;
+    f32x4 v[KT][4];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) v[k][dy] = *reinterpret_cast<const f32x4*>(base + k * plane + (size_t)dy * W);
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            float mx = v[0][dy][dx];
+#pragma unroll
+            for (int k = 1; k < KT; ++k) mx = fmaxf(mx, v[k][dy][dx]);
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) den += expf(v[k][dy][dx] - mx);
+            const float p1 = expf(v[1][dy][dx] - mx) / den;
+            acc += soft ? p1 : (p1 > 0.5f ? 1.f : 0.f);
+        }
+    mask[i] = acc / 16.f;
+}
+
 // soft-mask gradient pieces (net/rp_net.py:283,308-311 with soft_mask: True)
 // dx = g * f(s), ds = sign * <g, x> per pixel, f(s) = s (mode 1) or 1 - s (mode 2)
 __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ g, const float* __restrict__ x,
@@ -505,7 +539,11 @@ extern "C" int rpnet_softmax_thresh_pool(const float* logits, float* mask, int B
     using namespace rpnet;
     RPNET_REQUIRE(logits && mask, RPNET_ERR_ARG, "softmax_thresh_pool: null pointer");
     RPNET_REQUIRE(K >= 2 && H % scale == 0 && W % scale == 0, RPNET_ERR_SHAPE, "softmax_thresh_pool: K=%d H=%d W=%d scale=%d", K, H, W, scale);
-    hipLaunchKernelGGL(softmax_thresh_pool_kernel, dim3(cdiv((long)B * (H / scale) * (W / scale), 256)), dim3(256), 0,
-                       (hipStream_t)stream, logits, mask, B, K, H, W, scale, soft);
+    const dim3 grid(cdiv((long)B * (H / scale) * (W / scale), 256));
+    if (scale == 4 && W % 4 == 0 && (K == 2 || K == 3) && ((size_t)logits & 15) == 0) {
+        if (K == 2) hipLaunchKernelGGL(softmax_thresh_pool4_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, logits, mask, B, K, H, W, soft);
+        else hipLaunchKernelGGL(softmax_thresh_pool4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, logits, mask, B, K, H, W, soft);
+    } else
+        hipLaunchKernelGGL(softmax_thresh_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, mask, B, K, H, W, scale, soft);
     return check_launch("softmax_thresh_pool");
 }

@@ -394,12 +394,14 @@ def test_maxpool(RF):
 def test_mask_avgpool_and_threshold(RF):
     m = (torch.rand(3, 32, 48, generator=torch.Generator().manual_seed(1)) > 0.6).float()
     assert torch.equal(RF.mask_avgpool(m.to(DEV), 4).cpu(), F.avg_pool2d(m[:, None], 4)[:, 0])
-    lg = rnd(14, 3, 2, 32, 48)
-    for soft in (False, True):
-        p = lg.softmax(1)[:, 1]
-        ref = F.avg_pool2d(((p > 0.5).float() if not soft else p)[:, None], 4)[:, 0]
-        got = RF.softmax_thresh_pool(lg.to(DEV), 4, soft).cpu()
-        assert (got - ref).abs().max() < 1e-6
+    # scale 4 with two / three classes: the vector-load kernel; scale 2 and four classes: the generic loop
+    for (shape, scale) in (((3, 2, 32, 48), 4), ((2, 3, 16, 24), 4), ((2, 2, 12, 10), 2), ((1, 4, 8, 8), 4)):
+        lg = rnd(14, *shape)
+        for soft in (False, True):
+            p = lg.softmax(1)[:, 1]
+            ref = F.avg_pool2d(((p > 0.5).float() if not soft else p)[:, None], scale)[:, 0]
+            got = RF.softmax_thresh_pool(lg.to(DEV), scale, soft).cpu()
+            assert (got - ref).abs().max() < 1e-6
 
 
 @pytest.mark.parametrize("dims", [(2, 64, 12, 10, 3), (1, 64, 16, 16, 5), (2, 256, 16, 24, 5), (3, 128, 11, 13, 5),
