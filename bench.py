@@ -479,11 +479,24 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
         step(net, bucket, inp, scaler)
     fence()
     exposed = [] if world > 1 else None
+    # per-step marks (an event on the compute stream + the host clock after each step's enqueue; no synchronisation): the
+    # spread of the timed steps goes into the line next to their total, so that one slow step (a busy host: the boxes are
+    # shared) is visible as such
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    host = []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
+        h0 = time.perf_counter()
         loss = step(net, bucket, inp, scaler, exposed)
+        marks[i + 1].record()
+        host.append(time.perf_counter() - h0)
     fence()
     el = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    spread = {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3),
+              "host_enqueue_median": round(1e3 * sorted(host)[len(host) // 2], 3),
+              "what": "per timed step: HIP events on the compute stream between the steps' ends (ms); the host's enqueue time of a step"}
     if math in ("f16x2", "f16") and not RF.f16_mode():
         # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
         # planes: label the line with what ran (`requested` keeps what was asked for)
@@ -512,8 +525,36 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
     RF.reset_arith()
     agg = profile_step(net, bucket, inp, scaler)
     arith = RF.arith_counts()          # which arithmetic every conv / correlation launch of that step actually ran
-    return {"value": world * w["batch"] * steps / el, "el": el, "agg": agg, "arith": arith, "math": math, "requested": requested,
+    return {"value": world * w["batch"] * steps / el, "el": el, "spread": spread, "agg": agg, "arith": arith, "math": math, "requested": requested,
             "net": net, "bucket": bucket, "inp": inp, "scaler": scaler, "cfg": cfg, "dist": dist_info, "fence": fence}
+
+
+def graph_replay_leg(net, bucket, inp, scaler, batch, fence, steps):
+    """The timed step captured once into a HIP graph (rpnet_amd.graph.GraphedTrainStep) and replayed `steps` times: the host
+    then enqueues ONE launch per step, so the figure does not depend on how busy the (shared) host is."""
+    from rpnet_amd.functional import dice_ce
+    from rpnet_amd.graph import GraphedTrainStep
+
+    def loss_fn(out, ql):
+        loss = dice_ce(out["output"], ql)
+        for v in out["refinement"].values():
+            loss = loss + dice_ce(v, ql)
+        return loss + scaler * out["align_loss"]
+    gts = GraphedTrainStep(net, bucket, loss_fn)
+    for _ in range(2):
+        gts(*inp[:4], inp[4], inp[5])
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        gts(*inp[:4], inp[4], inp[5])
+    t_enq = time.perf_counter() - t1
+    fence()
+    t_all = time.perf_counter() - t1
+    del gts
+    return {"value": round(batch * steps / t_all, 3), "unit": "pairs/s", "steps": steps, "ms_per_step": round(1e3 * t_all / steps, 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3),
+            "what": "the timed step captured once into a HIP graph and replayed (bit-identical gradients: "
+                    "tests/test_gpu_model.py::test_graphed_train_step_matches_eager); `value` above is the eager step"}
 
 
 CONV_MATH_TEXT = {
@@ -642,34 +683,12 @@ def main():
     graph_leg = None
     if world == 1 and not args.no_cpu_baseline:
         # the same step replayed from a HIP graph (rpnet_amd.graph.GraphedTrainStep): the host then enqueues ONE launch per step
-        from rpnet_amd.functional import dice_ce
-        from rpnet_amd.graph import GraphedTrainStep
-
-        def loss_fn(out, ql):
-            loss = dice_ce(out["output"], ql)
-            for v in out["refinement"].values():
-                loss = loss + dice_ce(v, ql)
-            return loss + scaler * out["align_loss"]
-        gts = GraphedTrainStep(net, bucket, loss_fn)
-        for _ in range(2):
-            gts(*inp[:4], inp[4], inp[5])
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            gts(*inp[:4], inp[4], inp[5])
-        t_enq = time.perf_counter() - t1
-        fence()
-        t_all = time.perf_counter() - t1
-        graph_leg = {"value": round(args.batch * 10 / t_all, 3), "unit": "pairs/s", "steps": 10, "ms_per_step": round(t_all * 100, 3),
-                     "host_enqueue_ms_per_step": round(t_enq * 100, 3),
-                     "what": "the timed step captured once into a HIP graph and replayed (bit-identical gradients: "
-                             "tests/test_gpu_model.py::test_graphed_train_step_matches_eager); `value` above is the eager step"}
-        del gts
+        graph_leg = graph_replay_leg(net, bucket, inp, scaler, args.batch, fence, 10)
     if rank == 0:
         result = {
             "metric": f"support/query pairs/sec (fwd+bwd, {args.shots}-shot {args.size}x{args.size}, T={args.iters})",
             "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * m["el"] / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * m["el"] / args.steps, 3), "step_ms": m["spread"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if math == "f16" else "f32", "data": "synthetic",
             "conv_math": CONV_MATH_TEXT[math],
             "config": {"workload": workload_text(w, world),
@@ -705,8 +724,11 @@ def main():
             om = measure(ow, 1, 0, dev, cfg, 5, 3, RF)
             result["other_configs"][name] = {
                 "workload": workload_text(ow, 1), "value": round(om["value"], 3), "unit": "pairs/s", "steps": 5, "warmup": 3,
-                "ms_per_step": round(1e3 * om["el"] / 5, 3), "dtype": "f16" if om["math"] == "f16" else "f32",
+                "ms_per_step": round(1e3 * om["el"] / 5, 3), "step_ms": om["spread"], "dtype": "f16" if om["math"] == "f16" else "f32",
                 "conv_math": om["math"], "launches_by_arithmetic": om["arith"], "roofline": roofline_of(om, ow, 1)}
+            if not args.no_cpu_baseline:
+                result["other_configs"][name]["graph_replay"] = graph_replay_leg(om["net"], om["bucket"], om["inp"], om["scaler"],
+                                                                                 ow["batch"], om["fence"], 5)
             del om
             torch.cuda.empty_cache()
         RF.set_conv_math(requested)

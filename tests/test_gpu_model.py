@@ -779,10 +779,12 @@ def test_eval_split_k_matches_one_block_per_tile():
         RF.set_conv_math(old)
 
 
-def test_graphed_train_step_matches_eager():
+@pytest.mark.parametrize("shots,ways,B,size", [(1, 1, 4, 128), (5, 1, 2, 64), (1, 2, 2, 128)])
+def test_graphed_train_step_matches_eager(shots, ways, B, size):
     """rpnet_amd.graph.GraphedTrainStep: the whole training step (forward, harness loss, backward with the weight gradients on
     side streams, into the flat bucket) captured into a HIP graph — loss and every gradient bit-identical to the eager step,
-    also on a second episode copied into the static inputs (the replay re-packs weights and re-measures nothing stale)."""
+    also on a second episode copied into the static inputs (the replay re-packs weights and re-measures nothing stale);
+    1-way 1-shot and the two extension shapes of BASELINE configs[2] / configs[4] (5-shot, 2-way)."""
     import rpnet_amd.functional as RF
     from rpnet_amd.graph import GraphedTrainStep
     from rpnet_amd.parallel import FlatGradBucket
@@ -793,7 +795,7 @@ def test_graphed_train_step_matches_eager():
     try:
         g = GraphedTrainStep(net, bucket, lambda out, ql: total_loss(out, ql, cfg["align_loss_scaler"]))
         for seed in (71, 72):
-            (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, 4, 128, DEV)
+            (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV, n_shots=shots, n_ways=ways)
             loss_g = g(si, fg, bg, qi, ql, appr).clone()
             torch.cuda.synchronize()
             grads_g = bucket.flat.clone()
