@@ -41,6 +41,8 @@ else:
 for _ in range(3):
     one()
 torch.cuda.synchronize()
+# backward on the calling thread, where cProfile can see it (the engine's device thread is not a Python thread)
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(a.steps):
