@@ -265,6 +265,56 @@ def test_full_size_properties():
             assert torch.equal(p.grad, g1[n]), n
 
 
+def test_eval_call_full_size_all_paths_agree():
+    """The reference driver's call (test_rpnet.py:189-215: eval mode, 2 slices, 256x256, T = 10) at full size under the default
+    arithmetic — fp16 planes on predicted scales, split K on the 16^2 / 32^2 levels, the two CRE convolutions on two
+    streams — against the same call on the fp32 matrix instruction (no planes, no scales, no split), eager and replayed
+    from its HIP graph, over four consecutive calls (the first measures, the others predict)."""
+    from rpnet_amd import functional as RF
+    from rpnet_amd.graph import GraphedEval
+    cfg = load_cfg(10)
+    eps = [episode_tensors(seed, 2, 256, DEV)[0] for seed in (51, 52, 53, 54)]
+    RF.set_conv_math("f32")
+    ref_net = build(cfg, False)
+    with torch.no_grad():
+        want = [ref_net(si, fg, bg, qi, appr_query_labels=appr) for (si, fg, bg, qi, ql, appr) in eps]
+        want = [[o["refinement"][i].clone() for i in range(10)] for o in want]
+    RF.set_conv_math("f16x2")
+    net = build(cfg, False)
+    lent, orig = [], RF.call
+
+    def spy(name, *args):
+        if name == "rpnet_conv_fwd":
+            lent.append(int(bool(args[0]._obj.splitk_ws)))
+        return orig(name, *args)
+
+    RF.call = spy
+    base = RF.pred_stats()
+    try:
+        with torch.no_grad():
+            RF.reset_arith()
+            got = [net(si, fg, bg, qi, appr_query_labels=appr) for (si, fg, bg, qi, ql, appr) in eps]
+            got = [[o["refinement"][i].clone() for i in range(10)] for o in got]
+    finally:
+        RF.call = orig
+    st = RF.pred_stats()
+    assert set(RF.arith_counts()["conv3x3"]) == {"f16x2"}
+    assert st["predicted_calls"] - base["predicted_calls"] == 3 and st["violations"] == base["violations"], (base, st)
+    assert sum(lent) == 4 * 4, sum(lent)                  # per call: Conv5 (two layers, M = 1024) and the two 1024 -> 512 layers at M = 4096
+    for w, g in zip(want, got):
+        # teacher-free: the hard threshold of the fed-back mask may flip pixels between arithmetics; iteration 0 has no
+        # feedback, the later ones are compared through the share of pixels whose class differs
+        assert rel_err(g[0], w[0]) < 2e-5
+        for i in range(1, 10):
+            flips = (g[i].argmax(1) != w[i].argmax(1)).float().mean().item()
+            assert flips < 2e-3, (i, flips)
+    graphed = GraphedEval(net)
+    for (si, fg, bg, qi, ql, appr), g in zip(eps[2:], got[2:]):
+        out = graphed(si, fg, bg, qi, appr_query_labels=appr)
+        for i in range(10):
+            assert rel_err(out["refinement"][i], g[i]) <= 1e-6, i
+
+
 def test_bn_bwd_reduction_in_dgrad_epilogue(monkeypatch):
     """rpnet_conv_desc.bnb_*: the first layer of each of the seven conv_blocks has ONE consumer, whose input-gradient
     launch can run the reduction pass of that layer's BatchNorm backward in its epilogue (off by default: measured
