@@ -46,6 +46,10 @@ __device__ __forceinline__ double block_sum256(double v, double* smem4) {
     return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// most K splits of the single-tap (1x1) weight gradient: its GEMM is a latency chain of 32-pixel steps over six output
+// tiles, so more and shorter blocks win until the serial walk of the reduce launch takes the gain back
+constexpr int kWgrad1MaxSplits = 128;
+
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private
 // L2); give every XCD a contiguous run of logical tiles so neighbouring tiles (which share
 // an operand panel) hit the same L2.  Bijective for any tile count.

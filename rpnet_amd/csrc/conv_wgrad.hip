@@ -447,7 +447,7 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
     ks = max(1, min(ks, max(1, total_steps / 8)));       // at least 8 K-steps per block
     // a 1x1 conv has few output tiles (384 x 64 here): the reduce kernel walks the splits serially with only a
     // handful of blocks, so deep splits cost more there than they win in the GEMM (measured 73 -> 45 us)
-    if (taps == 1) ks = min(ks, 32);
+    if (taps == 1) ks = min(ks, kWgrad1MaxSplits);
     *steps_per_split = (total_steps + ks - 1) / ks;
     *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
 }

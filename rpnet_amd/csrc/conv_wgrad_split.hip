@@ -374,7 +374,7 @@ void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_spl
     const int total_steps = (M + 31) / 32;
     int ks = (512 + tiles - 1) / tiles;                    // two blocks per CU
     ks = std::max(1, std::min(ks, std::max(1, total_steps / 8)));
-    ks = std::min(ks, 32);
+    ks = std::min(ks, kWgrad1MaxSplits);
     *steps_per_split = (total_steps + ks - 1) / ks;
     *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
 }
