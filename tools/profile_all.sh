@@ -31,6 +31,9 @@ python tools/cpu_overhead.py 2>/dev/null | grep -v Warning > $O/${TAG}_cpu_overh
 C5="python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
 RPNET_ASYNC_WGRAD=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_c5) $O/${TAG}_bench_c5_f16_kernel_stats.csv
+# the reference driver's call (eval mode, 2 slices, 256^2, T = 10): kernel trace of 33 eager + 33 replayed calls
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_eval -o t -- python tools/bench_eval.py > $O/${TAG}_eval_call.txt 2>&1
+python tools/rocpd_stats.py $(db $R/trace_eval) $O/${TAG}_eval_call_kernel_stats.csv
 # the bench lines themselves (default incl. CPU baseline and eval leg; configs[4]; configs[2]; two gloo ranks on the one GPU)
 python bench.py > $O/${TAG}_bench_final.json 2> $R/bench_final.err
 # (configs[2] / configs[4] are part of the default line since round 3: other_configs)
