@@ -449,12 +449,14 @@ static void wgrad_plan(int M, int Cin, int Cout, int taps, int* bm, int* bn, int
     // handful of blocks, so deep splits cost more there than they win in the GEMM (measured 73 -> 45 us)
     if (taps == 1) ks = min(ks, kWgrad1MaxSplits);
     *steps_per_split = (total_steps + ks - 1) / ks;
+    if (taps == 9) *steps_per_split += *steps_per_split & 1;      // even: the one-plane DMA kernel takes 64-pixel steps
     *ksplit = (total_steps + *steps_per_split - 1) / *steps_per_split;
 }
 
 // split-bf16 operands (conv_wgrad_split.hip)
 int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                       hipStream_t s);
+bool conv_wgrad9_dma_one_plane_ok(const rpnet_conv_desc* d, int M, int sps9);
 int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                           hipStream_t s);
 void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split);
@@ -506,7 +508,9 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
             if (dy) {    // dy == NULL: reduce phase only (rpnet_conv_wgrad_reduce)
                 // two fp16 planes: the LDS-DMA kernel (conv_wgrad_split_dma.hip; same partial sums, bit for bit); tune 8 =
                 // the register-staged 12-wave kernel of round 2 (A/B switch), 4 = its 4-wave layout
-                const bool dma = d->split_planes == 2 && d->tune != 8 && d->tune != 4;
+                // (one fp16 plane: the same kernel with the two halves of a 64-pixel step in the two plane slots, where the
+                // image rows are at least that long — conv_wgrad9_dma_one_plane_ok)
+                const bool dma = (d->split_planes == 2 || conv_wgrad9_dma_one_plane_ok(d, M, sps9)) && d->tune != 8 && d->tune != 4;
                 if (int rc = dma ? conv_wgrad9_split_dma(d, dy, part9, M, Cin, Cout, ks9, sps9, s)
                                  : conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s))
                     return rc;

@@ -39,7 +39,10 @@ __device__ __forceinline__ void static_for_w(F&& f) {
 
 // FAST: power-of-two images at least a K-step wide, no up-sampling (25 of the 27 weight-gradient launches of the step): the
 // addressing of a step collapses to a handful of scalar instructions (below).  POW2 (without FAST): shifts instead of divisions.
-template <int NP, bool POW2, bool FAST>
+// K64: ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]) in the same LDS geometry, as in conv_split_dma.hip: a
+// K-step is 64 pixels of one image row, whose two 32-pixel halves take the places of the two planes; the products are the
+// diagonal ones (half p of x with half p of dy): 18 MFMAs per wave and slice for the same 24 fragment reads.
+template <int NP, bool POW2, bool FAST, bool K64 = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                   float* __restrict__ partial, const int M, const int Cin,
                                                                   const int Cout, const int tiles, const int tiles_n,
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     // (slice, tap column, row half) registers that also carry the image-border redirects.
     constexpr int BOFF = NS * A_STAGE;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BOFF + NS * B_STAGE];
-    static_assert(NP == 2, "two fp16 planes (one plane has 9 MFMAs per slice for 12 fragment reads: another schedule)");
+    static_assert(NP == 2, "two plane slots: two fp16 planes, or the two halves of a 64-pixel step of one plane (K64)");
+    static_assert(!K64 || FAST, "the one-plane form needs a whole 64-pixel step in one image row");
+    constexpr int PXS = K64 ? 64 : BK;                              // pixels per K-step
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -82,12 +87,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     const size_t planex = (size_t)d.N * Hs * Ws * Cs, planey = (size_t)M * Cout;
     const int pbx = (int)(planex * 2), pby = (int)(planey * 2);
 
-    const int total_steps = (M + BK - 1) / BK;
+    const int total_steps = (M + PXS - 1) / PXS;
     const int s_begin = z * steps_per_split;
     const int s_end = min(s_begin + steps_per_split, total_steps);
 
     // one descriptor per tensor over all its planes (the plane is part of the scalar offset)
-    const srd_t rsx = make_srd(src, NP * pbx), rsy = make_srd(dy, NP * pby);
+    const srd_t rsx = make_srd(src, (K64 ? 1 : NP) * pbx), rsy = make_srd(dy, (K64 ? 1 : NP) * pby);
+    // the second plane slot: the other plane, or (K64) the next 32 pixels of the one plane
+    const int x_slot1 = K64 ? BK * (Cs * 2) : pbx, y_slot1 = K64 ? BK * (Cout * 2) : pby;
     const unsigned lds0 = lds_addr(smem);
     const unsigned ldsw = lds0 + 8 * wv * RB;                       // this wave's 8 rows inside a strip / dy piece wv
     const unsigned lds4 = lds0 + 32 * RB;                           // dy piece 4 (wave 0)
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
         constexpr int DST = stage * A_STAGE + kyi * BK * RB;
         int voff, soff;
         if constexpr (FAST) {
-            const int qb0 = st * BK + 8 * wv;                         // centre-row pixel of the piece; source = qb0 + (ky - 1) W
+            const int qb0 = st * PXS + 8 * wv;                        // centre-row pixel of the piece; source = qb0 + (ky - 1) W
             const int yc = (qb0 >> lw) & (H - 1);
             const bool ok = kyi == 1 || (kyi == 0 ? yc >= 1 : yc <= H - 2);
             soff = qb0 * Cs2 + cc * 2 + (kyi - 1) * wcs;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
             soff = cc * 2;
         }
         lds_dma16_at<DST>(rsx, ldsw, voff, soff);
-        lds_dma16_at<DST + A_PLANE>(rsx, ldsw, voff, soff + pbx);
+        lds_dma16_at<DST + A_PLANE>(rsx, ldsw, voff, soff + x_slot1);      // (an invalid row stays invalid: voff is out of range)
     };
     // dy: piece wv (rows 8 wv ..), wave 0 also the fifth piece (rows 32 .. 39); pixels before 0 or past M read as zeros (an
     // offset beyond num_records; the planes share one descriptor, so the bound is checked here)
@@ -138,17 +145,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     auto dma_y = [&](auto stagec, const bool fifth, const int st) {
         constexpr int stage = decltype(stagec)::value;
         constexpr int DST = BOFF + stage * B_STAGE;
-        const int rowb = st * BK - 1 + (fifth ? 32 : 8 * wv);       // first pixel of the piece (uniform): -1 for step 0, piece 0
+        const int rowb = st * PXS - 1 + (fifth ? 32 : 8 * wv);      // first pixel of the piece (uniform): -1 for step 0, piece 0
         const bool neg = rowb < 0;
         const int soff = (neg ? 0 : rowb) * (Cout * 2) + n0 * 2;
         int voff = neg ? ylane_m1 : ylane;
         voff = rowb + drow < M ? voff : (int)0x80000000;
+        // second slot: the other plane at the same pixels, or (K64) the piece 32 pixels on (never before pixel 0)
+        const int soff1 = K64 ? (rowb + BK) * (Cout * 2) + n0 * 2 : soff + y_slot1;
+        const int voff1 = K64 ? (rowb + BK + drow < M ? ylane : (int)0x80000000) : voff;
         if (fifth) {
             lds_dma16_at<DST>(rsy, lds4, voff, soff);
-            lds_dma16_at<DST + B_PLANE>(rsy, lds4, voff, soff + pby);
+            lds_dma16_at<DST + B_PLANE>(rsy, lds4, voff1, soff1);
         } else {
             lds_dma16_at<DST>(rsy, ldsw, voff, soff);
-            lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff, soff + pby);
+            lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff1, soff1);
         }
     };
     auto dma_step = [&](auto stagec, const int st) {
@@ -217,32 +227,35 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
         constexpr int s = decltype(sc)::value;
         if constexpr (FAST) {
             // a step's 32 pixels lie in one image row: only its first pixel can lack a left neighbour, only its last a right one
-            const int x0 = (st * BK) & (W - 1);
+            // (K64: the first pixel of the step is in slot 0, the last in slot 1: read_frag takes bsel for that slot only)
+            const int x0 = (st * PXS) & (W - 1);
             if constexpr (s == 0) bsel[0][2][0] = (x0 == 0 && lane_first) ? bzero : bconst[0][2][0];           // kx = +1: dy[q - 1]
-            else bsel[1][0][1] = (x0 == W - BK && lane_last) ? bzero : bconst[1][0][1];                        // kx = -1: dy[q + 1]
+            else bsel[1][0][1] = (x0 == W - PXS && lane_last) ? bzero : bconst[1][0][1];                       // kx = -1: dy[q + 1]
         } else {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int row = 16 * s + 4 * e + krow;
-                const int q = st * BK + row;
+                const int q = st * PXS + row;
                 const int ox = POW2 ? (q & (W - 1)) : (q % W);
                 bsel[s][0][e] = ox <= W - 2 ? bconst[s][0][e] : bzero;     // kx = -1: dy[q + 1]
                 bsel[s][2][e] = ox >= 1 ? bconst[s][2][e] : bzero;         // kx = +1: dy[q - 1]
             }
         }
     };
-    constexpr int NR = NP * 12, NMMA = nprod<NP>() * 9;
+    constexpr int NR = NP * 12, NMMA = (K64 ? 2 : nprod<NP>()) * 9;
     auto read_frag = [&](auto sc, auto kc, auto stagec) {
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value, stage = decltype(stagec)::value;
         constexpr int grp = k / 12, r = (k - grp * 12) >> 1, e = k & 1;      // plane pair, fragment of the pair, row half
-        constexpr int pa = NP - 1 - grp, pb = grp;
+        constexpr int pa = K64 ? grp : NP - 1 - grp, pb = grp;
         if constexpr (r == 0 || r >= 4) {
             constexpr int ky = r == 0 ? 0 : r - 3;
             constexpr int off = (stage & 1) * A_STAGE + pa * A_PLANE + (ky * BK + 16 * s + 4 * e) * RB;
             afr[s][ky][pa][e] = tr((stage >> 1 ? aptr1 : aptr0) + off);
         } else {
             constexpr int kx = r - 1;
-            bfr[s][kx][pb][e] = tr(bsel[s][kx][e] + (stage * B_STAGE + pb * B_PLANE));
+            // K64: the left-border redirect belongs to slot 0 (first pixel of the step), the right-border one to slot 1
+            constexpr bool sel = !K64 || (pb == 0 ? (s == 0 && kx == 2 && e == 0) : (s == 1 && kx == 0 && e == 1));
+            bfr[s][kx][pb][e] = tr((sel ? bsel[s][kx][e] : bconst[s][kx][e]) + (stage * B_STAGE + pb * B_PLANE));
         }
     };
     auto frag = [](const s16x4 lo, const s16x4 hi) {
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     auto mma_one = [&](auto sc, auto mc) {
         constexpr int s = decltype(sc)::value, m = decltype(mc)::value;
         constexpr int q = m / 9, tap = m - q * 9, ky = tap / 3, kx = tap - ky * 3;
-        constexpr int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
+        constexpr int pa = K64 ? q : prod_a<NP>(q), pb = K64 ? q : prod_b<NP>(q);
         acc[tap] = mma16<NP>(frag(afr[s][ky][pa][0], afr[s][ky][pa][1]), frag(bfr[s][kx][pb][0], bfr[s][kx][pb][1]), acc[tap]);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -285,6 +298,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
                     read_frag(I1{}, mc, SK{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (NR > NMMA && m < NR - NMMA) {      // K64: 24 reads behind 18 MFMAs
+                    read_frag(I1{}, std::integral_constant<int, NMMA + m>{}, SK{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (m == 3 || m == 9 || m == 15) {
                     dma_x(std::integral_constant<int, (m - 3) / 6>{}, SD{}, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
@@ -299,6 +316,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m < NR) {
                     read_frag(I0{}, mc, SN{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (NR > NMMA && m < NR - NMMA) {
+                    read_frag(I0{}, std::integral_constant<int, NMMA + m>{}, SN{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (m == 5) {
@@ -352,7 +373,14 @@ static int ilog2d(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// launches the nine-tap DMA kernel into `part9` ([ksplit][9][Cin][Cout] fp32, plan = wgrad9_plan); two fp16 planes only
+// one fp16 plane through the DMA kernel (K64): power-of-two images at least 64 pixels wide, no up-sampling, whole 64-pixel
+// steps per split
+bool conv_wgrad9_dma_one_plane_ok(const rpnet_conv_desc* d, int M, int sps9) {
+    return d->split_planes == 1 && !d->upsample && d->W >= 64 && ilog2d(d->W) >= 0 && ilog2d(d->H) >= 0 && M % 64 == 0 && sps9 % 2 == 0;
+}
+
+// launches the nine-tap DMA kernel into `part9` ([ksplit][9][Cin][Cout] fp32, plan = wgrad9_plan); two fp16 planes, or one
+// where conv_wgrad9_dma_one_plane_ok
 int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                           hipStream_t s) {
     const int tiles_n9 = Cout / 64, tiles9 = (Cin / 64) * tiles_n9;
@@ -366,8 +394,11 @@ int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9
     hipLaunchKernelGGL((conv_wgrad9_dma_kernel<NPL, P2, FA>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, \
                        tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0)
     if (d->split_planes == 2) { if (fast) RPNET_W9D(2, true, true); else if (p2) RPNET_W9D(2, true, false); else RPNET_W9D(2, false, false); }
-    else {
-        set_error("conv_wgrad9_split_dma: two fp16 planes only");
+    else if (conv_wgrad9_dma_one_plane_ok(d, M, sps9)) {
+        hipLaunchKernelGGL((conv_wgrad9_dma_kernel<2, true, true, true>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout,
+                           tiles9, tiles_n9, ks9, sps9 / 2, lw, lh);
+    } else {
+        set_error("conv_wgrad9_split_dma: two fp16 planes, or one on images of >= 64 pixels per row");
         return RPNET_ERR_ARG;
     }
 #undef RPNET_W9D

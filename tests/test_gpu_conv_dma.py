@@ -244,3 +244,44 @@ def test_dma_patch_kernel_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout, ups)
         assert rel_err(nchw(z), ref) < 1e-2          # fp16 operands (F16_LOGIT_TOL class): measured ~2e-3
     finally:
         RF.set_conv_math(old)
+
+
+@pytest.mark.parametrize("N,H,W,c0,c1,cout", [
+    (2, 16, 64, 128, 0, 128),      # one 64-pixel step per image row: every step has both a left and a right border
+    (1, 8, 128, 64, 64, 64),       # two sources, two steps per row (border on one side each)
+    (2, 64, 64, 64, 0, 192),       # square images, three column tiles
+    (4, 4, 256, 128, 0, 64),       # four steps per row, top / bottom borders in every second row
+])
+def test_dma_weight_gradient_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout):
+    """conv_wgrad9_dma_kernel<.., K64>: the weight gradient on ONE fp16 plane (f16 arithmetic of BASELINE configs[4]) through the
+    LDS-DMA kernel — a K-step = 64 pixels of an image row, the halves where the two planes of f16x2 sit.  Same products as the
+    register-staged one-plane kernel (tune 8) in another order: equal to fp32 summation round-off; and within the f16
+    error of that kernel against the fp64 reference."""
+    old = RF.conv_math()
+    RF.set_conv_math("f16")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(c0 + c1, cout, 3, 61)
+        a = rnd(62, N, c0, H, W)
+        b = rnd(63, N, c1, H, W) if c1 else None
+        go = rnd(64, N, cout, H, W)
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        br = b.double().requires_grad_(True) if c1 else None
+        xin = torch.cat([ar, br], 1) if c1 else ar
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go.double())
+        monkeypatch.setitem(RF.TUNE, "wgrad", 8)
+        dw_old = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
+        monkeypatch.setitem(RF.TUNE, "wgrad", 0)
+        dw_new = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
+        assert RF.arith_counts()["wgrad3x3"].get("f16", 0) >= 1
+        assert not torch.equal(dw_old, dw_new)          # another kernel ran (another summation order)
+        assert rel_err(dw_new, dw_old) < 2e-6
+        # (one fp16 plane of dy behind a BatchNorm backward: per-element roundings of 2^-11 of the TENSOR maximum — the
+        # error against fp64 is that of the arithmetic, the same for both kernels)
+        e_new, e_old = rel_err(dw_new, c_ref.weight.grad), rel_err(dw_old, c_ref.weight.grad)
+        assert e_new < 1.02 * e_old + 1e-5 and e_new < 0.1, (e_new, e_old)
+    finally:
+        RF.set_conv_math(old)
