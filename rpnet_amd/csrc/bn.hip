@@ -232,16 +232,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                 mx[k] = fmaxf(mx[k], fabsf(dm));
             }
         };
-        long r = r0 + tr;
-        for (; r + gm.rows_it < r1; r += 2 * gm.rows_it) {      // two rows per pass: four 16-byte loads in flight per thread
+        // Rows are dealt to the blocks CYCLICALLY in groups of rows_it (block b: groups b, b + nblk, ...): at any moment the
+        // blocks of the launch read one contiguous window of both tensors.  (A contiguous range per block put all blocks
+        // a fixed 2^k bytes apart — the same HBM channels at the same time: 3.7 - 4.4 TB/s against the 5.4 of the
+        // element-wise passes.)  Two groups per pass: four 16-byte loads in flight per thread.
+        (void)r0; (void)r1;
+        const long stride = (long)gm.nblk * gm.rows_it;
+        long r = (long)blk * gm.rows_it + tr;
+        for (; r + stride < R; r += 2 * stride) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C);
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(y + base + (size_t)(r + gm.rows_it) * C);
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)(r + gm.rows_it) * C);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(y + base + (size_t)(r + stride) * C);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)(r + stride) * C);
             take(v0, d0);
             take(v1, d1);
         }
-        if (r < r1)
+        if (r < R)
             take(*reinterpret_cast<const f32x4*>(y + base + (size_t)r * C), *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C));
     }
 #pragma unroll
