@@ -285,3 +285,62 @@ def test_dma_weight_gradient_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout):
         assert e_new < 1.02 * e_old + 1e-5 and e_new < 0.1, (e_new, e_old)
     finally:
         RF.set_conv_math(old)
+
+
+@pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [
+    (1, 16, 16, 160, 352, 512, False),    # 8 tiles -> 8 parts of two 32-channel chunks; part 2 straddles the two sources
+    (4, 16, 16, 1024, 0, 1024, False),    # the Conv5 layer of a batch-2 eval call: 64 tiles -> 4 parts
+    (2, 32, 32, 1024, 0, 512, True),      # nearest x2 in the gather (Up5 of that call at batch 1): 64 tiles -> 4 parts
+    (1, 32, 64, 128, 128, 128, False),    # 16 tiles, 8 chunks -> 4 parts of two chunks
+])
+def test_dma_patch_kernel_split_k(RF, N, H, W, c0, c1, cout, ups):
+    """rpnet_conv_desc.splitk_ws: eval-mode conv + folded BatchNorm + ReLU on a grid of a quarter of the CUs or fewer, K range
+    cut into parts (fp32 partial tiles + the reduce launch that does the epilogue) against one block per tile: equal to
+    fp32 summation round-off, max |output| and the fp64 reference as before."""
+    old, old_sk = RF.conv_math(), RF._EVAL_SPLITK
+    RF.set_conv_math("f16x2")
+    try:
+        layer = _mk_layer(c0 + c1, cout, 3, 51)
+        hs, ws = (H // 2, W // 2) if ups else (H, W)
+        a = rnd(52, N, c0, hs, ws)
+        b = rnd(53, N, c1, hs, ws) if c1 else None
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().eval()
+        xin = torch.cat([a, b], 1).double() if c1 else a.double()
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        with torch.no_grad():
+            ref = F.relu(b_ref(c_ref(xin)))
+        bound = max(a.abs().max().item(), b.abs().max().item() if c1 else 0.0)
+        sc = torch.tensor([2.0 ** (int(torch.ceil(torch.log2(torch.tensor(bound))).item()) - 15)], device=DEV)
+        outs, lent = {}, {}
+        for on in (False, True):
+            RF._EVAL_SPLITK = on
+            conv, bn = copy.deepcopy(layer[0]).to(DEV), copy.deepcopy(layer[1]).to(DEV).eval()
+            seen, orig = [], RF.call
+
+            def spy(name, *args):
+                if name == "rpnet_conv_fwd":
+                    seen.append(int(args[0]._obj.splitk_ws_bytes))
+                return orig(name, *args)
+
+            RF.call = spy
+            try:
+                with torch.no_grad():
+                    oa = RF.Operand(nhwc(a).to(DEV), scale=sc)
+                    ob = RF.Operand(nhwc(b).to(DEV), scale=sc) if c1 else None
+                    op = RF.conv_bn_relu_op(oa, conv, bn, RF.WeightCache(), False, x1=ob, upsample=ups, out_split=True)
+                    torch.cuda.synchronize()
+            finally:
+                RF.call = orig
+            outs[on], lent[on] = (op.x.clone(), op.p16.clone() if op.p16 is not None else None, op.scale.clone()), seen
+        assert lent[False] == [0] and lent[True][0] >= 2 * N * H * W * cout * 4, lent
+        z0, p0, s0 = outs[False]
+        z1, p1, s1 = outs[True]
+        assert not torch.equal(z0, z1) and rel_err(z1, z0) < 1e-5       # fp32 sums of up to 9216 products in another order
+        assert torch.equal(s0, s1)                          # the same power-of-two scale from the measured maximum
+        if p0 is not None:
+            assert rel_err(p1.float().sum(0), p0.float().sum(0)) < 1e-5
+        assert rel_err(nchw(z1), ref) < 1e-3
+    finally:
+        RF._EVAL_SPLITK = old_sk
+        RF.set_conv_math(old)
