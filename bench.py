@@ -654,6 +654,7 @@ def main():
     cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
     import rpnet_amd.functional as RF
     RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
+    RF.use_compute_stream(dev)       # the step's main chain on a high-priority stream (the side streams keep the default one)
     w = {"ways": args.ways, "shots": args.shots, "size": args.size, "iters": args.iters, "batch": args.batch,
          "conv_math": args.conv_math or RF.conv_math()}
     headline = (args.ways, args.shots, args.size, args.iters, args.batch) == (1, 1, 256, 5, 8) and w["conv_math"] == "f16x2"

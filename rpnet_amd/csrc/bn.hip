@@ -2,6 +2,8 @@
 // kernels: float4 accesses along C, fp64 accumulation for the statistics).
 // Replaces nn.BatchNorm2d + nn.ReLU(inplace) of net/modules.py:48-49,51-52,68-69 and
 // net/rp_net.py:52-53,57-58,67-68 and their autograd.
+#include <stdlib.h>
+
 #include "common.h"
 #include "split_bf16.h"
 
@@ -30,10 +32,71 @@ static BnGeom bn_geom(long R, int C) {
     return g;
 }
 
+// Cross-row reduction of a block's per-thread sums (thread t = row tr, float4 column tc; the owners are the threads of
+// row 0) in the order rr = 1, 2, ... .  WIN = 256: every thread's sums in LDS at once (16 - 20 KB per block).  WIN = 64:
+// through a ONE-wave window, wave after wave (4 - 5 KB): a block then fits into the 8 KB of LDS that a resident block of
+// the LDS-DMA convolution kernels leaves free on its CU (155 648 / 147 456 of 163 840 bytes), so the reduction pass of the
+// main stream co-runs with the weight-gradient launches of the side stream instead of waiting for whole CUs.  Same order
+// of additions either way: bit-identical partial sums.
+template <int WIN, bool MAXV>
+__device__ __forceinline__ void rows_reduce(double (&a)[4], double (&b)[4], float (&mx)[4], double* red, float* redm, const int t,
+                                            const int tc, const int tr, const int C4, const int rows_it) {
+    if constexpr (WIN == 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[t * 8 + k] = a[k]; red[t * 8 + 4 + k] = b[k];
+            if constexpr (MAXV) redm[t * 4 + k] = mx[k];
+        }
+        __syncthreads();
+        if (tr == 0)
+            for (int rr = 1; rr < rows_it; ++rr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] += red[(rr * C4 + tc) * 8 + k];
+                    b[k] += red[(rr * C4 + tc) * 8 + 4 + k];
+                    if constexpr (MAXV) mx[k] = fmaxf(mx[k], redm[(rr * C4 + tc) * 4 + k]);
+                }
+    } else {
+        const int wave = t >> 6, l = t & 63;
+        for (int w = 0; w * 64 < rows_it * C4; ++w) {       // block-uniform trip count
+            if (w) __syncthreads();                         // the readers of the previous window are done
+            if (wave == w) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    red[l * 8 + k] = a[k]; red[l * 8 + 4 + k] = b[k];
+                    if constexpr (MAXV) redm[l * 4 + k] = mx[k];
+                }
+            }
+            __syncthreads();
+            if (tr == 0) {
+                const int num = 64 * w - tc;                // first row of this window that belongs to column tc
+                int rr = num <= 0 ? 1 : (num + C4 - 1) / C4;
+                if (rr < 1) rr = 1;
+                for (; rr < rows_it && rr * C4 + tc < 64 * w + 64; ++rr) {
+                    const int i = rr * C4 + tc - 64 * w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[k] += red[i * 8 + k];
+                        b[k] += red[i * 8 + 4 + k];
+                        if constexpr (MAXV) mx[k] = fmaxf(mx[k], redm[i * 4 + k]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 64: the one-wave window (default); RPNET_BN_LDS=big: all sums at once (the A/B switch of the co-residency argument above)
+static int bn_lds_window() {
+    static const int w = [] { const char* e = getenv("RPNET_BN_LDS"); return e && e[0] == 'b' ? 256 : 64; }();
+    return w;
+}
+
 // partial[(g*nblk + blk)][C][2] doubles: sum, sumsq
+template <int WIN>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ y, double* __restrict__ partial,
                                                          long R, int C, BnGeom gm) {
-    __shared__ double red[256 * 8];
+    __shared__ double red[WIN * 8];
     const int t = threadIdx.x;
     const int tc = t % gm.C4, tr = t / gm.C4;
     const int g = blockIdx.y, blk = blockIdx.x;
@@ -48,13 +111,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
             for (int k = 0; k < 4; ++k) { s[k] += v[k]; q[k] += (double)v[k] * v[k]; }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s[k]; red[t * 8 + 4 + k] = q[k]; }
-    __syncthreads();
+    float nomax[4] = {0.f, 0.f, 0.f, 0.f};
+    rows_reduce<WIN, false>(s, q, nomax, red, nullptr, t, tc, tr, gm.C4, gm.rows_it);
     if (tr == 0) {
-        for (int rr = 1; rr < gm.rows_it; ++rr)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s[k] += red[(rr * gm.C4 + tc) * 8 + k]; q[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k]; }
         double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k * 2] = s[k]; o[k * 2 + 1] = q[k]; }
@@ -203,13 +262,14 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
 }
 
 // partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat; pmax[(g*nblk + blk)][C] = max |dz*m| (optional)
+template <int WIN>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const float* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        double* __restrict__ partial, float* __restrict__ pmax, long R, int C,
                                                        BnGeom gm) {
-    __shared__ double red[256 * 8];
-    __shared__ float redm[256 * 4];
+    __shared__ double red[WIN * 8];
+    __shared__ float redm[WIN * 4];
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
     const int t = threadIdx.x;
     const int tc = t % gm.C4, tr = t / gm.C4;
@@ -250,17 +310,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
         if (r < R)
             take(*reinterpret_cast<const f32x4*>(y + base + (size_t)r * C), *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C));
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; redm[t * 4 + k] = mx[k]; }
-    __syncthreads();
+    rows_reduce<WIN, true>(s1, s2, mx, red, redm, t, tc, tr, gm.C4, gm.rows_it);
     if (tr == 0) {
-        for (int rr = 1; rr < gm.rows_it; ++rr)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s1[k] += red[(rr * gm.C4 + tc) * 8 + k];
-                s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k];
-                mx[k] = fmaxf(mx[k], redm[(rr * gm.C4 + tc) * 4 + k]);
-            }
         double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k * 2] = s1[k]; o[k * 2 + 1] = s2[k]; }
@@ -465,13 +516,14 @@ __device__ __forceinline__ int pool_argmax(const float a0, const float a1, const
 
 // reduction pass over POOLED rows (Rp = R / 4 per group): dz is zero off the window maxima, so
 // s1 = sum dp [z_max > 0], s2 = sum dp [z_max > 0] xhat(argmax); same partial layout as bn_bwd_partial
+template <int WIN>
 __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restrict__ dp, const float* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             double* __restrict__ partial, float* __restrict__ pmax, long Rp, int C,
                                                             BnGeom gm, PoolGeom pg) {
-    __shared__ double red[256 * 8];
-    __shared__ float redm[256 * 4];
+    __shared__ double red[WIN * 8];
+    __shared__ float redm[WIN * 4];
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
     const int t = threadIdx.x;
     const int tc = t % gm.C4, tr = t / gm.C4;
@@ -506,17 +558,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; redm[t * 4 + k] = mx[k]; }
-    __syncthreads();
+    rows_reduce<WIN, true>(s1, s2, mx, red, redm, t, tc, tr, gm.C4, gm.rows_it);
     if (tr == 0) {
-        for (int rr = 1; rr < gm.rows_it; ++rr)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s1[k] += red[(rr * gm.C4 + tc) * 8 + k];
-                s2[k] += red[(rr * gm.C4 + tc) * 8 + 4 + k];
-                mx[k] = fmaxf(mx[k], redm[(rr * gm.C4 + tc) * 4 + k]);
-            }
         double* o = partial + ((size_t)(g * gm.nblk + blk) * C + tc * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k * 2] = s1[k]; o[k * 2 + 1] = s2[k]; }
@@ -635,7 +678,8 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     const long R = (long)(N / groups) * HW;
     const BnGeom gm = bn_geom(R, C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_partial, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
+    if (bn_lds_window() == 64) hipLaunchKernelGGL(bn_stats_partial<64>, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
+    else hipLaunchKernelGGL(bn_stats_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
     hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(256), 0, s, (const double*)workspace, gm.nblk, R, C,
                        groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
                        mean, invstd);
@@ -750,8 +794,12 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
         const long Rp = R / 4;
         const BnGeom gp = bn_geom(Rp, C);
-        hipLaunchKernelGGL(bn_bwd_partial_pool, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
-                           pmax, Rp, C, gp, pg);
+        if (bn_lds_window() == 64)
+            hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                               pmax, Rp, C, gp, pg);
+        else
+            hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                               pmax, Rp, C, gp, pg);
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * HW * C;
@@ -771,8 +819,12 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, given_partial, given_rows, R, C, groups, coef, dgamma, dbeta,
                            accumulate, f16 ? given_pmax : (const float*)nullptr, scale, bound);
     } else {
-        hipLaunchKernelGGL(bn_bwd_partial, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
-                           pmax, R, C, gm);
+        if (bn_lds_window() == 64)
+            hipLaunchKernelGGL(bn_bwd_partial<64>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                               pmax, R, C, gm);
+        else
+            hipLaunchKernelGGL(bn_bwd_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+                               pmax, R, C, gm);
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
     }

@@ -92,6 +92,29 @@ def _direct(p):
             and not getattr(p, "_rpnet_autograd_grad", False))
 
 
+def use_compute_stream(device):
+    """Make a HIGH-priority HIP stream the calling thread's current stream (the step's main chain: forward, the dgrad chain
+    and its BatchNorm / correlation passes; autograd runs every backward node on its forward's stream) and return it.  The
+    weight-gradient side streams keep the default priority (the device offers two levels, 0 and -1).  With equal
+    priorities the dispatcher alternates between the blocks of dgrad(L-1) and wgrad(L), the side stream never falls behind
+    and nothing MFMA-bound is left to run beside the HBM-bound passes of the main chain; with the main chain in front the
+    weight gradients queue up and fill the machine whenever the main chain is in a BatchNorm pass or a kernel's tail:
+    18.72 -> 18.53 ms per batch-8 step, two alternations on one box (tools/ab_overlap.py) — but launching every weight
+    gradient BEHIND its layer's dgrad (RPNET_WGRAD_DEFER, the default since) gets 18.37 ms on that box with or without the
+    priority, so this is OFF by default: RPNET_COMPUTE_PRIORITY=-1 switches it on, otherwise the caller's stream stays.
+    Drivers call this once (bench.py, train_rpnet.py); the modules never switch streams on their own."""
+    prio = int(os.environ.get("RPNET_COMPUTE_PRIORITY", "0"))
+    if prio == 0:
+        return torch.cuda.current_stream(device)
+    key = ("compute", torch.device(device).index)
+    s = _ASYNC["side"].get(key)
+    if s is None:
+        s = _ASYNC["side"][key] = torch.cuda.Stream(device=device, priority=prio)
+    torch.cuda.current_stream(device).synchronize()      # whatever the caller enqueued so far is done before the switch
+    torch.cuda.set_stream(s)
+    return s
+
+
 def _reduce_stream(device):
     key = ("reduce", device)
     s = _ASYNC["side"].get(key)
@@ -345,6 +368,8 @@ class BnRef:
 # the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
 # launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
 _BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
+# async weight gradients go out behind their layer's dgrad (ConvBnRelu.backward); 0: in front of it (A/B switch)
+_WGRAD_DEFER = os.environ.get("RPNET_WGRAD_DEFER", "1") == "1"
 # A/B switch: split K for the eval-mode 3x3 convolutions whose grid covers half of the CUs or fewer
 _EVAL_SPLITK = os.environ.get("RPNET_EVAL_SPLITK", "1") == "1"
 # A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
@@ -823,33 +848,43 @@ class ConvBnRelu(Function):
                 dyp = dy
                 d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample, wgrad=True)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
+            deferred = None
             if _direct(weight):
-                dev = y.device
-                side, main = _side_stream(dev), torch.cuda.current_stream(dev)
-                side.wait_stream(main)                       # dy, x are ready on the main stream
-                d.accumulate = 1
-                with torch.cuda.stream(side):
-                    ws2 = _ws(wb, y)
-                    if wsplit:   # GEMM on the side stream, its HBM-bound reduce on a third one under the next layer's GEMM
-                        _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
-                        red = _reduce_stream(dev)
-                        red.wait_stream(side)
-                        for tns in (ws2, ctx.sx, ctx.sx1, sdy):           # read by the reduce (partials, the operand scales)
-                            if tns is not None:
-                                tns.record_stream(red)
-                        with torch.cuda.stream(red):
-                            _cconv("rpnet_conv_wgrad", d, None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                def launch_async():
+                    dev = y.device
+                    side, main = _side_stream(dev), torch.cuda.current_stream(dev)
+                    side.wait_stream(main)                   # dy, x are ready on the main stream (deferred: and the dgrad is done)
+                    d.accumulate = 1
+                    with torch.cuda.stream(side):
+                        ws2 = _ws(wb, y)
+                        if wsplit:   # GEMM on the side stream, its HBM-bound reduce on a third one under the next layer's GEMM
+                            _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                            red = _reduce_stream(dev)
+                            red.wait_stream(side)
+                            for tns in (ws2, ctx.sx, ctx.sx1, sdy):           # read by the reduce (partials, the operand scales)
+                                if tns is not None:
+                                    tns.record_stream(red)
+                            with torch.cuda.stream(red):
+                                _cconv("rpnet_conv_wgrad", d, None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
+                                     ptr(ws2), wb)
+                        else:
+                            _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                                  ptr(ws2), wb)
-                    else:
-                        _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
-                             ptr(ws2), wb)
-                for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
-                    if tns is not None:
-                        tns.record_stream(side)
-                if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
-                    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
-                    _ASYNC["queued"] = True
-                _ASYNC["pending"].add(dev)
+                    for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
+                        if tns is not None:
+                            tns.record_stream(side)
+                    if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
+                        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+                        _ASYNC["queued"] = True
+                    _ASYNC["pending"].add(dev)
+                # RPNET_WGRAD_DEFER (default): the launch goes out right BEHIND this layer's dgrad and waits for it, so that it
+                # starts when the main chain enters the BatchNorm-backward passes of the layer below — every HBM-bound pass
+                # of the chain then has an MFMA-bound partner on the machine.  Launched in front of the dgrad (=0) the two
+                # GEMMs share the CUs, end together, and the passes behind them run alone.
+                if _WGRAD_DEFER:
+                    deferred = launch_async
+                else:
+                    launch_async()
                 dw = None
             else:
                 ws2 = _ws(wb, y)
@@ -885,6 +920,9 @@ class ConvBnRelu(Function):
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
                 _cconv("rpnet_conv_fwd", dd)
+                if deferred is not None:
+                    deferred()
+                    deferred = None
                 if need_s:   # d(x*f(s)) -> dx = g*f(s), ds = +-<g, x>
                     gx, dscale = torch.empty_like(g0), torch.empty_like(in_scale)
                     call("rpnet_rowdot_scale", ptr(g0), ptr(x0), ptr(in_scale), ptr(gx), ptr(dscale), N * H * W, c0,
@@ -896,6 +934,8 @@ class ConvBnRelu(Function):
                     g0 = h0
                 dx0 = g0 if need0 else None
                 dx1 = g1 if need1 else None
+            if deferred is not None:      # no input gradient wanted: nothing to wait for
+                deferred()
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = None if _direct(bias) else torch.zeros_like(gamma)
         return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None

@@ -70,6 +70,11 @@ CONV_CASES = [
     (3, 16, 16, 64, 128, 3),
     (1, 8, 8, 128, 256, 3),
     (2, 16, 16, 256, 64, 1),
+    # BatchNorm reduction passes through their one-wave LDS window (bn.hip rows_reduce): 48 float4 columns (256 threads are
+    # not a whole number of rows), 128 (the owners span two waves, one row per window), 256 (one row per block pass)
+    (2, 16, 16, 64, 192, 1),
+    (2, 16, 16, 64, 512, 1),
+    (1, 16, 16, 64, 1024, 1),
 ]
 
 

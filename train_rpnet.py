@@ -53,6 +53,10 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
     bucket = FlatGradBucket(net)
     import rpnet_amd.functional as RF
     RF.set_async_wgrad(True)             # weight gradients on a second stream, straight into the bucket
+    caller_stream = None
+    if torch.device(dev).type == "cuda":
+        caller_stream = torch.cuda.current_stream(dev)
+        RF.use_compute_stream(dev)       # the main chain in front of the weight-gradient side streams
     params = [p for _, p in bucket.params]
     opt = torch.optim.Adam(params, lr=lr if lr is not None else config["init_lr"], weight_decay=config["weight_decay"])
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=config["scheduler_step"])
@@ -89,7 +93,11 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
         if rank == 0 and log_every and (it + 1) % log_every == 0:
             print(f"step {it + 1:5d}  loss {float(history[-1]):.4f}  ({(time.time() - t0) / (it + 1) * 1e3:.0f} ms/step)", flush=True)
     pool.shutdown(wait=False)
-    return net, [float(v) for v in history]
+    history = [float(v) for v in history]
+    if caller_stream is not None:        # hand the thread back on the stream it came with
+        torch.cuda.current_stream(dev).synchronize()
+        torch.cuda.set_stream(caller_stream)
+    return net, history
 
 
 def main():
