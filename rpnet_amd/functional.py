@@ -30,7 +30,7 @@ BN_MOMENTUM = 0.1
 # into the parameter's existing .grad buffer (the flat bucket) instead of being returned to
 # autograd; the backward pass's HBM-bound kernels then run beside MFMA work.  The two streams are
 # joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
-_ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False}
+_ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": []}
 
 # Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
@@ -130,8 +130,26 @@ def _side_stream(device):
     return s
 
 
+def _defer_wgrad(launch):
+    """Queue an async weight-gradient launch (ConvBnRelu.backward) for release behind a later dgrad; the end of the backward
+    pass (engine callback) and every bucket operation flush the queue through join_side_streams."""
+    _ASYNC["fifo"].append(launch)
+    if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        _ASYNC["queued"] = True
+
+
+def _release_wgrads(keep):
+    """Launch the queued weight gradients, oldest first, down to the `keep` newest: each launch waits for everything the
+    main stream holds at this moment (the dgrad just enqueued)."""
+    q = _ASYNC["fifo"]
+    while len(q) > keep:
+        q.pop(0)()
+
+
 def join_side_streams():
-    """Make the current stream wait for every async weight-gradient launch issued so far."""
+    """Launch what is still queued, then make the current stream wait for every async weight-gradient launch issued so far."""
+    _release_wgrads(0)
     for dev in list(_ASYNC["pending"]):
         torch.cuda.current_stream(dev).wait_stream(_ASYNC["side"][dev])
         red = _ASYNC["side"].get(("reduce", dev))
@@ -144,7 +162,7 @@ def join_side_streams():
 def reset_async():
     """Start of a forward pass / of a gradient-bucket operation: join whatever a previous backward left on the side
     streams (a backward that raised never ran its engine callback) and allow the next backward to queue its own join."""
-    if _ASYNC["pending"]:
+    if _ASYNC["pending"] or _ASYNC["fifo"]:
         join_side_streams()
     _ASYNC["queued"] = False
 
@@ -368,8 +386,9 @@ class BnRef:
 # the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
 # launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
 _BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
-# async weight gradients go out behind their layer's dgrad (ConvBnRelu.backward); 0: in front of it (A/B switch)
-_WGRAD_DEFER = os.environ.get("RPNET_WGRAD_DEFER", "1") == "1"
+# async weight gradients go out behind a dgrad (ConvBnRelu.backward): 1 = their own layer's, d = the one d - 1 layers further
+# down the chain (a deeper backlog of MFMA-bound work beside the chain's HBM-bound passes); 0 = in front of their own
+_WGRAD_DEFER = int(os.environ.get("RPNET_WGRAD_DEFER", "1"))
 # A/B switch: split K for the eval-mode 3x3 convolutions whose grid covers half of the CUs or fewer
 _EVAL_SPLITK = os.environ.get("RPNET_EVAL_SPLITK", "1") == "1"
 # A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
@@ -877,12 +896,13 @@ class ConvBnRelu(Function):
                         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
                         _ASYNC["queued"] = True
                     _ASYNC["pending"].add(dev)
-                # RPNET_WGRAD_DEFER (default): the launch goes out right BEHIND this layer's dgrad and waits for it, so that it
+                # RPNET_WGRAD_DEFER >= 1 (default 1): the launch goes out right BEHIND this layer's dgrad and waits for it, so that it
                 # starts when the main chain enters the BatchNorm-backward passes of the layer below — every HBM-bound pass
                 # of the chain then has an MFMA-bound partner on the machine.  Launched in front of the dgrad (=0) the two
                 # GEMMs share the CUs, end together, and the passes behind them run alone.
                 if _WGRAD_DEFER:
-                    deferred = launch_async
+                    _defer_wgrad(launch_async)
+                    deferred = True
                 else:
                     launch_async()
                 dw = None
@@ -920,8 +940,8 @@ class ConvBnRelu(Function):
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
                 _cconv("rpnet_conv_fwd", dd)
-                if deferred is not None:
-                    deferred()
+                if deferred:
+                    _release_wgrads(_WGRAD_DEFER - 1)
                     deferred = None
                 if need_s:   # d(x*f(s)) -> dx = g*f(s), ds = +-<g, x>
                     gx, dscale = torch.empty_like(g0), torch.empty_like(in_scale)
@@ -934,8 +954,8 @@ class ConvBnRelu(Function):
                     g0 = h0
                 dx0 = g0 if need0 else None
                 dx1 = g1 if need1 else None
-            if deferred is not None:      # no input gradient wanted: nothing to wait for
-                deferred()
+            if deferred:                  # no input gradient wanted: no dgrad to wait for
+                _release_wgrads(_WGRAD_DEFER - 1)
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
         db = None if _direct(bias) else torch.zeros_like(gamma)
         return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None

@@ -57,3 +57,15 @@ for si in range(max(0, len(starts) - 4), len(starts) - 1):       # the last full
           file=out)
     for n, v in att.most_common(14):
         print(f"    {v / 1e6:7.3f} ms  {n}", file=out)
+    if si == len(starts) - 3:       # one step in detail: the longest MFMA-idle gaps, what ran in them and the GEMM in front
+        big = sorted(((b - a, a, b) for a, b in gaps if b > a), reverse=True)[:28]
+        for ln, a, b in sorted(big, key=lambda g: g[1]):
+            inside = [short(n) for n, s_, e_ in seg if e_ > a and s_ < b and not GEMM.search(n)]
+            before = next((short(n) for n, s_, e_ in reversed(seg) if GEMM.search(n) and e_ <= a + 1), "-")
+            cnt = collections.Counter(inside)
+            print(f"    gap at {(a - t0) / 1e6:7.3f} ms, {ln / 1e3:6.1f} us ({'bwd' if a >= tb else 'fwd'}) after {before[:40]}: "
+                  + ", ".join(f"{k} x{v}" if v > 1 else k for k, v in cnt.most_common(6)), file=out)
+            if ln > 400e3:          # a long one: every kernel in it, in order (start offset inside the gap, duration)
+                for n, s_, e_ in seg:
+                    if e_ > a and s_ < b and not GEMM.search(n):
+                        print(f"        +{(s_ - a) / 1e3:7.1f} us  {(e_ - s_) / 1e3:6.1f} us  {short(n)[:90]}", file=out)
