@@ -96,13 +96,12 @@ def make_inputs(seed, B, size, dev, n_shots=1, n_ways=1):
 def step(net, bucket, inp, scaler, exposed=None):
     """exposed (N > 1): list that receives a (start, end) HIP-event pair around the part of the gradient exchange that is
     NOT hidden under backward — from the end of backward on the compute stream to the moment the averaged bucket is ready"""
-    from rpnet_amd.functional import dice_ce
+    from rpnet_amd.functional import dice_ce_sum
     si, fg, bg, qi, ql, appr = inp
     bucket.zero()
     out = net(si, fg, bg, qi, appr_query_labels=appr)
-    loss = dice_ce(out["output"], ql)
-    for v in out["refinement"].values():
-        loss = loss + dice_ce(v, ql)
+    # dice_ce of the final output and of every refinement iteration's output, summed (one multi-tensor launch pair)
+    loss = dice_ce_sum([out["output"], *out["refinement"].values()], ql)
     loss = loss + scaler * out["align_loss"]
     loss.backward()
     if exposed is not None:

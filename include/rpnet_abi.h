@@ -414,6 +414,16 @@ int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, float* loss, f
 int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gscale,
                       float* dlogits, int B, int K, int H, int W, int with_dice, int ignore_index, int per_sample,
                       const float* sample_weight, int accumulate, rpnet_stream_t stream);
+/* The training objective sums dice_ce over the final output and every refinement iteration's output against the SAME
+ * labels (the reference ships no training loop; train_rpnet.py / bench.py do what its paper describes): n <= 16 logit
+ * tensors of one shape in two launches instead of 2 n, and one backward launch instead of n.  `logits` / `dlogits` are
+ * HOST arrays of n device pointers.  loss: n + 1 floats — loss[i] = dice_ce(logits[i], labels) (bit-identical to
+ * rpnet_dice_ce_fwd), loss[n] = their sum; stats: n * (B+1)*(2K+2) floats; workspace: n * rpnet_loss_workspace_bytes.
+ * backward: dlogits[i] = gscale[0] * d loss[i] / d logits[i] (gscale = the gradient arriving at the sum). */
+int rpnet_dice_ce_multi_fwd(const float* const* logits, int n, const int64_t* labels, float* loss, float* stats, int B,
+                            int K, int H, int W, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_dice_ce_multi_bwd(const float* const* logits, float* const* dlogits, int n, const int64_t* labels,
+                            const float* stats, const float* gscale, int B, int K, int H, int W, rpnet_stream_t stream);
 
 /* alignLoss pieces: arg-max class masks of the low-res prediction with their pixel
  * counts (net/rp_net.py:412-417) — masks [B][K][hw] (0/1), counts [B][K]; and the support

@@ -8,12 +8,16 @@ namespace rpnet {
 constexpr int kLossBlocks = 64;  // partial blocks per sample
 constexpr int kMaxCls = 4;
 
-// partial[b][blk][2K+2] doubles: inter_k, card_k, ce_sum, count
-__global__ __launch_bounds__(256) void dice_ce_partial(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+constexpr int kMaxLogitSets = 16;   // logit tensors per multi-tensor launch (rpnet_dice_ce_multi_*)
+struct LogitSet { const float* p[kMaxLogitSets]; };
+struct GradSet { float* p[kMaxLogitSets]; };
+
+// partial[z][b][blk][2K+2] doubles: inter_k, card_k, ce_sum, count (z = blockIdx.z: which logit tensor of the set)
+__global__ __launch_bounds__(256) void dice_ce_partial(const LogitSet set, const int64_t* __restrict__ labels,
                                                         double* __restrict__ partial, int K, int HW, int ignore_index) {
     __shared__ double sm4[4];
     const int b = blockIdx.y;
-    const float* lg = logits + (size_t)b * K * HW;
+    const float* lg = set.p[blockIdx.z] + (size_t)b * K * HW;
     const int64_t* lb = labels + (size_t)b * HW;
     double inter[kMaxCls] = {0, 0, 0, 0}, card[kMaxCls] = {0, 0, 0, 0}, ce = 0, cnt = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void dice_ce_partial(const float* __restrict__
             if (lab >= 0 && lab < K) ce += (double)((mx + logf(den)) - lg[(size_t)lab * HW + i]);  // -log_softmax[label]
         }
     }
-    double* o = partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * K + 2);
+    double* o = partial + (((size_t)blockIdx.z * gridDim.y + b) * gridDim.x + blockIdx.x) * (2 * K + 2);
     for (int k = 0; k < K; ++k) {
         const double a = block_sum256(inter[k], sm4), c = block_sum256(card[k], sm4);
         if (threadIdx.x == 0) { o[k] = a; o[K + k] = c; }
@@ -46,50 +50,63 @@ __global__ __launch_bounds__(256) void dice_ce_partial(const float* __restrict__
     if (threadIdx.x == 0) { o[2 * K] = a; o[2 * K + 1] = c; }
 }
 
-// stats: [B][2K+2] per sample, then [2K+2] totals.  loss[0] = dice + ce.
+// stats: per logit tensor z: [B][2K+2] per sample, then [2K+2] totals.  loss[z] = dice + ce; total[0] (optional) = their sum.
 // One 1024-thread block: each of its 16 waves sums the per-block partials of one (sample, slot) pair at a
-// time; thread 0 then does the O(B*K) scalar combine.
+// time; thread 0 then does the O(B*K) scalar combine.  The n tensors of a set one after the other.
 __global__ __launch_bounds__(1024) void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats,
                                                       float* __restrict__ loss, int B, int K, int nblk, int with_dice,
-                                                      int per_sample, const float* __restrict__ sample_weight) {
+                                                      int per_sample, const float* __restrict__ sample_weight, int n,
+                                                      float* __restrict__ total) {
     extern __shared__ double sums[];  // [B][S]
     const int S = 2 * K + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nwv = blockDim.x >> 6;
-    for (int idx = wv; idx < B * S; idx += nwv) {
-        const int b = idx / S, j = idx - b * S;
-        double v = 0;
-        for (int blk = lane; blk < nblk; blk += 64) v += partial[((size_t)b * nblk + blk) * S + j];
-        v = wave_sum(v);
-        if (lane == 0) sums[idx] = v;
+    double all = 0;
+    for (int z = 0; z < n; ++z) {
+        const double* pz = partial + (size_t)z * B * nblk * S;
+        float* sz = stats + (size_t)z * (B + 1) * S;
+        for (int idx = wv; idx < B * S; idx += nwv) {
+            const int b = idx / S, j = idx - b * S;
+            double v = 0;
+            for (int blk = lane; blk < nblk; blk += 64) v += pz[((size_t)b * nblk + blk) * S + j];
+            v = wave_sum(v);
+            if (lane == 0) sums[idx] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot[2 * kMaxCls + 2];
+            for (int j = 0; j < S; ++j) tot[j] = 0;
+            double ce_ps = 0;
+            for (int b = 0; b < B; ++b) {
+                for (int j = 0; j < S; ++j) { sz[b * S + j] = (float)sums[b * S + j]; tot[j] += sums[b * S + j]; }
+                const double wgt = sample_weight ? (double)sample_weight[b] : 1.0;
+                if (wgt != 0.0) ce_ps += wgt * sums[b * S + 2 * K] / sums[b * S + 2 * K + 1];
+            }
+            for (int j = 0; j < S; ++j) sz[B * S + j] = (float)tot[j];
+            double l = per_sample ? ce_ps / (double)B : tot[2 * K] / tot[2 * K + 1];
+            if (with_dice) {
+                double d = 0;
+                for (int k = 0; k < K; ++k) d += 2.0 * tot[k] / (tot[K + k] + 1e-7);
+                l += 1.0 - d / (double)K;
+            }
+            loss[z] = (float)l;
+            all += (double)(float)l;       // the sum of the fp32 losses, as a chain of fp32 tensors' values would be added in fp64
+        }
+        __syncthreads();                   // `sums` is rewritten by the next tensor
     }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double tot[2 * kMaxCls + 2];
-    for (int j = 0; j < S; ++j) tot[j] = 0;
-    double ce_ps = 0;
-    for (int b = 0; b < B; ++b) {
-        for (int j = 0; j < S; ++j) { stats[b * S + j] = (float)sums[b * S + j]; tot[j] += sums[b * S + j]; }
-        const double wgt = sample_weight ? (double)sample_weight[b] : 1.0;
-        if (wgt != 0.0) ce_ps += wgt * sums[b * S + 2 * K] / sums[b * S + 2 * K + 1];
-    }
-    for (int j = 0; j < S; ++j) stats[B * S + j] = (float)tot[j];
-    double l = per_sample ? ce_ps / (double)B : tot[2 * K] / tot[2 * K + 1];
-    if (with_dice) {
-        double d = 0;
-        for (int k = 0; k < K; ++k) d += 2.0 * tot[k] / (tot[K + k] + 1e-7);
-        l += 1.0 - d / (double)K;
-    }
-    loss[0] = (float)l;
+    if (threadIdx.x == 0 && total) total[0] = (float)all;
 }
 
-__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ stats, const float* __restrict__ gscale,
-                                                           float* __restrict__ dlogits, int B, int K, int HW, int with_dice,
+__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const LogitSet set, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ stats_all, const float* __restrict__ gscale,
+                                                           const GradSet gset, int B, int K, int HW, int with_dice,
                                                            int ignore_index, int per_sample,
                                                            const float* __restrict__ sample_weight, int accumulate) {
     const int b = blockIdx.y;
     const int S = 2 * K + 2;
+    const float* logits = set.p[blockIdx.z];
+    float* dlogits = gset.p[blockIdx.z];
+    const float* stats = stats_all + (size_t)blockIdx.z * (B + 1) * S;
     const float gs = gscale ? gscale[0] : 1.f;
     float ce_coef;
     if (per_sample) {
@@ -179,10 +196,31 @@ extern "C" int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, flo
     RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "dice_ce_fwd: K=%d", K);
     RPNET_REQUIRE(workspace_bytes >= rpnet_loss_workspace_bytes(B, K, H, W), RPNET_ERR_WORKSPACE, "dice_ce_fwd: workspace");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B), dim3(256), 0, s, logits, labels, (double*)workspace, K, H * W, ignore_index);
+    LogitSet set{};
+    set.p[0] = logits;
+    hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B), dim3(256), 0, s, set, labels, (double*)workspace, K, H * W, ignore_index);
     hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
-                       per_sample, sample_weight);
+                       per_sample, sample_weight, 1, (float*)nullptr);
     return check_launch("dice_ce_fwd");
+}
+
+extern "C" int rpnet_dice_ce_multi_fwd(const float* const* logits, int n, const int64_t* labels, float* loss, float* stats, int B,
+                                       int K, int H, int W, void* workspace, size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(logits && labels && loss && stats && workspace, RPNET_ERR_ARG, "dice_ce_multi_fwd: null pointer");
+    RPNET_REQUIRE(n >= 1 && n <= kMaxLogitSets, RPNET_ERR_ARG, "dice_ce_multi_fwd: %d logit tensors (1..%d per call)", n, kMaxLogitSets);
+    RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "dice_ce_multi_fwd: K=%d", K);
+    RPNET_REQUIRE(workspace_bytes >= (size_t)n * rpnet_loss_workspace_bytes(B, K, H, W), RPNET_ERR_WORKSPACE, "dice_ce_multi_fwd: workspace");
+    LogitSet set{};
+    for (int i = 0; i < n; ++i) {
+        RPNET_REQUIRE(logits[i], RPNET_ERR_ARG, "dice_ce_multi_fwd: null logit tensor %d", i);
+        set.p[i] = logits[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B, n), dim3(256), 0, s, set, labels, (double*)workspace, K, H * W, -1);
+    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, 1,
+                       0, (const float*)nullptr, n, loss + n);
+    return check_launch("dice_ce_multi_fwd");
 }
 
 extern "C" int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gscale,
@@ -192,9 +230,32 @@ extern "C" int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, con
     RPNET_REQUIRE(logits && labels && stats && dlogits, RPNET_ERR_ARG, "dice_ce_bwd: null pointer");
     RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "dice_ce_bwd: K=%d", K);
     int nb = cdiv(H * W, 256); if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, logits, labels, stats, gscale, dlogits,
+    LogitSet set{};
+    GradSet gset{};
+    set.p[0] = logits;
+    gset.p[0] = dlogits;
+    hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, set, labels, stats, gscale, gset,
                        B, K, H * W, with_dice, ignore_index, per_sample, sample_weight, accumulate);
     return check_launch("dice_ce_bwd");
+}
+
+extern "C" int rpnet_dice_ce_multi_bwd(const float* const* logits, float* const* dlogits, int n, const int64_t* labels,
+                                       const float* stats, const float* gscale, int B, int K, int H, int W, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(logits && dlogits && labels && stats, RPNET_ERR_ARG, "dice_ce_multi_bwd: null pointer");
+    RPNET_REQUIRE(n >= 1 && n <= kMaxLogitSets, RPNET_ERR_ARG, "dice_ce_multi_bwd: %d logit tensors (1..%d per call)", n, kMaxLogitSets);
+    RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "dice_ce_multi_bwd: K=%d", K);
+    LogitSet set{};
+    GradSet gset{};
+    for (int i = 0; i < n; ++i) {
+        RPNET_REQUIRE(logits[i] && dlogits[i], RPNET_ERR_ARG, "dice_ce_multi_bwd: null tensor %d", i);
+        set.p[i] = logits[i];
+        gset.p[i] = dlogits[i];
+    }
+    int nb = cdiv(H * W, 256); if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B, n), dim3(256), 0, (hipStream_t)stream, set, labels, stats, gscale, gset,
+                       B, K, H * W, 1, -1, 0, (const float*)nullptr, 0);
+    return check_launch("dice_ce_multi_bwd");
 }
 
 extern "C" int rpnet_argmax_masks(const float* pred, float* masks, float* counts, int B, int K, int hw, rpnet_stream_t stream) {

@@ -99,6 +99,8 @@ _SIGS = {
     "rpnet_loss_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_dice_ce_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
     "rpnet_dice_ce_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "rpnet_dice_ce_multi_fwd": (ci, [C.POINTER(vp), ci, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_dice_ce_multi_bwd": (ci, [C.POINTER(vp), C.POINTER(vp), ci, vp, vp, vp, ci, ci, ci, ci, vp]),
     "rpnet_argmax_masks": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
 }

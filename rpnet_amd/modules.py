@@ -32,6 +32,11 @@ _F16_MIN_PIXELS_EVAL = int(os.environ.get("RPNET_F16_MIN_PIXELS_EVAL", "524288")
 # eval-mode CRE: w_q on a second HIP stream beside w_k while a call has at most this many feature pixels (B h w)
 _CRE_STREAMS = os.environ.get("RPNET_CRE_STREAMS", "1") != "0"
 _CRE_STREAMS_MAX_PIXELS = int(os.environ.get("RPNET_CRE_STREAMS_MAX_PIXELS", "16384"))
+# train-mode CRE: w_q (convolution, BatchNorm + ReLU and, through autograd, their backward) on its own HIP stream beside
+# w_k: each branch's HBM-bound BatchNorm passes run beside the other branch's convolution — 18.11 -> 17.87 ms per batch-8
+# step, configs[4] 33.65 -> 33.34 ms (two alternations on one box, tools/ab_overlap.py); same kernels, same bits.
+# RPNET_CRE_STREAMS_TRAIN=0: both branches on the caller's stream (A/B switch)
+_CRE_STREAMS_TRAIN = os.environ.get("RPNET_CRE_STREAMS_TRAIN", "1") == "1"
 
 
 def _to_nhwc(x):
@@ -330,11 +335,18 @@ class ContextCorrelationEncoder(nn.Module):
         # inference on a few slices (test_rpnet.py: 2 per call): either convolution is 256 four-wave blocks of a machine
         # that holds 512 — the two are independent, so w_q runs on the side stream beside w_k (one block of each per CU)
         pixels = fk.shape[0] * fk.shape[1] * fk.shape[2]
-        if _CRE_STREAMS and not t and not torch.is_grad_enabled() and fk.is_cuda and pixels <= _CRE_STREAMS_MAX_PIXELS:
-            main, side = torch.cuda.current_stream(fk.device), RF._side_stream(fk.device)
+        two_eval = _CRE_STREAMS and not t and not torch.is_grad_enabled() and fk.is_cuda and pixels <= _CRE_STREAMS_MAX_PIXELS
+        two_train = _CRE_STREAMS_TRAIN and t and fk.is_cuda
+        if two_eval or two_train:
+            main = torch.cuda.current_stream(fk.device)
+            side = RF._cre_stream(fk.device) if two_train else RF._side_stream(fk.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fm2 = w_q()
+            if two_train:        # read by the side stream (the caching allocator must not hand their blocks out before it is done)
+                for tns in (fq, mask, fts_scale):
+                    if tns is not None:
+                        tns.record_stream(side)
             fm1 = w_k()
             main.wait_stream(side)
             for tns in (fm2.x, fm2.p16, fm2.pbf, fm2.scale):     # allocated on the side stream, read on the main one from here on

@@ -546,6 +546,28 @@ def test_dice_ce_golden(RF, golden):
     assert rel_err(lg.grad, 1.5 * g["dce_grad"]) < 1e-4
 
 
+@pytest.mark.parametrize("n,B,K,H,W", [(7, 3, 2, 24, 20), (12, 2, 3, 16, 16), (18, 1, 2, 8, 8)])
+def test_dice_ce_sum_matches_separate_calls(RF, n, B, K, H, W):
+    """the multi-tensor launch pair (rpnet_dice_ce_multi_*: the training objective's sum over the final and every refinement
+    output) against n separate dice_ce calls: every term's statistics and every gradient bit-identical, the sum to fp32
+    rounding; 18 tensors = two chunks of the 16-pointer kernel argument"""
+    lab = torch.from_numpy(np.random.default_rng(5).integers(0, K, (B, H, W))).to(DEV)
+    lgs = [rnd(40 + i, B, K, H, W).to(DEV) for i in range(n)]
+    a = [t.clone().requires_grad_(True) for t in lgs]
+    b = [t.clone().requires_grad_(True) for t in lgs]
+    sep = [RF.dice_ce(t, lab) for t in a]
+    ref = sep[0]
+    for v in sep[1:]:
+        ref = ref + v
+    (ref * 0.75).backward()
+    tot = RF.dice_ce_sum(b, lab)
+    (tot * 0.75).backward()
+    assert abs(float(tot) - float(ref)) <= 4e-7 * abs(float(ref)) * n
+    assert abs(float(tot) - sum(float(v) for v in sep)) <= 2e-7 * abs(float(ref))
+    for x, y in zip(a, b):
+        assert torch.equal(x.grad, y.grad)
+
+
 def test_align_loss(golden):
     """alignLoss against the reference's value and gradients (tests/golden/ops.npz) incl. the skip-way case."""
     from rpnet_amd.modules import RP_Net

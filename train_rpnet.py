@@ -23,16 +23,21 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from net.model import model_factory  # noqa: E402
-from rpnet_amd.functional import dice_ce  # noqa: E402
+from rpnet_amd.functional import dice_ce, dice_ce_sum  # noqa: E402
 from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters  # noqa: E402
 from rpnet_amd.utils.synth import make_episode  # noqa: E402
 from utils.util import load_yaml  # noqa: E402
 
 
 def objective(out, labels, scaler):
-    loss = dice_ce(out["output"], labels)
-    for v in out["refinement"].values():
-        loss = loss + dice_ce(v, labels)
+    # dice_ce of the final output and of every refinement iteration's output, summed (on the GPU: one multi-tensor launch pair)
+    terms = [out["output"], *out["refinement"].values()]
+    if terms[0].is_cuda:
+        loss = dice_ce_sum(terms, labels)
+    else:
+        loss = dice_ce(terms[0], labels)
+        for v in terms[1:]:
+            loss = loss + dice_ce(v, labels)
     return loss + scaler * out["align_loss"]
 
 
