@@ -138,8 +138,10 @@ def profile_step(net, bucket, inp, scaler):
     hip.call = timed
     import rpnet_amd.functional as RF
     RF.call = timed
-    was_async = RF._ASYNC["on"]
+    import rpnet_amd.modules as RM
+    was_async, was_cre = RF._ASYNC["on"], RM._CRE_STREAMS_TRAIN
     RF.set_async_wgrad(False)   # per-kernel durations need each launch to own the GPU: streams serialised here
+    RM._CRE_STREAMS_TRAIN = False   # (the CRE's second branch too)
     try:
         step(net, bucket, inp, scaler)
         torch.cuda.synchronize()
@@ -147,6 +149,7 @@ def profile_step(net, bucket, inp, scaler):
         hip.call = orig
         RF.call = orig
         RF.set_async_wgrad(was_async)
+        RM._CRE_STREAMS_TRAIN = was_cre
     agg = {}
     for name, flops, nbytes, a, b in records:
         e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])

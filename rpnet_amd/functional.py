@@ -164,6 +164,9 @@ def join_side_streams():
         red = _ASYNC["side"].get(("reduce", dev))
         if red is not None:
             torch.cuda.current_stream(dev).wait_stream(red)
+        cre = _ASYNC["side"].get(("cre", dev))      # the CRE's second branch writes its BatchNorm parameter gradients there
+        if cre is not None:
+            torch.cuda.current_stream(dev).wait_stream(cre)
     _ASYNC["pending"].clear()
     _ASYNC["queued"] = False
 

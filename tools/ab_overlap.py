@@ -4,6 +4,8 @@
   RPNET_COMPUTE_PRIORITY=0  the step's main chain on the caller's (default-priority) stream instead of the high-priority
                           one of RF.use_compute_stream; the weight-gradient side streams are at the default priority either way
   RPNET_WGRAD_DEFER=0     async weight gradients launched in front of their layer's dgrad instead of behind it
+  RPNET_CRE_STREAMS_TRAIN=0  both CRE branches (w_k, w_q) on one stream
+  RPNET_DICE_MULTI=0      one dice_ce launch pair per loss term instead of the multi-tensor pair
   AB_CONFIG=c5            BASELINE configs[4] (2-way 512^2 T=10 batch 4, one fp16 plane) instead of configs[1]
 Prints one line: variant, ms per step (wall clock around `steps` steps, synchronised on both sides), pairs/s.
 Usage: python tools/ab_overlap.py [steps]"""
@@ -39,6 +41,7 @@ if True:
         ms = 1e3 * (time.perf_counter() - t0) / steps
         best = ms if best is None else min(best, ms)
 batch = 4 if c5 else 8
-print(f"{'c5' if c5 else 'c1'} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
-      f"wgrad_defer={os.environ.get('RPNET_WGRAD_DEFER', '1')} async={os.environ.get('RPNET_ASYNC_WGRAD', '1')}: "
+print(f"{'configs[4]' if c5 else 'configs[1]'} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
+      f"wgrad_defer={os.environ.get('RPNET_WGRAD_DEFER', '1')} cre_streams_train={os.environ.get('RPNET_CRE_STREAMS_TRAIN', '1')} "
+      f"dice_multi={os.environ.get('RPNET_DICE_MULTI', '1')} async={os.environ.get('RPNET_ASYNC_WGRAD', '1')}: "
       f"best of 3 x {steps} steps {best:.3f} ms/step = {batch / best * 1e3:.1f} pairs/s", flush=True)
