@@ -123,6 +123,36 @@ def _reduce_stream(device):
     return s
 
 
+# Two chains of one forward / backward pass on two streams that share BatchNorm modules (the support and the query call of
+# the encoder: RP_Net.forward): every launch that updates a module's running statistics (forward) or accumulates into its
+# parameter gradients (backward) waits for the previous such launch of the SAME module on the other stream — the order of
+# the reference's two calls is kept, no two launches write one buffer at a time.  Keyed by the parameter's address.
+_ORDER = {"on": False, "ev": {}}
+
+
+def order_begin(on):
+    """RP_Net.forward: (re)start the per-module ordering for this pass"""
+    _ORDER["on"] = bool(on)
+    _ORDER["ev"].clear()
+
+
+def _order_wait(key):
+    if _ORDER["on"]:
+        rec = _ORDER["ev"].get(key)
+        if rec is not None:
+            cur = torch.cuda.current_stream()
+            if rec[1] != cur.cuda_stream:
+                cur.wait_event(rec[0])
+
+
+def _order_done(key):
+    if _ORDER["on"]:
+        cur = torch.cuda.current_stream()
+        e = torch.cuda.Event()
+        e.record(cur)
+        _ORDER["ev"][key] = (e, cur.cuda_stream)
+
+
 def _cre_stream(device):
     """the stream of the CRE's second branch (modules.ContextCorrelationEncoder.forward_masked, train mode)"""
     key = ("cre", device)
@@ -756,6 +786,7 @@ class ConvBnRelu(Function):
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
             _cconv("rpnet_conv_fwd", d)
+        _order_wait(gamma.data_ptr())      # the running statistics: after the other chain's update of this module
         if fused:
             call("rpnet_bn_stats_from_partial", ptr(part), fused, N, H * W, cout, groups, ptr(gamma), ptr(beta),
                  ptr(running_mean), ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]),
@@ -766,6 +797,7 @@ class ConvBnRelu(Function):
             call("rpnet_bn_stats", ptr(y), N, H * W, cout, groups, ptr(gamma), ptr(beta), ptr(running_mean),
                  ptr(running_var), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
                  ptr(ws), wsb)
+        _order_done(gamma.data_ptr())
         # the output also as the operand planes of its consumer: out_split True = a 3x3 convolution reads it as is (fp16
         # planes with the tensor scale in f16x2 mode), "corr" = the local correlation (bf16 planes), "scale" = no planes
         # but the fp16 tensor scale (pooled / concatenated / masked 3x3 consumers split the fp32 tensor), False = none
@@ -851,10 +883,14 @@ class ConvBnRelu(Function):
         if ctx.bn_ref is not None:
             ctx.bn_ref.fused = None
         ARITH[("bn_bwd", "reduction in the consumer's dgrad epilogue" if gp is not None else "own reduction pass")] += 1
+        if direct:
+            _order_wait(gamma.data_ptr())  # gamma.grad / beta.grad: after the other chain's accumulation into them
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
              ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(gp), ptr(gm_), grows,
              W if ctx.pool else 0, ptr(ws), wsb)
+        if direct:
+            _order_done(gamma.data_ptr())
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:

@@ -37,6 +37,13 @@ _CRE_STREAMS_MAX_PIXELS = int(os.environ.get("RPNET_CRE_STREAMS_MAX_PIXELS", "16
 # step, configs[4] 33.65 -> 33.34 ms (two alternations on one box, tools/ab_overlap.py); same kernels, same bits.
 # RPNET_CRE_STREAMS_TRAIN=0: both branches on the caller's stream (A/B switch)
 _CRE_STREAMS_TRAIN = os.environ.get("RPNET_CRE_STREAMS_TRAIN", "1") == "1"
+# train-mode encoder: the support and the query call as two chains on two streams: 0 = never, 1 (default) = when they are
+# separate calls anyway (multi-shot / multi-way) AND of comparable length (support images <= 2 x query images), 2 = always,
+# also for 1-way 1-shot (two half-size launches per layer instead of one).  Measured, two alternations on one box
+# (tools/ab_overlap.py): configs[4] (2-way 512^2: 8 + 4 images) 33.81 -> 33.02 ms; configs[2] (5-shot: 80 + 16 images, the
+# query chain ends after a fifth of the support chain) 84.3 -> 85.0 ms; configs[1] in two half-size launches per layer
+# 17.95 -> 18.54 ms (the 16^2 / 32^2 levels no longer fill the machine) — hence the default
+_ENC_STREAMS = int(os.environ.get("RPNET_ENC_STREAMS", "1"))
 
 
 def _to_nhwc(x):
@@ -455,12 +462,32 @@ class RP_Net(nn.Module):
         if enc_mask is not None and ns != B:
             raise NotImplementedError("mask_feature_map with more than one support image per episode: the reference "
                                       "concatenates B masks onto Wa*Sh*B images (net/unet.py:438) and fails")
-        if ns == B:
+        # training: the support call and the query call of the encoder (two calls in the reference, net/rp_net.py:248,257) as
+        # two chains on two HIP streams — each chain's statistics-finalize and BatchNorm + ReLU passes run beside the other
+        # chain's convolution, in backward likewise; the launches that touch a BatchNorm module's running statistics or
+        # parameter gradients keep the order of the two calls (RF.order_begin).  Policy and measurements: _ENC_STREAMS
+        two_chains = (self.training and supp.is_cuda and enc_mask is None and
+                      (_ENC_STREAMS == 2 or (_ENC_STREAMS == 1 and ns != B and ns <= 2 * B)))
+        RF.order_begin(two_chains)
+        if ns == B and not two_chains:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2,
                                            mask=None if enc_mask is None else torch.cat([enc_mask, enc_mask], 0))
             s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it
             d4 = d4.x
             supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
+        elif two_chains:
+            main, side = torch.cuda.current_stream(supp.device), RF._cre_stream(supp.device)
+            qin = qry.reshape(B, H, W, 1)
+            side.wait_stream(main)
+            o_s = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
+            with torch.cuda.stream(side):
+                o_q = self.encoder.forward_nhwc(qin, cache)
+            qin.record_stream(side)
+            main.wait_stream(side)
+            for tns in (o_q.x, o_q.p16, o_q.pbf, o_q.scale):
+                if tns is not None:
+                    tns.record_stream(main)
+            (supp_d4, s_supp), (qry_d4, s_qry) = (o_s.x, o_s.scale), (o_q.x, o_q.scale)
         else:
             o_s = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
             o_q = self.encoder.forward_nhwc(qry.reshape(B, H, W, 1), cache)

@@ -499,6 +499,45 @@ def test_two_way_extension_vs_composed_oracle():
         assert (a - b).norm() < 5e-3 * b.norm(), n
 
 
+@pytest.mark.parametrize("async_wgrad", [False, True])
+def test_encoder_two_chains_match_one_stream(async_wgrad):
+    """2-way (support call: 2 B images, query call: B): the encoder's two calls as two chains on two HIP streams, their
+    BatchNorm modules' running statistics and parameter gradients ordered by events (RF.order_begin), against the same
+    step on one stream: same kernels in the same order per buffer -> logits, every gradient and every BatchNorm buffer
+    bit-identical; with and without the weight gradients on their side stream, two runs of the two-chain step"""
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    from rpnet_amd.parallel import FlatGradBucket
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(91, 4, 128, DEV, n_shots=1, n_ways=2)
+    was = RM._ENC_STREAMS
+    res = []
+    try:
+        for enc in (0, 1, 1):
+            RM._ENC_STREAMS = enc
+            net = build(cfg, True)
+            bucket = FlatGradBucket(net) if async_wgrad else None
+            RF.set_async_wgrad(async_wgrad)
+            if bucket is not None:
+                bucket.zero()
+            out = net(si, fg, bg, qi, appr_query_labels=appr)
+            total_loss(out, ql, 1.0).backward()
+            if bucket is not None:
+                bucket.allreduce()
+            torch.cuda.synchronize()
+            res.append((out["output"].detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                        {n: b.clone() for n, b in net.named_buffers()}))
+    finally:
+        RM._ENC_STREAMS = was
+        RF.set_async_wgrad(False)
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for n, g in res[0][1].items():
+            assert torch.equal(g, other[1][n]), n
+        for n, b in res[0][2].items():
+            assert torch.equal(b, other[2][n]), n
+
+
 def test_config3_full_size_properties():
     """BASELINE configs[2]: 1-way 5-shot, 256x256, T=5, batch 16 — full-size forward + backward through
     the multi-shot path: shapes, finiteness, BatchNorm update counts, prototype = mean over shots."""

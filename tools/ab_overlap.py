@@ -6,6 +6,9 @@
   RPNET_WGRAD_DEFER=0     async weight gradients launched in front of their layer's dgrad instead of behind it
   RPNET_CRE_STREAMS_TRAIN=0  both CRE branches (w_k, w_q) on one stream
   RPNET_DICE_MULTI=0      one dice_ce launch pair per loss term instead of the multi-tensor pair
+  RPNET_ENC_STREAMS=0|1|2 the encoder's support / query calls as two chains on two streams: never / when they are separate
+                          calls anyway (multi-shot, multi-way) / also for 1-way 1-shot
+  AB_CONFIG=c2            BASELINE configs[2] (5-shot, batch 16)
   AB_CONFIG=c5            BASELINE configs[4] (2-way 512^2 T=10 batch 4, one fp16 plane) instead of configs[1]
 Prints one line: variant, ms per step (wall clock around `steps` steps, synchronised on both sides), pairs/s.
 Usage: python tools/ab_overlap.py [steps]"""
@@ -20,6 +23,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda", 0)
 cfg = yaml.load(open(os.path.join(bench.ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
 c5 = os.environ.get("AB_CONFIG") == "c5"
+c2 = os.environ.get("AB_CONFIG") == "c2"        # BASELINE configs[2]: 5-shot, batch 16
 cfg["n_iter_refinement"] = 10 if c5 else 5
 RF.set_conv_math("f16" if c5 else "f16x2")
 RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")
@@ -28,7 +32,7 @@ prio = getattr(main, "priority", "?")
 if True:
     net = bench.build_model(cfg, dev)
     bucket = FlatGradBucket(net)
-    inp = bench.make_inputs(1234, 4 if c5 else 8, 512 if c5 else 256, dev, 1, 2 if c5 else 1)
+    inp = bench.make_inputs(1234, 4 if c5 else (16 if c2 else 8), 512 if c5 else 256, dev, 5 if c2 else 1, 2 if c5 else 1)
     for _ in range(3):
         bench.step(net, bucket, inp, cfg["align_loss_scaler"])
     best = None
@@ -40,8 +44,8 @@ if True:
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         best = ms if best is None else min(best, ms)
-batch = 4 if c5 else 8
-print(f"{'configs[4]' if c5 else 'configs[1]'} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
+batch = 4 if c5 else (16 if c2 else 8)
+print(f"{'configs[4]' if c5 else ('configs[2]' if c2 else 'configs[1]')} enc_streams={os.environ.get('RPNET_ENC_STREAMS', 'default')} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
       f"wgrad_defer={os.environ.get('RPNET_WGRAD_DEFER', '1')} cre_streams_train={os.environ.get('RPNET_CRE_STREAMS_TRAIN', '1')} "
       f"dice_multi={os.environ.get('RPNET_DICE_MULTI', '1')} async={os.environ.get('RPNET_ASYNC_WGRAD', '1')}: "
       f"best of 3 x {steps} steps {best:.3f} ms/step = {batch / best * 1e3:.1f} pairs/s", flush=True)
