@@ -139,9 +139,10 @@ def profile_step(net, bucket, inp, scaler):
     import rpnet_amd.functional as RF
     RF.call = timed
     import rpnet_amd.modules as RM
-    was_async, was_cre = RF._ASYNC["on"], RM._CRE_STREAMS_TRAIN
+    was_async, was_cre, was_enc = RF._ASYNC["on"], RM._CRE_STREAMS_TRAIN, RM._ENC_STREAMS
     RF.set_async_wgrad(False)   # per-kernel durations need each launch to own the GPU: streams serialised here
-    RM._CRE_STREAMS_TRAIN = False   # (the CRE's second branch too)
+    RM._CRE_STREAMS_TRAIN = False   # (the CRE's second branch and the encoder's second chain too)
+    RM._ENC_STREAMS = 0
     try:
         step(net, bucket, inp, scaler)
         torch.cuda.synchronize()
@@ -150,6 +151,7 @@ def profile_step(net, bucket, inp, scaler):
         RF.call = orig
         RF.set_async_wgrad(was_async)
         RM._CRE_STREAMS_TRAIN = was_cre
+        RM._ENC_STREAMS = was_enc
     agg = {}
     for name, flops, nbytes, a, b in records:
         e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])

@@ -32,6 +32,7 @@ hip.call = timed; RF.call = timed
 RF.set_async_wgrad(False)
 import rpnet_amd.modules as RM
 RM._CRE_STREAMS_TRAIN = False       # one launch at a time on the GPU
+RM._ENC_STREAMS = 0
 bench.step(net, bucket, inp, cfg["align_loss_scaler"])
 torch.cuda.synchronize()
 hip.call = orig; RF.call = orig

@@ -12,18 +12,18 @@ B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
 S="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
 db() { find $1 -name "*.db" | head -1; }
 csvc() { find $1 -name "*counter_collection.csv" | head -1; }
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_serial -o t -- $B > $R/trace_serial.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_serial -o t -- $B > $R/trace_serial.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_serial) $O/${TAG}_bench_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_async -o t -- $B > $R/trace_async.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_async) $O/${TAG}_bench_kernel_stats_async_wgrad.csv
 # where the matrix pipe idles inside the default (multi-stream) step: union of the MFMA-bound kernels' intervals per step
 python tools/mfma_idle.py $(db $R/trace_async) $O/${TAG}_mfma_idle.txt
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/pmc_fetch -o p --output-format csv -- $S > $R/pmc_fetch.log 2>&1
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/pmc_write -o p --output-format csv -- $S > $R/pmc_write.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/pmc_fetch -o p --output-format csv -- $S > $R/pmc_fetch.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/pmc_write -o p --output-format csv -- $S > $R/pmc_write.log 2>&1
 python tools/pmc_traffic.py $(csvc $R/pmc_fetch) $(csvc $R/pmc_write) $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.txt
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/pmc_mfma -o p --output-format csv -- $S > $R/pmc_mfma.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/pmc_mfma -o p --output-format csv -- $S > $R/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $(csvc $R/pmc_mfma) $O/${TAG}_pmc_mfma_busy.json > $O/${TAG}_pmc_mfma_busy.txt
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $R/pmc_sq -o p --output-format csv -- $S > $R/pmc_sq.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $R/pmc_sq -o p --output-format csv -- $S > $R/pmc_sq.log 2>&1
 python tools/pmc_sq.py $(csvc $R/pmc_sq) $O/${TAG}_pmc_sq_wave_cycles.json > $O/${TAG}_pmc_sq_wave_cycles.txt
 # the clock a chip-wide MFMA stream holds on zero / dense operands, and whether fragment reads hide under it
 [ -x tools/probe/lds_mfma_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probe/lds_mfma_probe tools/probe/lds_mfma_probe.cpp
@@ -36,11 +36,12 @@ python tools/cpu_overhead.py 2>/dev/null | grep -v Warning > $O/${TAG}_cpu_overh
   RPNET_CRE_STREAMS_TRAIN=0 python tools/ab_overlap.py | tail -1
   RPNET_BN_LDS=big python tools/ab_overlap.py | tail -1
   python tools/ab_overlap.py | tail -1
-  AB_CONFIG=c5 RPNET_WGRAD_DEFER=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_BN_LDS=big RPNET_DICE_MULTI=0 python tools/ab_overlap.py 10 | tail -1
+  AB_CONFIG=c5 RPNET_WGRAD_DEFER=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 RPNET_BN_LDS=big RPNET_DICE_MULTI=0 python tools/ab_overlap.py 10 | tail -1
+  AB_CONFIG=c5 RPNET_ENC_STREAMS=0 python tools/ab_overlap.py 10 | tail -1
   AB_CONFIG=c5 python tools/ab_overlap.py 10 | tail -1 ) > $O/${TAG}_ab_overlap.txt 2>/dev/null
 # configs[4] (one fp16 plane, 2-way 512^2 T=10 batch 4): kernel trace of the same command as its bench line
 C5="python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
-RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_c5) $O/${TAG}_bench_c5_f16_kernel_stats.csv
 # the reference driver's call (eval mode, 2 slices, 256^2, T = 10): kernel trace of 33 eager + 33 replayed calls
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_eval -o t -- python tools/bench_eval.py > $O/${TAG}_eval_call.txt 2>&1
