@@ -612,6 +612,17 @@ def roofline_of(m, w, world):
                     "value/ms_per_step measured with async weight gradients on"}
 
 
+def stream_layout():
+    """what the timed step runs beside what: the switches in force, for the record in the line"""
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    return {"async_wgrad": bool(RF._ASYNC["on"]), "wgrad_released_behind_dgrad": RF._WGRAD_DEFER,
+            "cre_second_branch_on_own_stream": bool(RM._CRE_STREAMS_TRAIN), "encoder_two_chains": RM._ENC_STREAMS,
+            "high_priority_compute_stream": int(os.environ.get("RPNET_COMPUTE_PRIORITY", "0")) != 0,
+            "what": "same kernels and bits as the one-stream step (tests: test_async_weight_gradients_match, "
+                    "test_encoder_two_chains_match_one_stream); per-kernel roofline figures come from an extra step with all of it serialised"}
+
+
 def workload_text(w, world):
     ns = argparse.Namespace(**w)
     return (f"{w['ways']}-way {w['shots']}-shot, {w['size']}x{w['size']}, T={w['iters']}, batch {w['batch']}/GPU "
@@ -700,6 +711,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "conv_math": math,
                        "conv_math_requested": requested,
                        "launches_by_arithmetic": m["arith"],
+                       "streams": stream_layout(),
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
             "roofline": roofline_of(m, w, world),
         }
