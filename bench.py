@@ -482,6 +482,32 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
     for _ in range(warmup):
         step(net, bucket, inp, scaler)
     fence()
+    # How the timed steps are issued, decided BEFORE the timed region from a probe of three untimed steps: eagerly (the
+    # default: ~450 launches from Python per step, the faster way while the host keeps ahead of the GPU), or — single
+    # process, when the host's enqueue time of a step has reached the GPU's time for it (a busy shared host: the boxes of
+    # the pool are shared) — as replays of the step captured into a HIP graph (rpnet_amd.graph.GraphedTrainStep: one launch
+    # per step from the host, bit-identical gradients).  RPNET_BENCH_GRAPH=0 / 1 forces eager / replay.
+    mode, probe = "eager", None
+    want = os.environ.get("RPNET_BENCH_GRAPH", "auto")
+    if world == 1 and want != "0":
+        pa, pb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hs = []
+        pa.record()
+        for _ in range(3):
+            h0 = time.perf_counter()
+            step(net, bucket, inp, scaler)
+            hs.append(time.perf_counter() - h0)
+        pb.record()
+        fence()
+        probe = {"host_enqueue_ms": round(1e3 * sorted(hs)[1], 3), "gpu_ms_per_step": round(pa.elapsed_time(pb) / 3, 3)}
+        if want == "1" or probe["host_enqueue_ms"] > 0.95 * probe["gpu_ms_per_step"]:
+            mode = "hip_graph_replay"
+    gts = None
+    if mode == "hip_graph_replay":
+        gts = graphed_step(net, bucket, scaler)
+        for _ in range(2):
+            gts(*inp[:4], inp[4], inp[5])
+        fence()
     exposed = [] if world > 1 else None
     # per-step marks (an event on the compute stream + the host clock after each step's enqueue; no synchronisation): the
     # spread of the timed steps goes into the line next to their total, so that one slow step (a busy host: the boxes are
@@ -492,15 +518,19 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
     marks[0].record()
     for i in range(steps):
         h0 = time.perf_counter()
-        loss = step(net, bucket, inp, scaler, exposed)
+        loss = gts(*inp[:4], inp[4], inp[5]) if gts is not None else step(net, bucket, inp, scaler, exposed)
         marks[i + 1].record()
         host.append(time.perf_counter() - h0)
     fence()
     el = time.perf_counter() - t0
+    del gts
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     spread = {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3),
               "host_enqueue_median": round(1e3 * sorted(host)[len(host) // 2], 3),
-              "what": "per timed step: HIP events on the compute stream between the steps' ends (ms); the host's enqueue time of a step"}
+              "what": "per timed step: HIP events on the compute stream between the steps' ends (ms); the host's enqueue time of a step",
+              "issued": mode, "probe": probe,
+              "issued_what": "eager = ~450 launches per step from Python; hip_graph_replay = the captured step replayed (chosen before the "
+                             "timed region when the probe's host enqueue time exceeds 0.95 of its GPU time per step: a busy host)"}
     if math in ("f16x2", "f16") and not RF.f16_mode():
         # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
         # planes: label the line with what ran (`requested` keeps what was asked for)
@@ -533,18 +563,20 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
             "net": net, "bucket": bucket, "inp": inp, "scaler": scaler, "cfg": cfg, "dist": dist_info, "fence": fence}
 
 
-def graph_replay_leg(net, bucket, inp, scaler, batch, fence, steps):
-    """The timed step captured once into a HIP graph (rpnet_amd.graph.GraphedTrainStep) and replayed `steps` times: the host
-    then enqueues ONE launch per step, so the figure does not depend on how busy the (shared) host is."""
-    from rpnet_amd.functional import dice_ce
+def graphed_step(net, bucket, scaler):
+    """the bench step (same objective as `step`) as a rpnet_amd.graph.GraphedTrainStep"""
+    from rpnet_amd.functional import dice_ce_sum
     from rpnet_amd.graph import GraphedTrainStep
 
     def loss_fn(out, ql):
-        loss = dice_ce(out["output"], ql)
-        for v in out["refinement"].values():
-            loss = loss + dice_ce(v, ql)
-        return loss + scaler * out["align_loss"]
-    gts = GraphedTrainStep(net, bucket, loss_fn)
+        return dice_ce_sum([out["output"], *out["refinement"].values()], ql) + scaler * out["align_loss"]
+    return GraphedTrainStep(net, bucket, loss_fn)
+
+
+def graph_replay_leg(net, bucket, inp, scaler, batch, fence, steps):
+    """The timed step captured once into a HIP graph (rpnet_amd.graph.GraphedTrainStep) and replayed `steps` times: the host
+    then enqueues ONE launch per step, so the figure does not depend on how busy the (shared) host is."""
+    gts = graphed_step(net, bucket, scaler)
     for _ in range(2):
         gts(*inp[:4], inp[4], inp[5])
     fence()
@@ -558,7 +590,7 @@ def graph_replay_leg(net, bucket, inp, scaler, batch, fence, steps):
     return {"value": round(batch * steps / t_all, 3), "unit": "pairs/s", "steps": steps, "ms_per_step": round(1e3 * t_all / steps, 3),
             "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3),
             "what": "the timed step captured once into a HIP graph and replayed (bit-identical gradients: "
-                    "tests/test_gpu_model.py::test_graphed_train_step_matches_eager); `value` above is the eager step"}
+                    "tests/test_gpu_model.py::test_graphed_train_step_matches_eager); `value` above is the eager step unless step_ms.issued says hip_graph_replay"}
 
 
 CONV_MATH_TEXT = {
