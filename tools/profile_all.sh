@@ -8,8 +8,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$TAG
 R=$O/raw
 rm -rf $O; mkdir -p $R
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
-S="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
+# (under the tracer the host is slow enough for bench.py's probe to choose graph replays: the traced runs force eager steps)
+B="env RPNET_BENCH_GRAPH=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
+S="env RPNET_BENCH_GRAPH=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
 db() { find $1 -name "*.db" | head -1; }
 csvc() { find $1 -name "*counter_collection.csv" | head -1; }
 RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_serial -o t -- $B > $R/trace_serial.log 2>&1
@@ -40,7 +41,7 @@ python tools/cpu_overhead.py 2>/dev/null | grep -v Warning > $O/${TAG}_cpu_overh
   AB_CONFIG=c5 RPNET_ENC_STREAMS=0 python tools/ab_overlap.py 10 | tail -1
   AB_CONFIG=c5 python tools/ab_overlap.py 10 | tail -1 ) > $O/${TAG}_ab_overlap.txt 2>/dev/null
 # configs[4] (one fp16 plane, 2-way 512^2 T=10 batch 4): kernel trace of the same command as its bench line
-C5="python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
+C5="env RPNET_BENCH_GRAPH=0 python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
 RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
 python tools/rocpd_stats.py $(db $R/trace_c5) $O/${TAG}_bench_c5_f16_kernel_stats.csv
 # the reference driver's call (eval mode, 2 slices, 256^2, T = 10): kernel trace of 33 eager + 33 replayed calls
