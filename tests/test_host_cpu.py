@@ -180,3 +180,36 @@ def test_driver_import_closure():
     assert dice_score_seperate(a, a, num_class=1) == [1.0] and dice_score_seperate(a, a * 0, num_class=1) == [None]
     x = torch.arange(16.0).reshape(4, 4)
     assert abs(NCC(x, x).item() + 1.0) < 1e-6 and MSE(x, x).item() == 0
+
+
+def test_deferred_weight_gradient_queue_order():
+    """the release queue of the asynchronous weight gradients (rpnet_amd.functional._defer_wgrad / _release_wgrads /
+    join_side_streams): a launch goes out behind the dgrad `depth - 1` layers further down, oldest first, and whatever is
+    still queued at the end of a backward pass (or before a bucket operation) is flushed by join_side_streams"""
+    import rpnet_amd.functional as RF
+    st = RF._ASYNC
+    saved = (st["queued"], list(st["fifo"]), set(st["pending"]))
+    try:
+        st["queued"] = True            # as if the engine callback of this backward pass were registered already
+        st["fifo"].clear()
+        st["pending"].clear()
+        for depth, want in ((1, ["L3", "L2", "L1"]), (2, ["L3", "L2", "L1"]), (3, ["L3", "L2", "L1"])):
+            log, held = [], []
+            st["queued"] = True        # (join_side_streams re-arms the registration at the end of every pass)
+            for layer in ("L3", "L2", "L1"):                      # backward runs the layers top down
+                RF._defer_wgrad(lambda n=layer: log.append(n))
+                RF._release_wgrads(depth - 1)                      # ... right after that layer's dgrad is enqueued
+                held.append(len(st["fifo"]))
+            assert held == [min(i + 1, depth - 1) for i in range(3)], (depth, held)
+            assert log == want[:3 - (depth - 1)] if depth > 1 else log == want
+            RF.join_side_streams()                                 # end of backward: the rest, oldest first
+            assert log == want and not st["fifo"]
+        st["queued"] = True
+        RF._defer_wgrad(lambda: log.append("late"))
+        RF.reset_async()                                           # start of the next forward / a bucket operation: flushed too
+        assert log[-1] == "late" and not st["fifo"] and st["queued"] is False
+    finally:
+        st["queued"] = saved[0]
+        st["fifo"][:] = saved[1]
+        st["pending"].clear()
+        st["pending"].update(saved[2])
