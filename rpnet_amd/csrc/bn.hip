@@ -388,7 +388,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
 
 // same, 8 channels per thread: dy as split-bf16 planes (and, when `dy` is not NULL, also in fp32)
 template <int NP>
-__global__ __launch_bounds__(256) void bn_bwd_apply_split(const float* __restrict__ dz, const float* __restrict__ y,
+// amdgpu_waves_per_eu(8, 8): at most 64 registers (62 without spills instead of 68), so that TWO waves of this pass fit into
+// the 128 registers per lane a resident LDS-DMA GEMM wave leaves free on its SIMD (one at 68): the pass runs beside the
+// weight-gradient launches of the side stream — 18.09 -> 18.05 ms per batch-8 step, configs[4] 33.34 -> 33.11 ms (the
+// three-plane form, bf16x3, pays for the cap with two spilled dwords)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_bwd_apply_split(const float* __restrict__ dz, const float* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dy,
