@@ -277,6 +277,169 @@ def gen_model(tag, size, B, T, training, seed, stride=1, d4_stride=1, fts_stride
     save(tag, **fx)
 
 
+# ------------------------------------------------- extension rows: multi-shot / multi-way, composed from the reference's pieces
+def composed_forward(net, cfg, si, fg, bg, qi, appr, caps):
+    """SURVEY.md §8a "Extension rows": the reference's forward (net/rp_net.py:226-350) fails for n_shots > 1 or n_ways > 1
+    (:275 feeds shot [0][0] only, :288 then indexes a [1, 1, ...] tensor), so the expected behaviour is DEFINED as the
+    composition of the reference's OWN modules and methods — net.encoder, net.cre, net.getFeatures, net.getPrototype,
+    net.calDist, net.alignLoss, all called here on the reference object — with the one generalisation of :271-275: the CRE
+    runs once per (way, shot) on that shot's features with that shot's own pooled foreground mask, way-major / shot-minor
+    (which fixes the order of the BatchNorm running-statistic updates).  Everything else is the reference's line, cited."""
+    import torch.nn.functional as F
+    n_ways, n_shots, n_queries = len(si), len(si[0]), len(qi)
+    B = si[0][0].shape[0]
+    img_size = qi[0].shape[-2:]
+    imgs = torch.cat([torch.cat(way, dim=0) for way in si], dim=0)                      # :245
+    img_fts = net.encoder(imgs, fg[0][0].unsqueeze(1))["d4"]                            # :248-249
+    fts_size = img_fts.shape[-2:]
+    supp_d4 = img_fts.view(n_ways, n_shots, B, -1, *fts_size)                           # :252
+    qry_d4 = net.encoder(torch.cat(qi, dim=0), fg[0][0].unsqueeze(1))["d4"]             # :254-258
+    qry_fts = qry_d4.view(n_queries, B, -1, *fts_size)                                  # :262
+    fore = torch.stack([torch.stack(way, dim=0) for way in fg], dim=0)                  # :264-265
+    back = torch.stack([torch.stack(way, dim=0) for way in bg], dim=0)                  # :266-267
+    qry_mask = F.avg_pool2d(appr.unsqueeze(1), net.scale)                               # :269-270
+    rows = []
+    for wa in range(n_ways):                                                            # :271-275, per (way, shot)
+        row = []
+        for s in range(n_shots):
+            sm = F.avg_pool2d(fore[wa][s].unsqueeze(1), net.scale)
+            row.append(net.cre(supp_d4[wa][s] * sm, supp_d4[wa][s] * (1 - sm)))
+        rows.append(torch.stack(row, 0))
+    supp_fts = torch.stack(rows, 0)                                                     # Wa x Sh x B x C x h x w
+    caps.update(supp_d4=supp_d4, qry_d4=qry_d4, supp_fts=supp_fts, inter=[], protos=None)
+
+    def match(inter):
+        outs, preds, protos = [], [], []
+        for epi in range(B):
+            fgf = [[net.getFeatures(supp_fts[wa, s, [epi]], fore[wa, s, [epi]]) for s in range(n_shots)]
+                   for wa in range(n_ways)]                                             # :288-290
+            bgf = [[net.getFeatures(supp_fts[wa, s, [epi]], back[wa, s, [epi]]) for s in range(n_shots)]
+                   for wa in range(n_ways)]                                             # :291-293
+            fgp, bgp = net.getPrototype(fgf, bgf)                                       # :297
+            prototypes = [bgp] + fgp                                                    # :300
+            protos.append(torch.cat(prototypes, 0))
+            dist = [net.calDist(inter[:, epi], p) for p in prototypes]                  # :301
+            pred = torch.stack(dist, dim=1)                                             # :302
+            preds.append(pred)
+            outs.append(F.interpolate(pred, size=img_size, mode="bilinear"))            # :303
+        outs = torch.stack(outs, dim=1)                                                 # :305
+        caps["protos"] = torch.stack(protos, 0)
+        return outs.view(-1, *outs.shape[2:]), preds                                    # :306
+
+    refinement = {}
+    for i in range(net.num_iter):                                                       # :281
+        inter = net.cre(qry_fts[0] * qry_mask, qry_fts[0] * (1 - qry_mask))[None]      # :283
+        caps["inter"].append(inter[0])
+        logits, _ = match(inter)
+        outputs = logits.softmax(dim=1)[:, 1, ...]                                      # :308
+        if net.backbone_cfg["soft_mask"] == False:  # noqa: E712                        # :309-310
+            outputs = (outputs > 0.5).float()
+        qry_mask = F.avg_pool2d(outputs.unsqueeze(1), net.scale)                        # :311
+        refinement[i] = logits                                                          # :312
+    output, preds = match(inter)                                                        # :320-337
+    align_loss = 0
+    if net.config["align"] and net.training:                                            # :340-343
+        for epi in range(B):
+            align_loss = align_loss + net.alignLoss(inter[:, epi], preds[epi], supp_fts[:, :, epi], fore[:, :, epi],
+                                                    back[:, :, epi])
+    return {"output": output, "align_loss": align_loss / B, "refinement": refinement}    # :348-350
+
+
+def gen_composed(tag, size, B, T, seed, n_ways, n_shots, d4_stride=4):
+    """Fixture set 4 of SURVEY.md §8c: the composed reference (composed_forward) on a multi-shot / multi-way episode —
+    stage taps, logits per iteration, prototypes, align loss, loss, gradient norms / heads, BatchNorm buffers — and the
+    oracle's multi-shot / multi-way branch (oracle/rpnet_oracle.py rp_net_forward) checked against it, both modes."""
+    cfg = dict(CFG)
+    cfg["n_iter_refinement"] = T
+    net = build_ref(cfg)
+    net.train(True)
+    ep = make_episode(seed, B, size, n_shots=n_shots, n_ways=n_ways)
+    si, fg, bg, qi, ql, appr = to_t(ep)
+    caps = {}
+    out = composed_forward(net, cfg, si, fg, bg, qi, appr, caps)
+    loss = O.total_loss(out, ql, cfg["align_loss_scaler"])
+    assert torch.equal(out["output"], out["refinement"][T - 1])
+    # on a 1-way 1-shot episode the composition IS the reference's forward (checked once per run in __main__)
+    fx = {"meta": np.array([size, B, T, 1, seed, n_ways, n_shots]),
+          "in_checksum": np.array([float(ep["query_images"].astype(np.float64).sum()),
+                                   float(ep["support_images"][0][0].astype(np.float64).sum()),
+                                   float(ep["appr_query_labels"].sum()), float(ep["support_fg"][0][0].sum())]),
+          "output": out["output"], "loss": loss, "align_loss": torch.as_tensor(out["align_loss"]).float(),
+          "supp_d4": caps["supp_d4"][:, :, :, ::d4_stride], "qry_d4": caps["qry_d4"][:, ::d4_stride],
+          "supp_fts": caps["supp_fts"], "protos": caps["protos"], "strides": np.array([1, d4_stride, 1])}
+    for i in range(T):
+        fx[f"refinement_{i}"] = out["refinement"][i]
+        fx[f"inter_{i}"] = caps["inter"][i]
+        p = out["refinement"][i].softmax(1)[:, 1]
+        fx[f"fg_frac_{i}"] = (p > 0.5).float().mean()
+        fx[f"next_mask_{i}"] = torch.nn.functional.avg_pool2d((p > 0.5).float().unsqueeze(1), 4)
+        pred = (p > 0.5).long()
+        fx[f"dice_{i}"] = 2.0 * (pred * ql).sum() / (pred.sum() + ql.sum() + 1e-7)
+    loss.backward()
+    names, norms, heads = [], [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        norms.append(g.double().norm().item())
+        heads.append(torch.nn.functional.pad(g.flatten()[:32], (0, max(0, 32 - g.numel()))))
+    fx["grad_names"], fx["grad_norms"], fx["grad_heads"] = np.array(names), np.array(norms), torch.stack(heads, 0)
+    fx["unused"] = np.array([n for n, p in net.named_parameters() if p.grad is None])
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            fx["sd." + k] = v
+    for as_written in (True, False):
+        P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True)
+        taps = {}
+        o = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, align=True, as_written=as_written, taps=taps)
+        ol = O.total_loss(o, ql, cfg["align_loss_scaler"])
+        w = f"{tag}[as_written={as_written}]"
+        close(taps["supp_d4"], caps["supp_d4"], 1e-4, w + ".supp_d4")
+        close(taps["qry_d4"], caps["qry_d4"], 1e-4, w + ".qry_d4")
+        close(taps["supp_fts"], caps["supp_fts"], 1e-4, w + ".supp_fts")
+        close(taps["protos"], caps["protos"], 1e-4, w + ".protos")
+        flips = 0
+        for i in range(T):
+            flips += ((o["refinement"][i].softmax(1)[:, 1] > 0.5) != (out["refinement"][i].softmax(1)[:, 1] > 0.5)).sum().item()
+            close(taps[f"inter_{i}"][0], caps["inter"][i], 1e-4, w + f".inter[{i}]")
+            close(o["refinement"][i], out["refinement"][i], 1e-4, w + f".refinement[{i}]")
+        close(o["output"], out["output"], 1e-4, w + ".output")
+        close(o["align_loss"], out["align_loss"], 1e-5, w + ".align_loss")
+        close(ol, loss, 1e-5, w + ".loss")
+        ol.backward()
+        params = dict(net.named_parameters())
+        for n, p in params.items():
+            if p.grad is None:
+                assert P[n].grad is None, n
+                continue
+            e = (P[n].grad - p.grad).double().norm().item()
+            sib = params.get(n.rsplit(".", 1)[0] + ".weight")
+            floor = 1e-5 * max(1.0, sib.grad.double().norm().item() if sib is not None and sib.grad is not None else 1.0)
+            assert e < 2e-3 * p.grad.double().norm().item() + floor, f"{w} grad {n}: abs {e:.2e}"
+        for k, v in net.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                close(P[k], v, 1e-5, w + "." + k)
+        print(f"  oracle == composed reference on {w} (threshold flips: {flips})")
+    save(tag, **fx)
+
+
+def check_composition_is_the_reference():
+    """composed_forward on a 1-way 1-shot episode against the reference's own RP_Net.forward: bit-identical outputs, align
+    loss and BatchNorm buffers — the composition adds nothing of its own where the reference has behaviour."""
+    cfg = dict(CFG)
+    cfg["n_iter_refinement"] = 2
+    si, fg, bg, qi, ql, appr = to_t(make_episode(1001, 2, 64))
+    a, b = build_ref(cfg), build_ref(cfg)
+    a.train(True); b.train(True)
+    oa = a(si, fg, bg, qi, appr_query_labels=appr)
+    ob = composed_forward(b, cfg, si, fg, bg, qi, appr, {})
+    assert torch.equal(oa["output"], ob["output"]) and torch.equal(oa["align_loss"], ob["align_loss"])
+    for i in range(2):
+        assert torch.equal(oa["refinement"][i], ob["refinement"][i])
+    for (k, v), (_, u) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, u), k
+    print("  composed_forward == RP_Net.forward (bit-identical) on a 1-way 1-shot episode")
+
+
 def gen_vgg():
     enc = REF["vgg"].Encoder(3, None)
     sd = {f"vgg.{k}": v for k, v in enc.state_dict().items()}
@@ -299,4 +462,9 @@ if __name__ == "__main__":
     for mfm in ("x", "x2", "x3"):      # the yaml's non-default mask_feature_map settings
         gen_model(f"m64_train_{mfm}", 64, 2, 2, True, 1004, d4_stride=4, mask_feature_map=mfm)
     gen_vgg()
+    # SURVEY.md §8c fixture set 4: the extension rows (BASELINE configs[2] / configs[4] shape classes), composed reference
+    check_composition_is_the_reference()
+    gen_composed("m64_5shot", 64, 2, 2, 1005, n_ways=1, n_shots=5)
+    gen_composed("m64_2way", 64, 2, 2, 1006, n_ways=2, n_shots=1)
+    gen_composed("m64_2way2shot", 64, 2, 2, 1007, n_ways=2, n_shots=2)
     print("golden fixtures regenerated; oracle pinned against the reference")

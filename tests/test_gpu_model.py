@@ -74,6 +74,12 @@ def conv_math(request):
     RF.set_conv_math(old)
 
 
+def _meta(g):
+    """(size, B, T, training, seed, n_ways, n_shots) of a model fixture (the 1-way 1-shot fixtures store the first five)"""
+    m = [int(v) for v in g["meta"]]
+    return tuple(m) if len(m) == 7 else tuple(m) + (1, 1)
+
+
 YARD_EPS = 4e-7      # relative input perturbation of the yardstick: moves the fp64 forward as much as the HIP path deviates
 YARD_FLOOR = 5e-5    # relative L2: fp32 round-off of reductions over ~1e5 terms, where the yardstick itself is at round-off level
 _YARD_CACHE = {}     # tag -> fp64 oracle results (shared by the three arithmetics and by the two tests that use them)
@@ -86,12 +92,12 @@ def _yardstick(tag, g):
     (each is one fp64 forward + backward on the host)."""
     from tests.helpers import oracle_step
     if tag not in _YARD_CACHE:
-        size, B, T, _, seed = (int(v) for v in g["meta"])
+        size, B, T, _, seed, n_ways, n_shots = _meta(g)
         cfg = load_cfg(T)
-        mfm = tag.rsplit("_", 1)[1] if tag.count("_") == 2 else None
+        mfm = tag.rsplit("_", 1)[1] if tag.startswith("m64_train_") else None
         if mfm:
             cfg["mask_feature_map"] = mfm
-        cpu_inputs, _ = episode_tensors(seed, B, size)
+        cpu_inputs, _ = episode_tensors(seed, B, size, n_shots=n_shots, n_ways=n_ways)
         g64, l64, o64 = oracle_step(cfg, cpu_inputs, dtype=torch.float64)
         yard, fwd_moves = {}, []
         for draw in range(6 if size < 256 else 2):
@@ -408,6 +414,74 @@ def test_five_shot_extension_vs_composed_oracle():
         assert rel_err(out["refinement"][i], ref["refinement"][i]) < TOL
 
 
+@pytest.mark.parametrize("tag", ["m64_5shot", "m64_2way", "m64_2way2shot"])
+def test_extension_rows_vs_composed_reference(golden, tag, conv_math):
+    """BASELINE configs[2] / configs[4] shape classes (multi-shot, multi-way): the reference's forward has no behaviour there
+    (net/rp_net.py:275,288 fail), so SURVEY.md §8a defines it as the composition of the reference's OWN encoder, cre,
+    getFeatures, getPrototype, calDist and alignLoss per (way, shot); tests/golden/gen_golden.py::gen_composed runs exactly
+    that on the imported reference and stores stage taps, logits, align loss, loss, every gradient norm / head and the
+    BatchNorm buffers.  The HIP path against those fixtures, under all three arithmetics, all gradients."""
+    g = golden(tag)
+    size, B, T, _, seed, n_ways, n_shots = _meta(g)
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), ep = episode_tensors(seed, B, size, DEV, n_shots=n_shots, n_ways=n_ways)
+    assert np.allclose(in_checksum(ep), g["in_checksum"], rtol=0, atol=1e-6), "synthetic inputs drifted"
+    s_d4 = int(g["strides"][1])
+    net = build(cfg, True)
+    net.taps = {}
+    from rpnet_amd import functional as RF
+    RF.reset_arith()
+    out = net(si, fg, bg, qi, appr_query_labels=appr)
+    loss = total_loss(out, ql, cfg["align_loss_scaler"])
+    counts = RF.arith_counts()
+    assert set(counts["conv3x3"]) == {conv_math} and set(counts["corr"]) == {conv_math}, counts
+    assert out["output"].shape == (B, 1 + n_ways, size, size) and out["output"] is out["refinement"][T - 1]
+    tp = net.taps
+    for err in (rel_err, rel_l2):
+        assert err(tp["supp_d4"][:, :, :, ::s_d4], g["supp_d4"]) < TOL and err(tp["qry_d4"][:, ::s_d4], g["qry_d4"]) < TOL
+        for wa in range(n_ways):
+            for s_ in range(n_shots):
+                assert err(tp["supp_fts"][wa][s_], g["supp_fts"][wa, s_]) < TOL, (wa, s_)
+        assert err(tp["protos"], g["protos"]) < TOL
+        for i in range(T):
+            assert err(tp[f"inter_{i}"], g[f"inter_{i}"]) < TOL, f"inter[{i}]"
+            assert err(out["refinement"][i], g[f"refinement_{i}"]) < TOL, f"refinement[{i}]"
+    for i in range(T):
+        p = out["refinement"][i].softmax(1)[:, 1]
+        assert abs(float((p > 0.5).float().mean()) - float(g[f"fg_frac_{i}"])) <= 1e-3
+        pred = (p > 0.5).long()
+        dice = 2.0 * (pred * ql).sum() / (pred.sum() + ql.sum() + 1e-7)
+        assert abs(float(dice) - float(g[f"dice_{i}"])) <= 1e-3, f"Dice deviation at iteration {i}"
+    assert rel_err(loss, g["loss"]) < TOL and rel_err(out["align_loss"], g["align_loss"]) < TOL
+    loss.backward()
+    unused = set(str(u) for u in g["unused"])
+    params = dict(net.named_parameters())
+    yard = _yardstick(tag, g)[3]
+    for n, ref, head in zip(g["grad_names"], g["grad_norms"], g["grad_heads"]):
+        n = str(n)
+        gr = params[n].grad
+        if n in unused:
+            assert gr is None, n
+            continue
+        if ref < 1e-4:
+            assert gr.abs().max() < 1e-4
+            continue
+        e = abs(gr.double().norm().item() - ref) / ref
+        if n.startswith("encoder."):     # conditioned by ReLU / max-pool switches: bound = this episode's measured conditioning (test_model_vs_golden)
+            assert e <= 6.0 * yard[n] + 1e-6, f"grad norm {n}: rel {e:.2e}, yardstick {yard[n]:.2e}"
+            continue
+        assert e < 1e-3, f"grad norm {n}: rel {e:.2e}"
+        k = min(32, gr.numel())
+        hd = torch.from_numpy(head[:k])
+        he = (gr.flatten()[:k].cpu() - hd).abs().max() / (hd.abs().max() + 1e-12)
+        assert he < 4e-3, f"grad head {n}: rel {he:.2e}"
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("sd."):
+            assert rel_err(sd[k[3:]].float(), g[k]) < 1e-4, k
+    assert int(sd["cre.w_k.1.num_batches_tracked"]) == n_ways * n_shots + T
+
+
 def test_soft_mask_training_vs_oracle():
     """soft_mask: True — the fed-back mask stays differentiable (net/rp_net.py:309): forward and
     gradients against the CPU oracle (autograd through softmax -> avg_pool -> x*mask)."""
@@ -674,6 +748,18 @@ def test_graphed_eval_matches_eager(fp16_planes):
 
 @pytest.mark.parametrize("tag", ["m64_train", "m128_train", "m256_train"])
 def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
+    _gradients_vs_fp64_yardstick(golden, tag, conv_math)
+
+
+@pytest.mark.parametrize("tag", ["m64_5shot", "m64_2way"])
+def test_extension_gradients_vs_fp64_yardstick(golden, tag, conv_math):
+    """the same yardstick on the multi-shot / multi-way episodes of the composed-reference fixtures: EVERY parameter gradient
+    of the extension rows' path (per-(way, shot) CRE calls, prototype means over shots / ways, the encoder's two calls as two
+    chains) element-wise against the fp64 oracle — whose fp32 form tests/golden/gen_golden.py::gen_composed pins to the reference's own pieces"""
+    _gradients_vs_fp64_yardstick(golden, tag, conv_math)
+
+
+def _gradients_vs_fp64_yardstick(golden, tag, conv_math):
     """Backward parity with a reproducible yardstick instead of a loose constant.  Reference point: the CPU oracle in
     FLOAT64 on the same inputs.  Yardstick: how far the fp64 oracle's OWN gradients move when every image pixel is
     perturbed by YARD_EPS = 4e-7 relative (which moves the fp64 logits by 3e-6 .. 7e-6: the size of the HIP path's forward
@@ -687,11 +773,11 @@ def test_gradients_vs_fp64_yardstick(golden, tag, conv_math):
     chance proportional to its forward error; the perturbation draws sample exactly that chance at the HIP path's error
     level (tests/test_oracle_conditioning.py is the CPU-only statement of the same sensitivity)."""
     g = golden(tag)
-    size, B, T, _, seed = (int(v) for v in g["meta"])
+    size, B, T, _, seed, n_ways, n_shots = _meta(g)
     cfg = load_cfg(T)
     g64, l64, logits64, yard, fwd_moves = _yardstick(tag, g)
     net = build(cfg, True)
-    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, DEV, n_shots=n_shots, n_ways=n_ways)
     out = net(si, fg, bg, qi, appr_query_labels=appr)
     loss = total_loss(out, ql, cfg["align_loss_scaler"])
     loss.backward()

@@ -130,6 +130,44 @@ def test_model_vs_golden(golden, tag):
                 assert rel_err(P[k[3:]], g[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("tag", ["m64_5shot", "m64_2way", "m64_2way2shot"])
+def test_extension_rows_vs_composed_reference(golden, tag):
+    """SURVEY.md §8c fixture set 4: the oracle's multi-shot / multi-way branch (rp_net_forward, the per-(way, shot) CRE
+    calls) against the fixtures tests/golden/gen_golden.py::gen_composed wrote by calling the REFERENCE's own encoder, cre,
+    getFeatures, getPrototype, calDist and alignLoss per (way, shot) — stage taps, logits, align loss, loss, every gradient
+    norm, BatchNorm buffers (whose update order the way-major / shot-minor CRE calls fix)."""
+    g = golden(tag)
+    size, B, T, _, seed, n_ways, n_shots = (int(v) for v in g["meta"])
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), ep = episode_tensors(seed, B, size, n_shots=n_shots, n_ways=n_ways)
+    assert np.allclose(in_checksum(ep), g["in_checksum"], rtol=0, atol=1e-6), "synthetic inputs drifted"
+    s_d4 = int(g["strides"][1])
+    P = O.seeded_params(cfg["mask_refinement_correlation_radius"], requires_grad=True)
+    taps = {}
+    out = O.rp_net_forward(P, cfg, si, fg, bg, qi, appr, True, taps=taps)
+    loss = O.total_loss(out, ql, cfg["align_loss_scaler"])
+    assert out["output"].shape == (B, 1 + n_ways, size, size)
+    assert rel_err(taps["supp_d4"][:, :, :, ::s_d4], g["supp_d4"]) < TOL and rel_err(taps["qry_d4"][:, ::s_d4], g["qry_d4"]) < TOL
+    assert tuple(taps["supp_fts"].shape[:3]) == (n_ways, n_shots, B) and rel_err(taps["supp_fts"], g["supp_fts"]) < TOL
+    assert rel_err(taps["protos"], g["protos"]) < TOL
+    for i in range(T):
+        assert rel_err(taps[f"inter_{i}"][0], g[f"inter_{i}"]) < TOL
+        assert rel_err(out["refinement"][i], g[f"refinement_{i}"]) < TOL
+    assert rel_err(loss, g["loss"]) < 1e-5 and rel_err(torch.as_tensor(out["align_loss"]), g["align_loss"]) < 1e-5
+    loss.backward()
+    unused = set(str(u) for u in g["unused"])
+    for n, ref in zip(g["grad_names"], g["grad_norms"]):
+        gr = P[str(n)].grad
+        if str(n) in unused:
+            assert gr is None
+        elif ref > 1e-4:
+            assert abs(gr.double().norm().item() - ref) < 2e-3 * ref, n
+    for k in g:
+        if k.startswith("sd."):
+            assert rel_err(P[k[3:]], g[k]) < 1e-5, k
+    assert int(P["cre.w_k.1.num_batches_tracked"]) == n_ways * n_shots + T and int(P["encoder.Conv1.conv.1.num_batches_tracked"]) == 2
+
+
 def test_teacher_forced_iteration(golden):
     """Feeding the reference's own masks reproduces each iteration independently."""
     g = golden("m64_train")
