@@ -458,11 +458,12 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
     return res
 
 
-def measure(w, world, rank, dev, cfg, steps, warmup, RF):
+def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
     """Times `steps` steps of workload w = dict(ways, shots, size, iters, batch, conv_math) after `warmup` untimed ones
     (barrier + synchronize on both sides, MAX over ranks), then one extra profiled step (HIP events per C-ABI call,
     streams serialised).  -> dict with value, ms_per_step, the per-call aggregate, the arithmetic that ran, the model."""
     from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters
+    ddp = (world > 1) if ddp is None else ddp      # the gradient exchange runs (N > 1, or the forced one-rank RCCL group)
     cfg = dict(cfg)
     cfg["n_iter_refinement"] = w["iters"]
     scaler = cfg["align_loss_scaler"]
@@ -470,12 +471,12 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
     requested = math = RF.conv_math()
     net = build_model(cfg, dev)
     broadcast_parameters(net)
-    bucket = FlatGradBucket(net)
+    bucket = FlatGradBucket(net, force_active=ddp)
     inp = make_inputs(1234 + rank, w["batch"], w["size"], dev, w["shots"], w["ways"])   # resident in HBM before timing
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -489,7 +490,7 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
     # per step from the host, bit-identical gradients).  RPNET_BENCH_GRAPH=0 / 1 forces eager / replay.
     mode, probe = "eager", None
     want = os.environ.get("RPNET_BENCH_GRAPH", "auto")
-    if world == 1 and want != "0":
+    if want != "0":
         pa, pb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         hs = []
         pa.record()
@@ -500,15 +501,22 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
         pb.record()
         fence()
         probe = {"host_enqueue_ms": round(1e3 * sorted(hs)[1], 3), "gpu_ms_per_step": round(pa.elapsed_time(pb) / 3, 3)}
-        if want == "1" or probe["host_enqueue_ms"] > 0.95 * probe["gpu_ms_per_step"]:
+        bound = want == "1" or probe["host_enqueue_ms"] > 0.95 * probe["gpu_ms_per_step"]
+        if ddp:      # one decision for the job: every rank replays if ANY rank's host cannot keep ahead of its GPU
+            flag = torch.tensor([1.0 if bound else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            probe["host_bound_ranks_any"] = bound = bool(flag.item() > 0)
+        if bound:
             mode = "hip_graph_replay"
+    exposed = [] if ddp else None
     gts = None
     if mode == "hip_graph_replay":
-        gts = graphed_step(net, bucket, scaler)
+        gts = graphed_step(net, bucket, scaler, exposed)
         for _ in range(2):
             gts(*inp[:4], inp[4], inp[5])
         fence()
-    exposed = [] if world > 1 else None
+        if exposed:
+            exposed.clear()
     # per-step marks (an event on the compute stream + the host clock after each step's enqueue; no synchronisation): the
     # spread of the timed steps goes into the line next to their total, so that one slow step (a busy host: the boxes are
     # shared) is visible as such
@@ -529,14 +537,16 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
               "host_enqueue_median": round(1e3 * sorted(host)[len(host) // 2], 3),
               "what": "per timed step: HIP events on the compute stream between the steps' ends (ms); the host's enqueue time of a step",
               "issued": mode, "probe": probe,
-              "issued_what": "eager = ~450 launches per step from Python; hip_graph_replay = the captured step replayed (chosen before the "
-                             "timed region when the probe's host enqueue time exceeds 0.95 of its GPU time per step: a busy host)"}
+              "issued_what": "eager = ~450 launches per step from Python (N > 1: the gradient exchange in three segments from hooks during "
+                             "backward); hip_graph_replay = the captured step replayed (N > 1: followed by ONE all-reduce of the whole bucket, "
+                             "exposed) — chosen before the timed region when the probe's host enqueue time exceeds 0.95 of its GPU time per "
+                             "step on any rank: a busy host"}
     if math in ("f16x2", "f16") and not RF.f16_mode():
         # a call below the fp16 threshold (rpnet_amd.modules._F16_MIN_PIXELS: small, launch-bound episodes) ran on bf16
         # planes: label the line with what ran (`requested` keeps what was asked for)
         math = "bf16x3"
     dist_info = None
-    if world > 1:
+    if ddp:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -545,12 +555,39 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ex = torch.tensor([sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)], device=dev, dtype=torch.float64)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
-        dist_info = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (plumbing test, not RCCL)"),
+        # the OTHER way of issuing the step, 5 steps, so that the line carries both (eager + overlapped exchange / graph replay
+        # + exposed exchange) whichever the probe chose
+        other_ex = []
+        if mode == "eager":
+            og = graphed_step(net, bucket, scaler, other_ex)
+            run_other = lambda: og(*inp[:4], inp[4], inp[5])  # noqa: E731
+        else:
+            og = None
+            run_other = lambda: step(net, bucket, inp, scaler, other_ex)  # noqa: E731
+        for _ in range(2):
+            run_other()
+        other_ex.clear()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            run_other()
+        fence()
+        to = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(to, op=dist.ReduceOp.MAX)
+        oex = torch.tensor([sum(a.elapsed_time(b) for a, b in other_ex) / max(len(other_ex), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(oex, op=dist.ReduceOp.MAX)
+        del og
+        other = {"issued": "hip_graph_replay" if mode == "eager" else "eager", "value": round(world * w["batch"] * 5 / float(to.item()), 3),
+                 "unit": "pairs/s", "steps": 5, "ms_per_step": round(1e3 * float(to.item()) / 5, 3),
+                 "allreduce_exposed_ms": round(float(oex.item()), 3)}
+        dist_info = {"issued": mode, "other_issue_mode": other,
+                     "backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (plumbing test, not RCCL)"),
                      "rccl_ranks_seen": int(round(ones.item())), "world_size": world,
                      "allreduce_exposed_ms": round(float(ex.item()), 3),
                      "allreduce_exposed_what": "HIP events on the compute stream from the end of backward to the averaged bucket, mean "
-                                               "over the timed steps, max over ranks; the first two of the three bucket segments go out from "
-                                               "post-accumulate hooks during backward (rpnet_amd/parallel.py)",
+                                               "over the timed steps, max over ranks; eager: the first two of the three bucket segments go out "
+                                               "from post-accumulate hooks during backward (rpnet_amd/parallel.py); hip_graph_replay: the whole "
+                                               "bucket in one collective behind the replay",
                      "bucket_segments_mb": [round((bucket.bounds[i + 1] - bucket.bounds[i]) * 4 / 1e6, 1)
                                             for i in range(len(bucket.bounds) - 1)]}
     assert torch.isfinite(loss).item()
@@ -563,14 +600,15 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF):
             "net": net, "bucket": bucket, "inp": inp, "scaler": scaler, "cfg": cfg, "dist": dist_info, "fence": fence}
 
 
-def graphed_step(net, bucket, scaler):
-    """the bench step (same objective as `step`) as a rpnet_amd.graph.GraphedTrainStep"""
+def graphed_step(net, bucket, scaler, exposed=None):
+    """the bench step (same objective as `step`) as a rpnet_amd.graph.GraphedTrainStep (N > 1: the replay is followed by one
+    all-reduce of the whole bucket, bracketed by a HIP-event pair appended to `exposed`)"""
     from rpnet_amd.functional import dice_ce_sum
     from rpnet_amd.graph import GraphedTrainStep
 
     def loss_fn(out, ql):
         return dice_ce_sum([out["output"], *out["refinement"].values()], ql) + scaler * out["align_loss"]
-    return GraphedTrainStep(net, bucket, loss_fn)
+    return GraphedTrainStep(net, bucket, loss_fn, exposed=exposed)
 
 
 def graph_replay_leg(net, bucket, inp, scaler, batch, fence, steps):
@@ -661,6 +699,27 @@ def workload_text(w, world):
             f"({baseline_config(ns, world)}), train mode, align loss on, loss = dice_ce(output)+sum dice_ce(refinement)+align_loss")
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks ourselves — one process per GPU
+    through torch.distributed.run on 127.0.0.1 and a free port, exactly the line the driver uses — and hand its exit code
+    back; rank 0's JSON line is the only thing on stdout."""
+    import socket
+    import subprocess
+    backend = os.environ.get("RPNET_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this host shows {have} GPU(s); RCCL needs one device per rank "
+                         "(RPNET_DIST_BACKEND=gloo runs the ranks on the devices there are: plumbing only)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -682,17 +741,33 @@ def main():
                          "f16 = plain fp16 operands, configs[4] only)")
     args = ap.parse_args()
 
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    local_rank %= torch.cuda.device_count()   # > 1 rank per device only happens in the gloo plumbing test
+    if os.environ.get("RPNET_DIST_BACKEND", "nccl") == "nccl":
+        assert local_rank < torch.cuda.device_count(), f"LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s): RCCL needs one device per rank"
+    else:
+        local_rank %= torch.cuda.device_count()   # > 1 rank per device: only the gloo plumbing test
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RPNET_BENCH_FORCE_DIST=1 with --gpus 1: a process group of ONE rank, the gradient exchange forced on — the whole N > 1 code
+    # path of this file (hooks, segments, RCCL's stream, exposed-time events, the replay + all-reduce leg) on a single GPU
+    ddp = world > 1 or os.environ.get("RPNET_BENCH_FORCE_DIST", "0") == "1"
+    if ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("RPNET_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for 1-GPU plumbing tests
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                sock = socket.socket()
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+                sock.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -705,14 +780,14 @@ def main():
     w = {"ways": args.ways, "shots": args.shots, "size": args.size, "iters": args.iters, "batch": args.batch,
          "conv_math": args.conv_math or RF.conv_math()}
     headline = (args.ways, args.shots, args.size, args.iters, args.batch) == (1, 1, 256, 5, 8) and w["conv_math"] == "f16x2"
-    m = measure(w, world, rank, dev, cfg, args.steps, args.warmup, RF)
+    m = measure(w, world, rank, dev, cfg, args.steps, args.warmup, RF, ddp)
     math, requested, value = m["math"], m["requested"], m["value"]
     net, bucket, inp, scaler, fence = m["net"], m["bucket"], m["inp"], m["scaler"], m["fence"]
     cfg = m["cfg"]
 
     result = None
     alt = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not ddp and not args.no_cpu_baseline:
         # the same step under the other fp32-equivalent convolution arithmetics, for reference
         alt = {}
         for other in ("f32", "f16x2", "bf16x3"):
@@ -761,7 +836,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg, args.size, args.iters, net=net, bucket=bucket, dev=dev,
                                                   full=args.cpu_baseline_full)
             result["cpu_baseline"]["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
-    if world == 1 and headline and not args.no_other_configs:
+    if world == 1 and not ddp and headline and not args.no_other_configs:
         # the secondary BASELINE configurations that fit one GPU, timed by the same command (3 warm-up + 5 timed steps each,
         # their own roofline): configs[2] = 5-shot, batch 16; configs[4] = 2-way 512^2, T = 10, one fp16 plane, at its
         # per-GPU batch of 4 (global batch 32 across 8 GPUs)
@@ -781,7 +856,7 @@ def main():
             del om
             torch.cuda.empty_cache()
         RF.set_conv_math(requested)
-    if world > 1:
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

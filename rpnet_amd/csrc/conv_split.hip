@@ -935,15 +935,26 @@ static int halo4_tw(const rpnet_conv_desc* d) {
 int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int tw, int wn, hipStream_t s, int parts = 1, int bm = 256);
 int conv_splitk_parts(const rpnet_conv_desc* d, int M, int Cin, int Cout);
 
+// The LDS-DMA kernel (conv_split_dma.hip) reaches every operand through ONE buffer descriptor over all its planes, with 32-bit
+// byte offsets and num_records: a source's planes together, and the weight pack's, must stay below 2 GiB (64 channels at 512^2
+// from 32 images of two planes on would wrap, and the buffer rule would then return zeros instead of faulting).  Operands
+// beyond that take the register-staged kernels (variants 7 / 10 and below), whose addressing is 64-bit.
+static bool dma_addressable(const rpnet_conv_desc* d, int Cout) {
+    const size_t msrc = (size_t)d->N * (d->H >> d->upsample) * (d->W >> d->upsample);
+    const size_t np = d->split_planes > 0 ? d->split_planes : 1, lim = (size_t)1 << 31;
+    return np * msrc * d->C0 * 2 < lim && np * msrc * d->C1 * 2 < lim && np * 9 * (size_t)(d->C0 + d->C1) * Cout * 2 < lim;
+}
+
 // same rule as conv_igemm.hip: fewest idle block slots
 int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     const bool n128 = (Cout % 128 == 0) && (d->Co1 == 0 || d->Co0 % 128 == 0);
+    const bool addr = dma_addressable(d, Cout);
     if (d->tune > 0) {      // tuning / test override carried by the descriptor: tile variant d->tune - 1
         const int v = (d->tune & 0xff) - 1;      // bits 8..: ablation switches of conv_split_dma.hip
-        if ((v == 12 || v == 14) && d->split_planes == 2 && halo_tw(d, Cout)) return v;
-        if (v == 13 && d->split_planes == 1 && halo_tw(d, Cout) && halo_bn(d, Cout) == 128 && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0)
+        if ((v == 12 || v == 14) && d->split_planes == 2 && halo_tw(d, Cout) && addr) return v;
+        if (v == 13 && d->split_planes == 1 && halo_tw(d, Cout) && halo_bn(d, Cout) == 128 && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 && addr)
             return v;
-        if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2)) && halo_tw(d, Cout) &&
+        if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2 && addr)) && halo_tw(d, Cout) &&
              halo_bn(d, Cout) == 128) ||
             ((v == 8 || v == 9) && halo4_tw(d)))
             return v;
@@ -957,14 +968,14 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     // 4-wave form of it (wave tile 128 x 64, two blocks per CU) reads 25 % less per MFMA: 598 vs 531 TF on 128 -> 128 at
     // M = 262144, 767 vs 671 TF on 256 -> 256 at M = 65536 — once its grid fills both block slots of every CU
     // (round 3: where channel counts come in multiples of 64 the LDS-DMA kernel takes these layers — variant 13)
-    if (d->split_planes == 1 && !(d->tune & 0x10000) && hbn == 128 && halo_tw(d, Cout) && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 &&
+    if (d->split_planes == 1 && !(d->tune & 0x10000) && addr && hbn == 128 && halo_tw(d, Cout) && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 &&
         (long)(M / 256) * (Cout / 128) >= 192)
         return 13;
     if (d->split_planes == 1 && hbn == 128 && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 128) >= 512)
         return 10;
     // 256 x 128 patches, one block per CU: two fp16 planes -> the LDS-DMA kernel (conv_split_dma.hip: +14 ... 20 % over the
     // register-staged 8-wave kernel on every such layer, same bits); tune bit 16 = the round-2 policy (A/B switch)
-    const bool dma = d->split_planes == 2 && !(d->tune & 0x10000);
+    const bool dma = d->split_planes == 2 && !(d->tune & 0x10000) && addr;
     if (hbn == 128 && halo_tw(d, Cout) && (long)(M / 256) * (Cout / 128) >= (dma ? 192 : 224)) return dma ? 11 : 7;
     // grids too small for that: 256 x 64 tiles of the DMA kernel (twice the blocks; 419 vs 317 TF on 1024 -> 1024 at
     // M = 4096) from half a machine of blocks upwards
@@ -1001,7 +1012,7 @@ int split_tile_rows(int variant, int* wave_rows) {
 
 // split K (conv_split_dma.hip) when the caller lent a workspace and the launch is one of the half-empty ones
 static int splitk_parts_for(const rpnet_conv_desc* d, int M, int Cin, int Cout) {
-    if (!halo_tw(d, Cout)) return 1;
+    if (!halo_tw(d, Cout) || !dma_addressable(d, Cout)) return 1;
     return conv_splitk_parts(d, M, Cin, Cout);
 }
 

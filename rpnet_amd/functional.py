@@ -281,34 +281,51 @@ _EVAL_PREDICT = os.environ.get("RPNET_EVAL_PREDICT", "1") == "1"
 _PRED = {}
 
 
-def _pred_state(device):
-    st = _PRED.get(device)
+def _pred_dev(device):
+    """per device: the prediction records by call key, the record of the forward in progress, the tallies"""
+    pd = _PRED.get(device)
+    if pd is None:
+        pd = _PRED[device] = {"by_key": {}, "cur": None, "last_key": None, "calls": 0, "predicted_calls": 0, "violations": 0}
+    return pd
+
+
+def _pred_state(device, key):
+    """The record of ONE call shape (key = RP_Net.forward's pred_key: module, arithmetic, shapes, T): its predicted scales and
+    bounds, the violation flag its comparison launch writes, whether a captured graph owns a pending comparison.  Keyed, so
+    that two captured graphs (rpnet_amd.graph.GraphedEval of two shapes) or a graph beside eager calls of another shape never
+    run on each other's scales or trip over each other's flags."""
+    pd = _pred_dev(device)
+    st = pd["by_key"].get(key)
     if st is None:
-        st = _PRED[device] = {"scale": torch.zeros(_ABSMAX_SLOTS, device=device), "bound": torch.zeros(_ABSMAX_SLOTS, device=device),
-                              "viol": torch.zeros(1, device=device, dtype=torch.int32), "key": None, "n": 0, "active": False,
-                              "calls": 0, "predicted_calls": 0, "violations": 0, "pending": False}
+        st = pd["by_key"][key] = {"scale": torch.zeros(_ABSMAX_SLOTS, device=device), "bound": torch.zeros(_ABSMAX_SLOTS, device=device),
+                                  "viol": torch.zeros(1, device=device, dtype=torch.int32), "n": 0, "active": False, "pending": False}
     return st
 
 
 def pred_ready(device, key):
-    """does a history of this call shape exist (the previous eval call on this device had the same key)"""
-    st = _PRED.get(device)
-    return _EVAL_PREDICT and st is not None and st["key"] == key and st["n"] > 0
+    """does a history of this call shape exist (an earlier eval call on this device had the same key)"""
+    pd = _PRED.get(device)
+    st = pd["by_key"].get(key) if pd is not None else None
+    return _EVAL_PREDICT and st is not None and st["n"] > 0
 
 
 def pred_begin(device, key, allow=True):
-    """start of an eval-mode forward on fp16 planes (after reset_absmax_pool): predicted scales are used when the previous
+    """start of an eval-mode forward on fp16 planes (after reset_absmax_pool): predicted scales are used when an earlier
     call had this key and `allow` (False: the redo after a violation)"""
-    st = _pred_state(device)
-    st["active"] = bool(allow and pred_ready(device, key))
-    st["calls"] += 1
-    st["predicted_calls"] += int(st["active"])
+    pd = _pred_dev(device)
+    ready = pred_ready(device, key)
+    st = _pred_state(device, key)
+    st["active"] = bool(allow and ready)
+    pd["cur"] = st
+    pd["calls"] += 1
+    pd["predicted_calls"] += int(st["active"])
     return st["active"]
 
 
 def pred_scale(device):
     """the predicted scale (device scalar) of the absmax slot handed out last, or None when this call measures"""
-    st = _PRED.get(device)
+    pd = _PRED.get(device)
+    st = pd["cur"] if pd is not None else None
     pool = _ABSMAX.get(device)
     if st is None or not st["active"] or pool is None or pool[1] > st["n"]:
         return None
@@ -319,8 +336,10 @@ def pred_end(device, key):
     """end of that forward: one launch compares the measured maxima with the bounds the call ran with (when it ran on
     predictions) and turns them into the next call's predictions.  Returns True when the call must be redone on measured
     scales (a maximum exceeded its predicted bound).  Inside a stream capture the comparison is recorded but not read:
-    pred_check_pending() reads it after the replay."""
-    st = _pred_state(device)
+    pred_check_pending(device, key) reads it after the replay."""
+    pd = _pred_dev(device)
+    st = _pred_state(device, key)
+    pd["cur"], pd["last_key"] = None, key
     pool = _ABSMAX.get(device)
     n = pool[1] if pool is not None else 0
     ran_predicted = st["active"]
@@ -328,42 +347,52 @@ def pred_end(device, key):
         raise RuntimeError(f"rpnet_amd: an eval call of key {key} took {n} absmax slots, its predecessor {st['n']}")
     st["active"] = False
     if n == 0:
-        st["key"], st["n"] = None, 0
+        st["n"] = 0
         return False
     if ran_predicted:
         st["viol"].zero_()
     call("rpnet_predict_scales", ptr(pool[0]), ptr(st["bound"]), ptr(st["scale"]), n, PRED_SAFETY, 1 if ran_predicted else 0,
          ptr(st["viol"]))
-    st["key"], st["n"] = key, n
+    st["n"] = n
     if not ran_predicted:
         return False
     if torch.cuda.is_current_stream_capturing():
-        st["pending"] = True
+        st["pending"] = True       # stays set: EVERY replay of that graph ran on predictions and has to be checked
         return False
     bad = int(st["viol"].item()) > 0
-    st["violations"] += int(bad)
+    pd["violations"] += int(bad)
     if bad:
-        st["key"], st["n"] = None, 0         # the redo measures and rebuilds the history
+        st["n"] = 0                # the redo measures and rebuilds the history
     return bad
 
 
-def pred_check_pending(device):
-    """after replaying a captured eval forward that ran on predicted scales: did a maximum exceed its bound"""
-    st = _PRED.get(device)
+def pred_last_key(device):
+    """the key of the eval forward that ended last on this device (GraphedEval remembers it with its captured graph)"""
+    pd = _PRED.get(device)
+    return pd["last_key"] if pd is not None else None
+
+
+def pred_check_pending(device, key=None):
+    """after replaying a captured eval forward of call key `key` that ran on predicted scales: did a maximum exceed its bound
+    (the replay itself zeroed the flag and ran the comparison: the flag read here is this replay's)"""
+    pd = _PRED.get(device)
+    if pd is None:
+        return False
+    st = pd["by_key"].get(key if key is not None else pd["last_key"])
     if st is None or not st["pending"]:
         return False
     bad = int(st["viol"].item()) > 0
-    st["violations"] += int(bad)
+    pd["violations"] += int(bad)
     return bad
 
 
 def pred_stats(device=None):
     """{calls, predicted_calls, violations} of the eval-mode fp16 prediction (all devices summed when device is None)"""
     out = {"calls": 0, "predicted_calls": 0, "violations": 0}
-    for dv, st in _PRED.items():
+    for dv, pd in _PRED.items():
         if device is None or dv == device:
             for k in out:
-                out[k] += st[k]
+                out[k] += pd[k]
     return out
 
 
@@ -629,6 +658,20 @@ class WeightCache:
                 it.cout, it.cin, it.taps = pw.cout, pw.cin, pw.taps
                 it.cin_off0, it.cin_split, it.cin_off1, it.cin_pad = pw.off0, pw.split, pw.off1, pw.cin_pad
             call("rpnet_pack_conv_weights_split", items, len(chunk), planes)
+
+
+    def materialize(self, weights, planes):
+        """Make every pack the layers of `weights` will read EXIST NOW, on the current stream (split packs of `planes`
+        planes, or the fp32 packs when planes == 0; layers prepack() already served cost nothing).  RP_Net.forward calls
+        this before it forks the encoder's two chains onto two streams: a pack made lazily by the first chain's launch would
+        be ordered on that chain's stream only, and the other chain — which gets the same cached PackedWeight — could read
+        the freshly allocated buffer before the pack kernel has run."""
+        for w in weights:
+            pw = self.get(w)
+            if planes and pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0 and pw.cout % 32 == 0:
+                pw.split_packs(planes)
+            else:
+                pw.wp      # noqa: B018 (the property packs on first use)
 
 
 # tuning / test override of the kernel variant, carried by every descriptor (rpnet_conv_desc.tune): 0 = the library's
@@ -917,10 +960,15 @@ class ConvBnRelu(Function):
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             deferred = None
             if _direct(weight):
+                # the stream this backward node runs on (the one that produced dy and will run this layer's dgrad), taken NOW:
+                # a deferred launch may be released by a later node that runs on another stream (the CRE's second branch, the
+                # encoder's second chain), and must still wait for THIS one
+                prod = torch.cuda.current_stream(y.device)
+
                 def launch_async():
                     dev = y.device
-                    side, main = _side_stream(dev), torch.cuda.current_stream(dev)
-                    side.wait_stream(main)                   # dy, x are ready on the main stream (deferred: and the dgrad is done)
+                    side, main = _side_stream(dev), prod
+                    side.wait_stream(main)                   # dy, x are ready on the producing stream (deferred: and the dgrad is done)
                     d.accumulate = 1
                     with torch.cuda.stream(side):
                         ws2 = _ws(wb, y)

@@ -35,7 +35,9 @@ class GraphedEval:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
             out = self.net([[static[0]]], [[static[1]]], [[static[2]]], [static[3]], appr_query_labels=static[4])
-        self._graphs[key] = (g, static, out)
+        from . import functional as RF
+        # the key of the captured forward's fp16 scale prediction (RF.pred_*): the replay checks ITS record, not another graph's
+        self._graphs[key] = (g, static, out, RF.pred_last_key(si.device) if RF.f16_mode() else None)
         return self._graphs[key]
 
     def __call__(self, supp_imgs, fore_mask, back_mask, qry_imgs, registration_field=None, grid=None,
@@ -46,12 +48,12 @@ class GraphedEval:
                 appr_query_labels.float())
         key = tuple(args[0].shape)
         entry = self._graphs.get(key) or self._capture(key, *args)
-        g, static, out = entry
+        g, static, out, pkey = entry
         for dst, src in zip(static, args):
             dst.copy_(src)
         g.replay()
         from . import functional as RF
-        if RF.pred_check_pending(args[0].device):
+        if pkey is not None and RF.pred_check_pending(args[0].device, pkey):
             # the captured forward runs on fp16 scales predicted from the previous call (RF.pred_*); a maximum above its
             # predicted bound invalidates this replay: redo the call eagerly on measured scales (the replay has already
             # turned the new maxima into the next replay's predictions)
@@ -75,11 +77,16 @@ class GraphedTrainStep:
     Usage:
         g = GraphedTrainStep(net, bucket, loss_fn)          # loss_fn(out, labels) -> scalar tensor
         loss = g(supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels)   # replays; gradients in bucket.flat
-    Inputs are copied into static buffers; the returned loss is a static tensor (clone it to keep it).  Single process
-    only: with a process group the bucket's all-reduce is issued by the caller after the replay (bucket.allreduce())."""
+    Inputs are copied into static buffers; the returned loss is a static tensor (clone it to keep it).  With a process
+    group the captured step contains NO collective (the bucket's post-accumulate hooks are suspended while it is captured):
+    the replay is followed by `bucket.allreduce()` — one all-reduce of the whole flat bucket on the collective library's
+    stream, exposed behind the step instead of overlapped with backward (what eight eager Python processes on one shared
+    host trade for one graph launch per step each).  `exposed`: a list that receives a HIP-event pair around that
+    exchange (bench.py)."""
 
-    def __init__(self, net, bucket, loss_fn, warmup=2):
+    def __init__(self, net, bucket, loss_fn, warmup=2, exposed=None):
         self.net, self.bucket, self.loss_fn, self.warmup = net, bucket, loss_fn, warmup
+        self.exposed = exposed
         self._graphs = {}
 
     @staticmethod
@@ -88,12 +95,17 @@ class GraphedTrainStep:
 
     def _run(self, st):
         si, fg, bg, qi, ql, appr = st
-        self.bucket.zero()
-        out = self.net(si, fg, bg, qi, appr_query_labels=appr)
-        loss = self.loss_fn(out, ql)
-        loss.backward()
-        from . import functional as RF
-        RF.join_side_streams()           # the weight gradients of the side streams land before the graph ends
+        was = self.bucket.hooks_enabled
+        self.bucket.hooks_enabled = False      # no collective inside the captured step
+        try:
+            self.bucket.zero()
+            out = self.net(si, fg, bg, qi, appr_query_labels=appr)
+            loss = self.loss_fn(out, ql)
+            loss.backward()
+            from . import functional as RF
+            RF.join_side_streams()           # the weight gradients of the side streams land before the graph ends
+        finally:
+            self.bucket.hooks_enabled = was
         return loss.detach()
 
     def _capture(self, key, args):
@@ -125,4 +137,14 @@ class GraphedTrainStep:
         st[4].copy_(labels)
         st[5].copy_(appr_query_labels)
         g.replay()
+        if self.bucket._active():            # the gradient exchange behind the replay (sum over ranks, 1 / world)
+            self.bucket._work = {}
+            if self.exposed is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.bucket.allreduce()
+                b.record()
+                self.exposed.append((a, b))
+            else:
+                self.bucket.allreduce()
         return loss

@@ -8,6 +8,7 @@ children are parameter containers only — they are never called.
 
 Internal activation layout is NHWC; NCHW tensors appear only at the module boundary.
 """
+import itertools
 import os
 
 import torch
@@ -44,6 +45,7 @@ _CRE_STREAMS_TRAIN = os.environ.get("RPNET_CRE_STREAMS_TRAIN", "1") == "1"
 # query chain ends after a fifth of the support chain) 84.3 -> 85.0 ms; configs[1] in two half-size launches per layer
 # 17.95 -> 18.54 ms (the 16^2 / 32^2 levels no longer fill the machine) — hence the default
 _ENC_STREAMS = int(os.environ.get("RPNET_ENC_STREAMS", "1"))
+_NET_SERIAL = itertools.count(1)      # a never-reused number per RP_Net instance (id() is reused after garbage collection)
 
 
 def _to_nhwc(x):
@@ -422,6 +424,7 @@ class RP_Net(nn.Module):
             raise NotImplementedError("scale != 4: the UNet d4 map is 1/4 resolution")
         self.cre = ContextCorrelationEncoder(backbone_cfg, in_channels=num_feat)
         self._cache = RF.WeightCache()
+        self._serial = next(_NET_SERIAL)      # part of the key of this module's eval-mode fp16 scale history (RF.pred_*)
 
     # ---------------------------------------------------------------- forward
     def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, registration_field=None, grid=None,
@@ -451,7 +454,7 @@ class RP_Net(nn.Module):
         if RF.f16_mode():
             RF.reset_absmax_pool(supp.device)       # measured fp16 scales (eval-mode layers, the correlation): one fill per forward
             if not self.training and not torch.is_grad_enabled() and RF._EVAL_PREDICT:
-                pred_key = (id(self), RF.conv_math(), ns, B, H, W, self.num_iter, n_ways, n_shots, self.forced_masks is not None)
+                pred_key = (self._serial, RF.conv_math(), ns, B, H, W, self.num_iter, n_ways, n_shots, self.forced_masks is not None)
                 RF.pred_begin(supp.device, pred_key, allow=not getattr(self, "_pred_redo", False))
         planes = RF.pack_planes()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
@@ -478,6 +481,10 @@ class RP_Net(nn.Module):
         elif two_chains:
             main, side = torch.cuda.current_stream(supp.device), RF._cre_stream(supp.device)
             qin = qry.reshape(B, H, W, 1)
+            # both chains read the SAME cached packs: whatever the prepack above did not make (fp32 arithmetic, RPNET_PREPACK=0)
+            # is made here, on the main stream, in front of the fork
+            cache.materialize([w for w in self._pack_weights() if w is not self.cre.w_k[0].weight and w is not self.cre.w_q[0].weight],
+                              planes)
             side.wait_stream(main)
             o_s = self.encoder.forward_nhwc(supp.reshape(ns, H, W, 1), cache)
             with torch.cuda.stream(side):

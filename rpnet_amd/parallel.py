@@ -8,6 +8,8 @@ reference), so the only exchange is the gradient sum.  Parameters that never rec
 gradient (cre.w_context.*, cre.out.*: constructed but unused, net/rp_net.py:60-64,70-74)
 are left out of the buffer: 34 808 000 of the 34 972 800 parameters travel (139.2 MB).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,9 +30,17 @@ class FlatGradBucket:
     All are plain sums over identical buffers on every rank, so results do not depend on the overlap.
     """
 
-    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES, split_at=("encoder.Conv5.", "encoder.Up5.")):
+    def __init__(self, module, skip_prefixes=UNUSED_PREFIXES, split_at=("encoder.Conv5.", "encoder.Up5."), force_active=None):
+        """force_active: run the exchange code (hooks, segments, collectives, the 1/world scaling) also in a process group of
+        ONE rank — the RCCL path (backend "nccl": its own stream, the event it records on the caller's current stream at call
+        time, work.wait() back onto the compute stream) can then be exercised on a single GPU, where its result must equal
+        the non-distributed step bit for bit (tests/test_gpu_dist.py); default: the RPNET_BUCKET_FORCE environment switch"""
         if isinstance(split_at, str):
             split_at = (split_at,)
+        self.force_active = (os.environ.get("RPNET_BUCKET_FORCE", "0") == "1") if force_active is None else bool(force_active)
+        # False while a step is being captured into a HIP graph (rpnet_amd.graph.GraphedTrainStep): the hooks then launch
+        # nothing, the caller exchanges the whole bucket after the replay
+        self.hooks_enabled = True
         self.params = [(n, p) for n, p in module.named_parameters()
                        if p.requires_grad and not n.startswith(tuple(skip_prefixes))]
         total = sum(p.numel() for _, p in self.params)
@@ -67,12 +77,12 @@ class FlatGradBucket:
         self._tail_work = None
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_active)
 
     def _launcher(self, seg):
         def launch(_param=None):
             # segments finish back to front; launch this one and any later one that has not gone out yet
-            if not self._active():
+            if not self._active() or not self.hooks_enabled:
                 return
             from .functional import join_side_streams
             join_side_streams()      # async weight gradients of the segment must have landed in the bucket
@@ -100,9 +110,12 @@ class FlatGradBucket:
         join_side_streams()          # also in single-process runs: the optimizer step reads the bucket next
         if not self._active():
             return None
-        for s in range(len(self.bounds) - 1):             # whatever has not been launched during backward
-            if s not in self._work:
-                dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM)
+        if not self._work:                                # nothing went out during backward (a replayed HIP graph): ONE collective
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        else:
+            for s in range(len(self.bounds) - 1):         # whatever has not been launched during backward
+                if s not in self._work:
+                    dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM)
         for w in self._work.values():
             w.wait()
         self._work = {}

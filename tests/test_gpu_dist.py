@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIZE, T, GLOBAL_B = 64, 2, 4
 
 
-def _setup_model():
+def _setup_model(force_active=None, T_=None):
     import rpnet_amd.functional as RF
     import rpnet_amd.modules as RM
     from rpnet_amd.modules import RP_Net
@@ -26,11 +26,11 @@ def _setup_model():
     RM._F16_MIN_PIXELS = 0
     RF.set_conv_math("f16x2")
     RF.set_async_wgrad(True)
-    cfg = load_cfg(T)
+    cfg = load_cfg(T_ or T)
     net = RP_Net(cfg={"align": True, "backbone": "UNet"}, backbone_cfg=cfg).to("cuda:0")
     seed_module_(net)
     net.train()
-    return net, FlatGradBucket(net), cfg
+    return net, FlatGradBucket(net, force_active=force_active), cfg
 
 
 def _shard_step(net, bucket, cfg, lo, hi):
@@ -104,12 +104,106 @@ def test_two_rank_rp_net_bucket_on_one_gpu():
     assert float(want.abs().max()) > 0
 
 
+def _nccl_world1_worker(port, q, ways, size, B, T_):
+    """ONE rank, backend nccl (= RCCL) on cuda:0, the bucket's exchange forced on: the real step — async weight gradients on
+    the side streams, the CRE's second branch (and for 2-way the encoder's second chain) on their own stream, the
+    three-segment exchange launched from post-accumulate hooks in autograd's thread — meets RCCL's stream semantics (the
+    collective runs on RCCL's own stream behind an event recorded on the caller's CURRENT stream at call time; work.wait()
+    orders the compute stream behind it).  A sum over one rank times 1/1 changes no bit, so the bucket must EQUAL the
+    non-distributed step's, every time (five repetitions: a missing stream dependency is a race, not a constant)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    assert dist.get_backend() == "nccl"
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    from rpnet_amd.functional import dice_ce
+    from rpnet_amd.graph import GraphedTrainStep
+    from tests.helpers import episode_tensors
+    net, bucket, cfg = _setup_model(force_active=True, T_=T_)
+    assert RM._CRE_STREAMS_TRAIN and RF._ASYNC["on"] and RF._WGRAD_DEFER >= 1
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(910, B, size, "cuda:0", n_ways=ways)
+
+    def loss_fn(out, lab):
+        loss = dice_ce(out["output"], lab)
+        for v in out["refinement"].values():
+            loss = loss + dice_ce(v, lab)
+        return loss + cfg["align_loss_scaler"] * out["align_loss"]
+
+    def one(active):
+        bucket.force_active = active
+        bucket.zero()
+        loss_fn(net(si, fg, bg, qi, appr_query_labels=appr), ql).backward()
+        launched = sorted(bucket._work)
+        bucket.allreduce()
+        torch.cuda.synchronize()
+        return launched, bucket.flat.clone()
+
+    one(False)                                   # warm-up (allocator, lazy initialisation)
+    _, want = one(False)
+    _, again = one(False)
+    res = {"deterministic": bool(torch.equal(want, again)), "nonzero": float(want.abs().max()) > 0, "equal": [], "launched": []}
+    for _ in range(5):
+        launched, got = one(True)
+        res["launched"].append(launched)
+        res["equal"].append(bool(torch.equal(got, want)))
+    # the same step replayed from a HIP graph with the exchange behind the replay (no collective inside the capture)
+    bucket.force_active = True
+    gts = GraphedTrainStep(net, bucket, loss_fn)
+    res["graph_equal"] = []
+    for _ in range(3):
+        gts(si, fg, bg, qi, ql, appr)
+        torch.cuda.synchronize()
+        res["graph_equal"].append(bool(torch.equal(bucket.flat, want)))
+    ones = torch.ones(4, device="cuda:0")
+    dist.all_reduce(ones)
+    res["ranks_seen"] = float(ones[0])
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ways,size,B,T_", [(1, 128, 4, 2), (2, 64, 2, 2)])
+def test_rccl_world1_bucket_equals_plain_step(ways, size, B, T_):
+    """RCCL's first contact with the side streams (one GPU is enough: a process group of one rank, FlatGradBucket(force_active=True))."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(39500 + os.getpid() % 2000 + ways, q, ways, size, B, T_))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res["deterministic"] and res["nonzero"], res
+    assert all(l == [1, 2] for l in res["launched"]), res      # both early segments left from the hooks, during backward
+    assert all(res["equal"]), res
+    assert all(res["graph_equal"]), res
+    assert res["ranks_seen"] == 1.0
+
+
+def test_bench_forced_rccl_group_on_one_gpu():
+    """bench.py with RPNET_BENCH_FORCE_DIST=1: a one-rank RCCL group, the exchange forced on — the line's `distributed` object
+    is then produced by the N > 1 code (backend nccl, exposed time by HIP events, both ways of issuing the step)."""
+    env = dict(os.environ, RPNET_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RPNET_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "128",
+           "--iters", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d = res["distributed"]
+    assert d["backend"].startswith("nccl") and d["rccl_ranks_seen"] == 1 and d["allreduce_exposed_ms"] >= 0
+    assert {d["issued"], d["other_issue_mode"]["issued"]} == {"eager", "hip_graph_replay"} and d["other_issue_mode"]["value"] > 0
+
+
 def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N > 1 code path end to end (rendezvous, sharded seeds, barrier-fenced timing, max over ranks, every
-    rank in the profiled step's collective) with two gloo ranks on the one GPU; small shapes."""
+    """bench.py's N > 1 code path end to end (SELF-LAUNCHED: `python bench.py --gpus 2` with no rendezvous in the environment
+    starts its own ranks; sharded seeds, barrier-fenced timing, max over ranks, every rank in the profiled step's
+    collective) with two gloo ranks on the one GPU; small shapes."""
     env = dict(os.environ, RPNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(35500 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "2", "--size", "128", "--iters", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -121,6 +215,9 @@ def test_bench_two_ranks_on_one_gpu():
     dinfo = res["distributed"]
     assert dinfo["rccl_ranks_seen"] == 2 and dinfo["world_size"] == 2 and dinfo["backend"].startswith("gloo")
     assert dinfo["allreduce_exposed_ms"] >= 0 and len(dinfo["bucket_segments_mb"]) == 3
+    # both ways of issuing the step are in the line: eager + overlapped exchange, graph replay + one exposed all-reduce
+    assert {dinfo["issued"], dinfo["other_issue_mode"]["issued"]} == {"eager", "hip_graph_replay"}
+    assert dinfo["other_issue_mode"]["value"] > 0
 
 
 def _train_worker(rank, world, port, q):

@@ -573,18 +573,25 @@ def test_two_way_extension_vs_composed_oracle():
         assert (a - b).norm() < 5e-3 * b.norm(), n
 
 
-@pytest.mark.parametrize("async_wgrad", [False, True])
-def test_encoder_two_chains_match_one_stream(async_wgrad):
+@pytest.mark.parametrize("async_wgrad,math,prepack", [(False, "f16x2", True), (True, "f16x2", True), (True, "f32", True),
+                                                        (True, "f16x2", False), (False, "bf16x3", False)])
+def test_encoder_two_chains_match_one_stream(async_wgrad, math, prepack):
     """2-way (support call: 2 B images, query call: B): the encoder's two calls as two chains on two HIP streams, their
     BatchNorm modules' running statistics and parameter gradients ordered by events (RF.order_begin), against the same
     step on one stream: same kernels in the same order per buffer -> logits, every gradient and every BatchNorm buffer
-    bit-identical; with and without the weight gradients on their side stream, two runs of the two-chain step"""
+    bit-identical; with and without the weight gradients on their side stream, two runs of the two-chain step.
+    Also under the arithmetics / switches in which NO prepack launch makes the weight packs up front (fp32 kernels,
+    RPNET_PREPACK=0): both chains share the cached packs, which RP_Net.forward then materialises in front of the fork
+    (WeightCache.materialize) — a pack made lazily on one chain's stream would be a race for the other."""
     import rpnet_amd.functional as RF
     import rpnet_amd.modules as RM
     from rpnet_amd.parallel import FlatGradBucket
     cfg = load_cfg(2)
     (si, fg, bg, qi, ql, appr), _ = episode_tensors(91, 4, 128, DEV, n_shots=1, n_ways=2)
-    was = RM._ENC_STREAMS
+    was, was_pp = RM._ENC_STREAMS, RM._PREPACK
+    RF.set_conv_math(math)
+    RM._F16_MIN_PIXELS = 0
+    RM._PREPACK = prepack
     res = []
     try:
         for enc in (0, 1, 1):
@@ -602,7 +609,7 @@ def test_encoder_two_chains_match_one_stream(async_wgrad):
             res.append((out["output"].detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
                         {n: b.clone() for n, b in net.named_buffers()}))
     finally:
-        RM._ENC_STREAMS = was
+        RM._ENC_STREAMS, RM._PREPACK = was, was_pp
         RF.set_async_wgrad(False)
     for other in res[1:]:
         assert torch.equal(res[0][0], other[0])

@@ -122,7 +122,17 @@ def _ddp_worker3(rank, world, port, q):
     net(xs[lo:hi]).square().sum().backward()
     launched = sorted(bucket._work)                          # segments 2 and 1 went out during backward, 0 is left
     bucket.allreduce()
-    q.put((rank, launched, bucket.flat.clone()))
+    first = bucket.flat.clone()
+    # the graph-replay form of the step (rpnet_amd.graph.GraphedTrainStep under a process group): hooks suspended, nothing
+    # goes out during backward, ONE collective over the whole bucket behind it — the same averaged gradients
+    bucket.hooks_enabled = False
+    bucket.zero()
+    net(xs[lo:hi]).square().sum().backward()
+    assert not bucket._work
+    bucket.allreduce()
+    bucket.hooks_enabled = True
+    assert torch.equal(bucket.flat, first)
+    q.put((rank, launched, first))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -213,3 +223,51 @@ def test_deferred_weight_gradient_queue_order():
         st["fifo"][:] = saved[1]
         st["pending"].clear()
         st["pending"].update(saved[2])
+
+
+def test_gradient_bucket_forced_one_rank_group():
+    """FlatGradBucket(force_active=True) in a process group of ONE rank (what tests/test_gpu_dist.py uses to put RCCL's stream
+    semantics under the real step on a single GPU): hooks fire, segments go out, sum x 1/1 — the same bits as no exchange"""
+    import torch.distributed as dist
+    from rpnet_amd.parallel import FlatGradBucket
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(27500 + os.getpid() % 2000))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+        xs = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+        bucket = FlatGradBucket(net, skip_prefixes=(), split_at=("2.", "4."), force_active=False)
+        bucket.zero()
+        net(xs).square().sum().backward()
+        assert not bucket._work and bucket.allreduce() is None
+        want = bucket.flat.clone()
+        bucket.force_active = True
+        bucket.zero()
+        net(xs).square().sum().backward()
+        assert sorted(bucket._work) == [1, 2]
+        bucket.allreduce()
+        assert torch.equal(bucket.flat, want) and float(want.abs().max()) > 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dma_kernels_not_chosen_beyond_their_32_bit_range():
+    """The LDS-DMA convolution kernel addresses a source through one buffer descriptor with 32-bit offsets (all planes
+    below 2 GiB); the tile policy (a host function: no GPU needed) must hand larger operands to the register-staged kernels
+    instead of letting the offsets wrap — and keep choosing the DMA kernel below the limit."""
+    import ctypes as C
+    from rpnet_amd import hip
+    lib = hip.load()
+
+    def variant(N, H, W, cin, cout, planes, tune=0):
+        d = hip.ConvDesc()
+        d.N, d.H, d.W, d.C0, d.C1, d.Co0, d.Co1, d.taps, d.split_planes, d.groups, d.tune = N, H, W, cin, 0, cout, 0, 9, planes, 1, tune
+        return lib.rpnet_conv_tile_variant(C.byref(d))
+
+    assert variant(8, 256, 256, 128, 128, 2) == 11 and variant(8, 128, 128, 256, 256, 1) == 13     # the step's own layers
+    assert variant(16, 512, 512, 64, 128, 2) == 11                  # two planes of 512 MiB: addressable
+    assert variant(32, 512, 512, 64, 128, 2) == 7                   # two planes of 1 GiB = 2^31 bytes: the register-staged patch kernel
+    # 64 images of 512^2 x 64 channels: two planes = 4 GiB, one plane = 2 GiB -> no DMA variant, forced or not
+    for planes in (2, 1):
+        for tune in (0, 12, 13, 14):
+            assert variant(64, 512, 512, 64, 128, planes, tune) not in (11, 12, 13, 14), (planes, tune)

@@ -116,7 +116,16 @@ def main():
     a = ap.parse_args()
     config, _ = load_yaml(a.yaml)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("train_rpnet.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RPNET_DIST_BACKEND", "nccl") == "nccl":
+        if local_rank >= n_dev:      # RCCL hangs / fails with a duplicate-device error when two ranks share a GPU
+            raise SystemExit(f"LOCAL_RANK {local_rank} but {n_dev} GPU(s): RCCL needs one device per rank "
+                             "(RPNET_DIST_BACKEND=gloo: several ranks per device, plumbing tests only)")
+    else:
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
