@@ -549,6 +549,44 @@ def test_eval_driver_over_nrrd_volumes(tmp_path):
     assert sorted(ref["Liver"].keys()) == list(range(10)) and few["Liver"] == list(ref["Liver"][9])
 
 
+def test_reference_driver_launcher(tmp_path):
+    """tools/run_reference_driver.py: a driver script with the two lines that stop the reference's literal test_rpnet.py on a
+    one-GPU ROCm box — `os.environ['CUDA_VISIBLE_DEVICES'] = '1'` in front of `import torch` (:3) and the tensorboard import
+    (:27) — still sees the GPU and runs the evaluation loop on the HIP path when started through the launcher."""
+    import subprocess
+    import sys
+    script = tmp_path / "driver_like_the_reference.py"
+    script.write_text(
+        "import os\n"
+        "os.environ['CUDA_VISIBLE_DEVICES'] = '1'\n"
+        "import torch\n"
+        "from torch.utils.tensorboard import SummaryWriter\n"
+        "from net.model import model_factory\n"
+        "from dataset.few_shot_reader import FewshotRegReader\n"
+        "from utils.util import load_yaml\n"
+        "from tools.eval_driver import evaluate\n"
+        "import sys\n"
+        "config, args = load_yaml(sys.argv[1])\n"
+        "config['n_iter_refinement'] = 2\n"
+        "assert torch.cuda.device_count() >= 1, 'the device mask took effect'\n"
+        "w = SummaryWriter('runs'); w.add_scalar('x', 1.0, 0); w.close()\n"
+        "ds = FewshotRegReader('/nonexistent', config['eval_set_name'], config, mode='eval', n_volumes=2, n_slices=4, size=64)\n"
+        "net = model_factory['RP_Net'](pretrained_path=None, cfg={'align': True, 'backbone': 'UNet'}, backbone_cfg=config).cuda()\n"
+        "net.eval()\n"
+        "aff, few, ref = evaluate(net, ds, config, n_items=1)\n"
+        "print('DRIVER_OK', len(few['Liver']))\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_reference_driver.py"), str(script),
+                        os.path.join(root, "yamls", "example.yml")], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and "DRIVER_OK 1" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    # and WITHOUT the launcher the same script loses the device (this is what the literal file does on a one-GPU box)
+    env = dict(os.environ, PYTHONPATH=root)
+    r2 = subprocess.run([sys.executable, str(script), os.path.join(root, "yamls", "example.yml")], capture_output=True, text=True,
+                        timeout=900, cwd=str(tmp_path), env=env)
+    assert r2.returncode != 0
+
+
 def test_two_way_extension_vs_composed_oracle():
     """BASELINE config 5 shape class (2-way, fp32 here): no reference behaviour; oracle composed from the
     reference's own pieces, incl. gradients of the well-conditioned CRE block and the align loss."""

@@ -271,3 +271,18 @@ def test_dma_kernels_not_chosen_beyond_their_32_bit_range():
     for planes in (2, 1):
         for tune in (0, 12, 13, 14):
             assert variant(64, 512, 512, 64, 128, planes, tune) not in (11, 12, 13, 14), (planes, tune)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/test_rpnet.py"), reason="the reference is mounted in the build container only")
+def test_literal_reference_driver_reaches_the_model_through_the_launcher():
+    """The UNMODIFIED /root/reference/test_rpnet.py under tools/run_reference_driver.py with this repository on the path: its
+    imports (:11-32, incl. tensorboard at :27, absent here), yaml loading, reader construction and model_factory call all
+    resolve to this repository and run; without a GPU it stops exactly at `net = net.cuda()` (:82)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RPNET_DRIVER_ALLOW_NO_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_driver.py"), "/root/reference/test_rpnet.py",
+                        "--yaml", os.path.join(ROOT, "yamls", "example.yml")], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode != 0 and "No HIP GPUs are available" in r.stderr, r.stderr[-1500:]
+    assert "net = net.cuda()" in r.stderr and "no-op torch.utils.tensorboard.SummaryWriter registered" in r.stderr
+    assert "ModuleNotFoundError" not in r.stderr and "ImportError" not in r.stderr
