@@ -120,7 +120,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # Under a process group on RCCL the collective library's watchdog THREAD polls its events (hipEventQuery) at any time;
+        # in the default (global) capture mode that call from another thread is an error while this thread captures and takes
+        # the process down ("operation not permitted when stream is capturing").  Thread-local mode restricts only this thread.
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             loss = self._run(st)
         self._graphs[key] = (g, st, loss)
         return self._graphs[key]

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -77,7 +78,8 @@ def _ddp_worker(rank, world, port, q):
     skipped = net[1].bias.grad.clone()
     assert bucket._tail_work is not None                     # the hook fired during backward: tail all-reduce in flight
     bucket.allreduce()
-    q.put((rank, lo, hi, bucket.flat.clone(), net[0].weight.detach().clone(), skipped, bucket.numel))
+    # by value (numpy): a torch tensor travels as a shared-memory handle the parent can no longer open once the worker is gone
+    q.put((rank, lo, hi, bucket.flat.numpy().copy(), net[0].weight.detach().numpy().copy(), skipped.numpy().copy(), bucket.numel))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,6 +94,7 @@ def test_gradient_bucket_allreduce_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
+    res = [tuple(torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in t) for t in res]
     (r0, lo0, hi0, f0, w0, s0, n0), (r1, lo1, hi1, f1, w1, s1, n1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 8)
     assert torch.equal(w0, w1)                               # broadcast replicated the weights
@@ -132,7 +135,7 @@ def _ddp_worker3(rank, world, port, q):
     bucket.allreduce()
     bucket.hooks_enabled = True
     assert torch.equal(bucket.flat, first)
-    q.put((rank, launched, first))
+    q.put((rank, launched, first.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -149,7 +152,7 @@ def test_gradient_bucket_three_segments_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (_, l0, f0), (_, l1, f1) = res
+    (_, l0, f0), (_, l1, f1) = [(r, l, torch.from_numpy(f)) for r, l, f in res]
     assert l0 == [1, 2] and l1 == [1, 2]
     assert torch.equal(f0, f1)
     torch.manual_seed(0)
