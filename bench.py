@@ -115,6 +115,35 @@ def step(net, bucket, inp, scaler, exposed=None):
     return loss
 
 
+def fp16_trained_dice_leg(dev, RF):
+    """north_star's "<= 1e-3 Dice deviation" for the fp16 configuration, measured and put in the line: 150 Adam steps of
+    train_rpnet.train on synthetic 2-way 512^2 episodes (T = 10, batch 4, f16x2), then configs[4]'s call free-running (every
+    iteration on the loop's own thresholded mask) under the one-plane f16 arithmetic and under the fp32-equivalent f16x2:
+    largest per-iteration deviation of Dice / foreground fraction, train-mode and eval-mode BatchNorm (tools/trained_f16_dice.py)."""
+    import rpnet_amd.modules as RM
+    import tools.trained_f16_dice as TD
+    was = (RF.conv_math(), RM._F16_MIN_PIXELS, RF._ASYNC["on"])
+    cur = torch.cuda.current_stream(dev)
+    try:
+        net, hist = TD.train_weights(150, 512, 1e-4, dev, n_ways=2, iters=10)
+        out = {"trained": {"steps": 150, "size": 512, "ways": 2, "T": 10, "batch": 4, "arithmetic": "f16x2", "first_loss": round(hist[0], 3),
+                           "last_loss": round(hist[-1], 3)}, "bar": 1e-3}
+        for mode in (True, False):
+            res = TD.free_running(net, TD.CASES["configs4_2way_512_T10_B4"], dev, mode)
+            dd, df = TD.deviations(res)
+            out["train_mode" if mode else "eval_mode"] = {"max_dice_dev": float(f"{max(dd):.3g}"), "max_fg_frac_dev": float(f"{max(df):.3g}"),
+                                                         "dice_f16x2": [round(a[0], 4) for a in res["f16x2"]]}
+        out["within_bar"] = all(out[k]["max_dice_dev"] <= 1e-3 for k in ("train_mode", "eval_mode"))
+        del net
+    finally:
+        RF.set_conv_math(was[0])
+        RM._F16_MIN_PIXELS = was[1]
+        RF.set_async_wgrad(was[2])
+        torch.cuda.set_stream(cur)
+        torch.cuda.empty_cache()
+    return out
+
+
 def profile_step(net, bucket, inp, scaler):
     """One extra step with every C-ABI call bracketed by HIP events on the launch stream."""
     from rpnet_amd import hip
@@ -855,6 +884,8 @@ def main():
                                                                                  ow["batch"], om["fence"], 5)
             del om
             torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            result["other_configs"]["configs[4]"]["fp16_free_running_dice_dev"] = fp16_trained_dice_leg(dev, RF)
         RF.set_conv_math(requested)
     if ddp:
         dist.barrier()

@@ -191,6 +191,16 @@ typedef struct rpnet_conv_desc {
                                           (eval-mode calls at batch 2: M = 8192 ... 1024) into 2 ... 8 parts computed by separate blocks
                                           (fp32 partial outputs in the workspace) and summed, in a fixed order, by a second launch that
                                           does the epilogue (bias, ep_*, out_absmax, y_split).  NULL / too small: one block per tile */
+    /* Optional: whole output tiles whose result is known to be zero before the bias skip their K loop (round 4).  The CRE's
+       w_k(x * mask) / w_q(x * (1 - mask)) (net/rp_net.py:275,283) read an input that is EXACTLY zero wherever the pooled mask is 0
+       (resp. 1): skip_mask [N][H][W] (the conv's resolution; no up-sampling), skip_mode 1: factor = mask, 2: factor = 1 - mask;
+       skip_halo 1: the factor multiplies the INPUT (forward: a tile is skipped when the factor is zero on the tile and its
+       one-pixel halo), 0: it multiplies the OUTPUT (input gradient with out_scale: zero on the tile itself).  skip_ws: caller's
+       scratch of >= N*H*W / 128 bytes for the per-tile flags (rpnet_conv_fwd fills it with one small launch in front).  Only the
+       LDS-DMA patch kernels honour it (others compute every tile); skipped and computed tiles give the same bits (0 * w adds +0),
+       unless a weight or gradient is Inf / NaN. */
+    const float* skip_mask; int skip_mode; int skip_halo; unsigned char* skip_ws;
+    const unsigned char* tile_skip;    /* internal (set by the launcher): flags [M tiles], 0 = skip */
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
@@ -237,9 +247,24 @@ int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  * from dz, the pre-BatchNorm tensor y, stats [4][groups][cout] (scale, shift, mean, invstd of rpnet_bn_stats, contiguous) and
  * coef [groups][cout][2] (rpnet_bn_bwd with dy == dy_split == NULL leaves it at workspace + rpnet_bn_bwd_coef_offset) —
  * Conv1.conv.0 has no input gradient, so its dy has no other reader and the BatchNorm backward's apply pass is not run */
-int rpnet_conv1_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* coef, float* dw,
+int rpnet_conv1_wgrad_bn(const float* x, const float* dz, const float* y /* NULL: made again from x, w, bias */,
+                         const float* stats, const float* coef, float* dw,
                          int N, int H, int W, int cout, int groups, void* workspace, size_t workspace_bytes,
-                         rpnet_stream_t stream);
+                         const float* w /* may be NULL when y is given */, const float* bias, rpnet_stream_t stream);
+/* Train mode without the pre-BatchNorm tensor y of this layer in memory (nine multiply-adds make a value, eight bytes write
+ * and re-read it): rpnet_conv1_fwd(y = NULL, stats_partial) only sums y for rpnet_bn_stats_from_partial;
+ * rpnet_conv1_bn_relu = nn.BatchNorm2d + nn.ReLU (net/modules.py:48-49) of conv(x) made on the spot -> z (fp32, may be NULL) and
+ * the operand planes z_split / split_scale exactly as rpnet_bn_relu writes them; rpnet_conv1_bn_bwd_partial = the reduction
+ * pass of rpnet_bn_bwd with y made on the spot: partial [groups * rpnet_conv1_bn_bwd_rows()][cout][2] for
+ * rpnet_bn_bwd(y = NULL, dy = dy_split = NULL, given_partial, given_rows); then rpnet_conv1_wgrad_bn(y = NULL, w, bias).
+ * Every value of y is made by one definition (explicit fused multiply-adds in a fixed order): the same bits each time. */
+int rpnet_conv1_bn_relu(const float* x, const float* w, const float* bias, const float* scale /*[groups][cout]*/,
+                        const float* shift, float* z, void* z_split, int planes, const float* gamma, const float* beta,
+                        float* split_scale, int N, int H, int W, int cout, int groups, rpnet_stream_t stream);
+int rpnet_conv1_bn_bwd_rows(int N, int H, int W, int cout, int groups);
+int rpnet_conv1_bn_bwd_partial(const float* x, const float* w, const float* bias, const float* dz,
+                               const float* stats /*[4][groups][cout]: scale, shift, mean, invstd*/, double* partial,
+                               int N, int H, int W, int cout, int groups, rpnet_stream_t stream);
 
 /* ---------------------------------------------------------------------- BatchNorm
  * Train-mode nn.BatchNorm2d + nn.ReLU(inplace) (net/modules.py:48-49,51-52,68-69),

@@ -534,10 +534,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
     const int g = blockIdx.y, blk = blockIdx.x;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (tr < gm.rows_it) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + g * C + tc * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + g * C + tc * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tc * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * C + tc * 4);
+        f32x4 sc = *reinterpret_cast<const f32x4*>(scale + g * C + tc * 4);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(shift + g * C + tc * 4);
+        f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + tc * 4);
+        f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * C + tc * 4);
+        // (window decisions from values behind a FULL wait, the loaded registers tied: see bn_bwd_apply_pool_split)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sc), "+v"(sh), "+v"(mu), "+v"(is) : : "memory");
         const long r0 = (long)blk * gm.rows_blk;
         const long r1 = min(r0 + gm.rows_blk, Rp);
         const size_t gbase = (size_t)g * pg.imgs_per_group * pg.img_elems + tc * 4;
@@ -547,9 +549,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
             const int nl = (int)(r / hw), rem = (int)(r - (long)nl * hw);
             const int oy = rem / pg.Wo, ox = rem - oy * pg.Wo;
             const float* src = y + gbase + (size_t)nl * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + rowC), v3 = *reinterpret_cast<const f32x4*>(src + rowC + C);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dp + ((size_t)g * Rp + r) * C + tc * 4);
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
+            f32x4 v2 = *reinterpret_cast<const f32x4*>(src + rowC), v3 = *reinterpret_cast<const f32x4*>(src + rowC + C);
+            f32x4 d = *reinterpret_cast<const f32x4*>(dp + ((size_t)g * Rp + r) * C + tc * 4);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(d) : : "memory");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float best;
@@ -575,7 +578,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
 }
 
 // thread = one pooled pixel x 8 channels: the four dy of its window (planes at full resolution, fp32 too when dy != NULL)
-template <int NP>
+//
+// DRAIN (round 4): every load of a half is waited for with `s_waitcnt vmcnt(0)` BEFORE any of its values is read (the asm
+// statement ties the loaded registers, so the compiler can make no early copy).  Without it hipcc issues the 18 loads of an
+// iteration back to back and reads them behind counted waits (vmcnt(17), vmcnt(16), ...), which is correct while loads
+// return in issue order.  Observed on MI355X (tools/diag_taps.py, profiles/r04_pool_apply_fault.txt): when the blocks of
+// this pass share their CUs with a running LDS-DMA weight-gradient kernel (conv_wgrad9_dma_kernel on the side stream — the
+// default schedule since round 3), a few dozen of the 4 - 8 M window decisions of a launch come out as if the FIRST value
+// compared (element 1 of a float4 of y) had not yet landed: the pooled gradient then lands on the wrong pixel of its 2 x 2
+// window, every later value of the thread (read behind later waits) is right.  Inputs and outputs of the launch were pinned
+// and compared between runs: identical y, statistics and dz, 2 - 130 differing elements of dy, 25 - 100 % of the steps
+// depending on what else is resident; with the full wait: 0 of 16.  The wrong decisions moved the gradients of the
+// layers below by 1e-4 ... 5e-2 (relative, max norm) in those steps.
+template <int NP, bool DRAIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const float* __restrict__ y,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -610,18 +625,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __re
             f32x4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(y + offs[q] + hh * 4);
-            const f32x4 d = reinterpret_cast<const f32x4*>(dp)[i * 2 + hh];
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
-            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+            f32x4 d = reinterpret_cast<const f32x4*>(dp)[i * 2 + hh];
+            f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
+            f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
+            f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
+            f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+            f32x4 cf0 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2), cf1 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2 + 4);
+            if constexpr (DRAIN)      // every load of this half has landed before ANY of its values is read: the loaded registers
+                                      // THEMSELVES are tied to the statement (no copy the compiler could make behind a counted wait)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(d), "+v"(sc), "+v"(sh), "+v"(mu), "+v"(is), "+v"(cf0), "+v"(cf1)
+                             :
+                             : "memory");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float best;
                 const int qb = pool_argmax(v[0][k] * sc[k] + sh[k], v[1][k] * sc[k] + sh[k], v[2][k] * sc[k] + sh[k],
                                            v[3][k] * sc[k] + sh[k], best);
                 const float dm = best > 0.f ? d[k] : 0.f;
-                const float c1 = coef[(o + k) * 2], c2 = coef[(o + k) * 2 + 1];
+                const float c1 = k < 2 ? cf0[2 * k] : cf1[2 * k - 4], c2 = k < 2 ? cf0[2 * k + 1] : cf1[2 * k - 3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     r[q][hh * 4 + k] = sc[k] * ((q == qb ? dm : 0.f) - c1 - (v[q][k] - mu[k]) * is[k] * c2);
@@ -776,7 +798,9 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
                             size_t workspace_bytes, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
-    RPNET_REQUIRE(dz && y && scale && shift && mean && invstd && dgamma && dbeta && workspace, RPNET_ERR_ARG, "bn_bwd: null pointer");
+    RPNET_REQUIRE(dz && scale && shift && mean && invstd && dgamma && dbeta && workspace, RPNET_ERR_ARG, "bn_bwd: null pointer");
+    // y may be NULL only where nothing reads it: the reduction already ran elsewhere (given_partial) and no dy is asked for
+    RPNET_REQUIRE(y || (given_partial && !dy && !dy_split), RPNET_ERR_ARG, "bn_bwd: y is NULL but a pass that reads it was asked for");
     RPNET_REQUIRE(!dy_split || (planes >= 1 && planes <= 3 && C % 8 == 0), RPNET_ERR_SHAPE, "bn_bwd: split planes=%d C=%d",
                   planes, C);
     if (int rc = bn_check("bn_bwd", N, HW, C, groups)) return rc;
@@ -798,18 +822,25 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
         const long Rp = R / 4;
         const BnGeom gp = bn_geom(Rp, C);
+        // RPNET_BN_POOL_ALONE (default 1): the two pooled passes reserve 24 KB of LDS they do not use, so that their blocks never
+        // share a CU with a block of the LDS-DMA GEMM kernels (147 - 156 of 160 KB) — see bn_bwd_apply_pool_split
+        static const size_t alone = [] { const char* e = getenv("RPNET_BN_POOL_ALONE"); return (e && e[0] == '0') ? (size_t)0 : (size_t)24576; }();
         if (bn_lds_window() == 64)
-            hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);
         else
-            hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * HW * C;
+        // DRAIN (default; RPNET_BN_POOL_DRAIN=0: the A/B switch that brings the fault back): see bn_bwd_apply_pool_split
+        static const bool drain = [] { const char* e = getenv("RPNET_BN_POOL_DRAIN"); return !(e && e[0] == '0'); }();
 #define RPNET_BN_POOL_BWD(NP_)                                                                                              \
-    hipLaunchKernelGGL(bn_bwd_apply_pool_split<NP_>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, \
-                       (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale)
+    do { if (drain) hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, true>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, \
+                       (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale); \
+    else hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, false>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, \
+                       (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale); } while (0)
         if (planes == 3) RPNET_BN_POOL_BWD(3);
         else if (planes == 2) RPNET_BN_POOL_BWD(2);
         else RPNET_BN_POOL_BWD(1);

@@ -3,9 +3,42 @@
 // output (forward) or reading dy (weight gradient).  One thread = one pixel x 4 output
 // channels, so a pixel's Cout channels are one coalesced float4 row; the 9 x Cout filter
 // sits in LDS.  The input image needs no gradient.
+//
+// Train mode on fp16 planes (round 4): the pre-BatchNorm tensor y of this layer is NEVER in memory.  It costs nine
+// multiply-adds per value to make and eight bytes per value to write and read back, so the statistics launch
+// (rpnet_conv1_fwd with y == NULL) only sums it, BatchNorm + ReLU (rpnet_conv1_bn_relu) makes it again and writes the
+// operand planes of Conv1.conv.3, and the backward's reduction pass and weight gradient (rpnet_conv1_bn_bwd_partial,
+// rpnet_conv1_wgrad_bn with y == NULL) make it again from the image.  conv1_quad is the ONE definition of a value of y
+// (explicit fused multiply-adds, taps in row-major order): a value made twice is the same bits twice.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace rpnet {
+
+// filter [9][Cout] + bias [Cout] in LDS (wl), as every kernel here keeps it
+__device__ __forceinline__ void conv1_load_filter(float* wl, const float* __restrict__ w, const float* __restrict__ bias,
+                                                  const int Cout) {
+    const int t = threadIdx.x;
+    for (int i = t; i < 9 * Cout; i += 256) { const int co = i / 9, tap = i - co * 9; wl[tap * Cout + co] = w[i]; }
+    for (int i = t; i < Cout; i += 256) wl[9 * Cout + i] = bias ? bias[i] : 0.f;
+}
+
+// y[pixel (nb + oy W + ox)][4 q .. 4 q + 3], bias included
+__device__ __forceinline__ f32x4 conv1_quad(const float* __restrict__ x, const float* wl, const int Cout, const int q,
+                                            const size_t nb, const int oy, const int ox, const int H, const int W) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[9 * Cout + q * 4]);
+#pragma unroll
+    for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+        for (int kx = -1; kx <= 1; ++kx) {
+            const int iy = oy + ky, ix = ox + kx;
+            const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[nb + (size_t)iy * W + ix] : 0.f;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[((ky + 1) * 3 + kx + 1) * Cout + q * 4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(xv, wv[k], acc[k]);
+        }
+    return acc;
+}
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
@@ -15,8 +48,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                          const int groups) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout] (+ the statistics reduction)
     const int t = threadIdx.x;
-    for (int i = t; i < 9 * Cout; i += 256) { const int co = i / 9, tap = i - co * 9; wl[tap * Cout + co] = w[i]; }
-    for (int i = t; i < Cout; i += 256) wl[9 * Cout + i] = bias ? bias[i] : 0.f;
+    conv1_load_filter(wl, w, bias, Cout);
     __syncthreads();
     const int Q = Cout / 4, ppb = 256 / Q;
     const int q = t % Q, pl = t / Q;
@@ -36,23 +68,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     for (size_t p = p_lo + pl; pl < ppb && p < p_hi; p += p_step) {
         const int ox = (int)(p % W), oy = (int)((p / W) % H);
         const size_t nb = p - (size_t)oy * W - ox;  // n*H*W
-        f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[9 * Cout + q * 4]);
-#pragma unroll
-        for (int ky = -1; ky <= 1; ++ky)
-#pragma unroll
-            for (int kx = -1; kx <= 1; ++kx) {
-                const int iy = oy + ky, ix = ox + kx;
-                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[nb + (size_t)iy * W + ix] : 0.f;
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[((ky + 1) * 3 + kx + 1) * Cout + q * 4]);
-                acc += xv * wv;
-            }
+        f32x4 acc = conv1_quad(x, wl, Cout, q, nb, oy, ox, H, W);
         if (ep_scale) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(ep_scale + q * 4);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(ep_shift + q * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k] * sc[k] + sh[k], 0.f);
         }
-        *reinterpret_cast<f32x4*>(y + p * Cout + q * 4) = acc;
+        if (y) *reinterpret_cast<f32x4*>(y + p * Cout + q * 4) = acc;      // y == NULL: the statistics only
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
         if (stats_partial) {
 #pragma unroll
@@ -93,13 +116,20 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // BatchNorm + ReLU output, its pre-BatchNorm tensor y and the coefficients of rpnet_bn_bwd's reduction pass,
 // dy = scale (dz [z > 0] - c1 - xhat c2) — the 12 bytes per element of a separate apply pass (this layer has no input
 // gradient, so its dy has no other reader) become 4
-template <bool BN>
+// RECOMP (with BN): ybn is not read either — y is made again from x and the filter (conv1_quad; wf, bf = weight, bias)
+template <bool BN, bool RECOMP = false>
 __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ ybn, const float* __restrict__ stats,
                                                             const float* __restrict__ coef, float* __restrict__ partial,
-                                                            int N, int H, int W, int Cout, int groups) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][Cout][9]
+                                                            int N, int H, int W, int Cout, int groups,
+                                                            const float* __restrict__ wf, const float* __restrict__ bf) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][Cout][9] (RECOMP: + the filter behind it)
     const int t = threadIdx.x;
+    float* const wl = red + (256 / (Cout / 4)) * Cout * 9;
+    if (RECOMP) {
+        conv1_load_filter(wl, wf, bf, Cout);
+        __syncthreads();
+    }
     const int Q = Cout / 4, ppb = 256 / Q;
     const int q = t % Q, pl = t / Q;
     const int g = blockIdx.y;
@@ -126,7 +156,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
             const size_t nb = p - (size_t)oy * W - ox;
             f32x4 gr = *reinterpret_cast<const f32x4*>(dy + p * Cout + q * 4);
             if (BN) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ybn + p * Cout + q * 4);
+                f32x4 v;
+                if constexpr (RECOMP) v = conv1_quad(x, wl, Cout, q, nb, oy, ox, H, W);
+                else v = *reinterpret_cast<const f32x4*>(ybn + p * Cout + q * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? gr[k] : 0.f;
@@ -156,6 +188,115 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
     }
 }
 
+// BatchNorm + ReLU of the layer with y made on the spot: thread = one pixel x 8 channels; z (optional, fp32) and the NP
+// operand planes of z / s, s = the rigorous tensor scale of rpnet_bn_relu (every block derives it from gamma, beta;
+// block 0 publishes it).  Pixels are dealt to the blocks cyclically in groups of 256 / (Cout / 8).
+template <int NP>
+__global__ __launch_bounds__(256) void conv1_bn_relu_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ z,
+                                                             unsigned short* __restrict__ zs, const int N, const int H,
+                                                             const int W, const int Cout, const int groups,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float sqrt_n, float* __restrict__ s_out) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    __shared__ float red4[4];
+    const int t = threadIdx.x;
+    conv1_load_filter(wl, w, bias, Cout);
+    float inv_s = 1.f;
+    if (NP <= 2) {
+        float m = 0.f;
+        for (int c = t; c < Cout; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((t & 63) == 0) red4[t >> 6] = m;
+        __syncthreads();
+        const float sc = pow2_scale(fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3])));
+        if (blockIdx.x == 0 && t == 0) *s_out = sc;
+        inv_s = 1.f / sc;
+    }
+    __syncthreads();
+    const int Q8 = Cout / 8, ppb = 256 / Q8;
+    const int q8 = t % Q8, pl = t / Q8;
+    const size_t M = (size_t)N * H * W, Mg = M / groups, plane = M * Cout;
+    for (size_t p = (size_t)blockIdx.x * ppb + pl; pl < ppb && p < M; p += (size_t)gridDim.x * ppb) {
+        const int ox = (int)(p % W), oy = (int)((p / W) % H);
+        const size_t nb = p - (size_t)oy * W - ox;
+        const int g = (int)(p / Mg);
+        float v[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 a = conv1_quad(x, wl, Cout, q8 * 2 + hh, nb, oy, ox, H, W);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(scale + g * Cout + q8 * 8 + hh * 4);
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(shift + g * Cout + q8 * 8 + hh * 4);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[k] = fmaxf(a[k] * s4[k] + h4[k], 0.f); v[hh * 4 + k] = o[k]; }
+            if (z) *reinterpret_cast<f32x4*>(z + p * Cout + q8 * 8 + hh * 4) = o;
+        }
+        if (NP <= 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= inv_s;
+        }
+        u32x4 pk[NP];
+        split8<NP>(v, pk);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<u32x4*>(zs + pp * plane + p * Cout + q8 * 8) = pk[pp];
+    }
+}
+
+// reduction pass of the layer's BatchNorm backward with y made on the spot: partial[(g nblk + blk)][Cout][2] doubles
+// (sum dz m, sum dz m xhat) as rpnet::bn_bwd_partial leaves them — for rpnet_bn_bwd(given_partial).  grid (nblk, groups);
+// the pixel groups of a statistic group are dealt to its blocks cyclically.
+__global__ __launch_bounds__(256) void conv1_bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, const float* __restrict__ dz,
+                                                                    const float* __restrict__ stats, double* __restrict__ partial,
+                                                                    const int N, const int H, const int W, const int Cout,
+                                                                    const int groups) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // filter, then [256][8] doubles of the reduction
+    const int t = threadIdx.x;
+    conv1_load_filter(wl, w, bias, Cout);
+    __syncthreads();
+    const int Q = Cout / 4, ppb = 256 / Q;
+    const int q = t % Q, pl = t / Q;
+    const int g = blockIdx.y;
+    const size_t Mg = (size_t)(N / groups) * H * W, p_lo = (size_t)g * Mg;
+    const int GC = groups * Cout, o = g * Cout + q * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(stats + o);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(stats + GC + o);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(stats + 2 * GC + o);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(stats + 3 * GC + o);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (pl < ppb) {
+        for (size_t pg = (size_t)blockIdx.x * ppb + pl; pg < Mg; pg += (size_t)gridDim.x * ppb) {
+            const size_t p = p_lo + pg;
+            const int ox = (int)(p % W), oy = (int)((p / W) % H);
+            const size_t nb = p - (size_t)oy * W - ox;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + p * Cout + q * 4);
+            const f32x4 v = conv1_quad(x, wl, Cout, q, nb, oy, ox, H, W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
+                s1[k] += dm;
+                s2[k] += (double)dm * ((v[k] - mu[k]) * is[k]);
+            }
+        }
+    }
+    double* red = reinterpret_cast<double*>(wl + 10 * Cout + (10 * Cout & 1));
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[t * 8 + k] = s1[k]; red[t * 8 + 4 + k] = s2[k]; }
+    __syncthreads();
+    if (pl == 0) {
+        for (int r = 1; r < ppb; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[k] += red[(r * Q + q) * 8 + k]; s2[k] += red[(r * Q + q) * 8 + 4 + k]; }
+        double* out = partial + ((size_t)(g * gridDim.x + blockIdx.x) * Cout + q * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { out[k * 2] = s1[k]; out[k * 2 + 1] = s2[k]; }
+    }
+}
+
 __global__ __launch_bounds__(64) void conv1_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int n) {
     const int i = blockIdx.x, lane = threadIdx.x;
     double s = 0;
@@ -180,7 +321,7 @@ extern "C" int rpnet_conv1_fwd(const float* x, const float* w, const float* bias
                                const float* ep_shift, int N, int H, int W, int cout, float* out_absmax,
                                double* stats_partial, int groups, rpnet_stream_t stream) {
     using namespace rpnet;
-    RPNET_REQUIRE(x && w && y, RPNET_ERR_ARG, "conv1_fwd: null pointer");
+    RPNET_REQUIRE(x && w && (y || stats_partial), RPNET_ERR_ARG, "conv1_fwd: null pointer (y may be NULL only with stats_partial)");
     RPNET_REQUIRE(cout % 4 == 0 && cout <= 1024 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_fwd: cout=%d", cout);
     const int ppb = 256 / (cout / 4);
     const size_t M = (size_t)N * H * W;
@@ -206,7 +347,7 @@ extern "C" size_t rpnet_conv1_wgrad_workspace_bytes(int N, int H, int W, int cou
 
 static int conv1_wgrad_launch(const float* x, const float* dy, const float* ybn, const float* stats, const float* coef, float* dw,
                               int N, int H, int W, int cout, int groups, void* workspace, size_t workspace_bytes,
-                              rpnet_stream_t stream) {
+                              rpnet_stream_t stream, const float* wf = nullptr, const float* bf = nullptr) {
     using namespace rpnet;
     RPNET_REQUIRE(x && dy && dw && workspace, RPNET_ERR_ARG, "conv1_wgrad: null pointer");
     RPNET_REQUIRE(cout % 4 == 0 && cout <= 256 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_wgrad: cout=%d", cout);
@@ -218,12 +359,17 @@ static int conv1_wgrad_launch(const float* x, const float* dy, const float* ybn,
     if (nb > kConv1WgradBlocks / groups) nb = kConv1WgradBlocks / groups;
     if (nb < 1) nb = 1;
     hipStream_t s = (hipStream_t)stream;
-    if (ybn)
-        hipLaunchKernelGGL(conv1_wgrad_partial<true>, dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
-                           ybn, stats, coef, (float*)workspace, N, H, W, cout, groups);
+    if (wf)
+        hipLaunchKernelGGL((conv1_wgrad_partial<true, true>), dim3(nb, groups), dim3(256),
+                           (size_t)(ppb * cout * 9 + 10 * cout) * sizeof(float), s, x, dy, (const float*)nullptr, stats, coef,
+                           (float*)workspace, N, H, W, cout, groups, wf, bf);
+    else if (ybn)
+        hipLaunchKernelGGL((conv1_wgrad_partial<true, false>), dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
+                           ybn, stats, coef, (float*)workspace, N, H, W, cout, groups, (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL(conv1_wgrad_partial<false>, dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, N, H, W, cout, groups);
+        hipLaunchKernelGGL((conv1_wgrad_partial<false, false>), dim3(nb, groups), dim3(256), (size_t)ppb * cout * 9 * sizeof(float), s, x, dy,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, N, H, W, cout, groups,
+                           (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(conv1_wgrad_final, dim3(cout * 9), dim3(64), 0, s, (const float*)workspace, dw, nb * groups, cout * 9);
     return check_launch("conv1_wgrad");
 }
@@ -235,9 +381,53 @@ extern "C" int rpnet_conv1_wgrad(const float* x, const float* dy, float* dw, int
 
 extern "C" int rpnet_conv1_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* coef,
                                     float* dw, int N, int H, int W, int cout, int groups, void* workspace,
-                                    size_t workspace_bytes, rpnet_stream_t stream) {
+                                    size_t workspace_bytes, const float* w, const float* bias, rpnet_stream_t stream) {
     using namespace rpnet;
-    RPNET_REQUIRE(y && stats && coef, RPNET_ERR_ARG, "conv1_wgrad_bn: null pointer");
+    RPNET_REQUIRE((y || w) && stats && coef, RPNET_ERR_ARG, "conv1_wgrad_bn: null pointer (y, or the filter w to make it again)");
     RPNET_REQUIRE(groups <= kConv1WgradBlocks, RPNET_ERR_SHAPE, "conv1_wgrad_bn: groups=%d", groups);
-    return conv1_wgrad_launch(x, dz, y, stats, coef, dw, N, H, W, cout, groups, workspace, workspace_bytes, stream);
+    return conv1_wgrad_launch(x, dz, y, stats, coef, dw, N, H, W, cout, groups, workspace, workspace_bytes, stream,
+                              y ? nullptr : w, y ? nullptr : bias);
+}
+
+extern "C" int rpnet_conv1_bn_relu(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                                   float* z, void* z_split, int planes, const float* gamma, const float* beta,
+                                   float* split_scale, int N, int H, int W, int cout, int groups, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && w && scale && shift && z_split, RPNET_ERR_ARG, "conv1_bn_relu: null pointer");
+    RPNET_REQUIRE(cout % 8 == 0 && cout <= 1024 && 256 % (cout / 8) == 0, RPNET_ERR_SHAPE, "conv1_bn_relu: cout=%d", cout);
+    RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "conv1_bn_relu: N=%d groups=%d", N, groups);
+    RPNET_REQUIRE(planes >= 1 && planes <= 3 && (planes == 3 || (gamma && beta && split_scale)), RPNET_ERR_ARG,
+                  "conv1_bn_relu: planes=%d (fp16 planes need gamma, beta and the scale output)", planes);
+    const size_t M = (size_t)N * H * W;
+    const int ppb = 256 / (cout / 8);
+    size_t nb = (M + (size_t)ppb * 4 - 1) / ((size_t)ppb * 4);      // four pixel groups per block and more
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    const float sqrt_n = sqrtf((float)((size_t)(N / groups) * H * W)) * 1.0001f;
+    const size_t lds = (size_t)10 * cout * sizeof(float);
+#define RPNET_C1BN(NP_)                                                                                                     \
+    hipLaunchKernelGGL(conv1_bn_relu_kernel<NP_>, dim3((int)nb), dim3(256), lds, (hipStream_t)stream, x, w, bias, scale, shift, z, \
+                       (unsigned short*)z_split, N, H, W, cout, groups, gamma, beta, sqrt_n, split_scale)
+    if (planes == 3) RPNET_C1BN(3);
+    else if (planes == 2) RPNET_C1BN(2);
+    else RPNET_C1BN(1);
+#undef RPNET_C1BN
+    return check_launch("conv1_bn_relu");
+}
+
+extern "C" int rpnet_conv1_bn_bwd_rows(int N, int H, int W, int cout, int groups) {
+    return rpnet_conv1_stats_blocks(N, H, W, cout, groups);
+}
+
+extern "C" int rpnet_conv1_bn_bwd_partial(const float* x, const float* w, const float* bias, const float* dz, const float* stats,
+                                          double* partial, int N, int H, int W, int cout, int groups, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(x && w && dz && stats && partial, RPNET_ERR_ARG, "conv1_bn_bwd_partial: null pointer");
+    RPNET_REQUIRE(cout % 4 == 0 && cout <= 1024 && 256 % (cout / 4) == 0, RPNET_ERR_SHAPE, "conv1_bn_bwd_partial: cout=%d", cout);
+    const int nblk = rpnet_conv1_bn_bwd_rows(N, H, W, cout, groups);
+    RPNET_REQUIRE(nblk > 0, RPNET_ERR_SHAPE, "conv1_bn_bwd_partial: N=%d groups=%d", N, groups);
+    const size_t lds = (size_t)(10 * cout + 2) * sizeof(float) + (size_t)256 * 8 * sizeof(double);
+    hipLaunchKernelGGL(conv1_bn_bwd_partial_kernel, dim3(nblk, groups), dim3(256), lds, (hipStream_t)stream, x, w, bias, dz, stats,
+                       partial, N, H, W, cout, groups);
+    return check_launch("conv1_bn_bwd_partial");
 }

@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * psw, 0, 0);
     };
 
+    // a tile whose input (forward) / output factor (input gradient) is zero everywhere (rpnet_conv_desc.skip_*): no K loop,
+    // the epilogue runs on the zero accumulators (bias, statistics, factor) as it would after multiplying zeros
+    const bool skip_tile = d.tile_skip != nullptr && d.tile_skip[tm] == 0;
+    if (!skip_tile) {
     // ---- prologue: halo of chunk 0, weight slabs of steps 0, 1, 2
     {
         const int c0 = chunk_c0(0);
@@ -291,8 +295,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
 
     // ablation switches for tools/bench_conv_split.py (rpnet_conv_desc.tune bits 8..: 1 = only the first channel chunk,
     // 2 = no epilogue): where a launch's time goes besides its K-steps
-    const int dbg = d.tune >> 8;
-    const int nchunks_run = (dbg & 1) ? 1 : kchunks;
+    const int nchunks_run = ((d.tune >> 8) & 1) ? 1 : kchunks;
     int ks = 0;
     for (int ci = 0; ci < nchunks_run; ++ci) {
         step(std::integral_constant<int, 0>{}, ci, ks + 0);
@@ -309,6 +312,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     (void)nsteps;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's DMAs: the epilogue reuses the memory
     __builtin_amdgcn_s_barrier();
+    }   // !skip_tile
+    const int dbg = d.tune >> 8;
     if (dbg & 2) {
         float sacc = 0.f;
 #pragma unroll
@@ -394,6 +399,28 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     }
 }
 
+// flags[tile] = 1 when the factor f(mask) (mode 1: mask, 2: 1 - mask) is non-zero somewhere on the tile's TH x TW patch
+// (+ a one-pixel halo when `halo`): one wave per tile
+__global__ __launch_bounds__(64) void mask_tile_flags_kernel(const float* __restrict__ mask, const int mode, const int halo,
+                                                              const int H, const int W, const int TW, const int TH,
+                                                              unsigned char* __restrict__ flags) {
+    const int tm = blockIdx.x, lane = threadIdx.x;
+    const int pxn = W / TW, ppi = (H / TH) * pxn;
+    const int n = tm / ppi, prem = tm - n * ppi;
+    const int y0 = (prem / pxn) * TH - halo, x0 = (prem % pxn) * TW - halo;
+    const int ph = TH + 2 * halo, pw = TW + 2 * halo;
+    bool any = false;
+    for (int i = lane; i < ph * pw; i += 64) {
+        const int yy = y0 + i / pw, xx = x0 + i % pw;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float m = mask[((size_t)n * H + yy) * W + xx];
+            any = any || (mode == 2 ? (1.f - m) != 0.f : m != 0.f);
+        }
+    }
+    const bool r = __any(any);
+    if (lane == 0) flags[tm] = r ? 1 : 0;
+}
+
 // Parts (a power of two, 1 = no split) into which conv_fwd_split_dma cuts the K range of this launch, given a workspace
 // (rpnet_conv_desc.splitk_ws): launches whose 256 x 64 tiles cover half of the CUs or fewer — the eval-mode calls at batch 2:
 // M = 8192 (the 22 CRE convolutions of a T = 10 call), 4096, 1024 — when the epilogue is one the reduce launch has.
@@ -420,6 +447,12 @@ int conv_fwd_split_dma(const rpnet_conv_desc* d, int M, int Cin, int Cout, int t
     const int tiles_m = M / bm, tiles_n = Cout / (64 * wn);
     const int ntiles = tiles_m * tiles_n;
     rpnet_conv_desc dp = *d;
+    dp.tile_skip = nullptr;
+    if (d->skip_mask && d->skip_ws && (d->skip_mode == 1 || d->skip_mode == 2) && !d->upsample && d->H % (bm / tw) == 0 && d->W % tw == 0) {
+        hipLaunchKernelGGL(mask_tile_flags_kernel, dim3(tiles_m), dim3(64), 0, s, d->skip_mask, d->skip_mode, d->skip_halo ? 1 : 0, d->H,
+                           d->W, tw, bm / tw, d->skip_ws);
+        dp.tile_skip = d->skip_ws;
+    }
     int kshift = 0;
     if (parts > 1) {
         if (d->split_planes != 2 || wn != 1 || (size_t)parts * M * Cout * sizeof(float) > d->splitk_ws_bytes || !d->splitk_ws) {

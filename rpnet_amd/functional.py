@@ -30,7 +30,13 @@ BN_MOMENTUM = 0.1
 # into the parameter's existing .grad buffer (the flat bucket) instead of being returned to
 # autograd; the backward pass's HBM-bound kernels then run beside MFMA work.  The two streams are
 # joined by an engine callback at the end of backward (and before the bucket's early all-reduce).
-_ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": []}
+_ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": [], "keep": []}
+# Tensors an async weight-gradient launch reads on the side streams (dy, its planes, the saved input, the operand scales,
+# the split-K workspace) are KEPT ALIVE until the streams are joined at the end of the backward pass (join_side_streams)
+# instead of being handed to the caching allocator's record_stream: every record costs an event record at free time and
+# event queries at later allocations (~10 tensors x 27 launches per step: measurable host time), and 288 GB of HBM hold a
+# backward pass's gradients without noticing.  RPNET_WGRAD_KEEPALIVE=0 restores record_stream (A/B switch).
+_KEEPALIVE = os.environ.get("RPNET_WGRAD_KEEPALIVE", "1") == "1"
 
 # Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
@@ -85,6 +91,21 @@ def set_async_wgrad(on=True):
     AccumulateGrad (one torch add per parameter).  Parameter hooks then do not fire for those parameters;
     a parameter that must keep its hook is tagged `_rpnet_autograd_grad = True`."""
     _ASYNC["on"] = bool(on)
+
+
+# diagnostic hook (None: off): a list that ConvBnRelu.backward fills with (tag, weight shape, clone) of its intermediate tensors
+# in stream order (tools/diag_taps.py compares them between runs of one step)
+_TAPS = None
+
+
+_TAPS_PIN = False      # True: keep the tensors themselves (no copy kernel: the step's timing stays what it is, their memory is not reused)
+
+
+def _tap(tag, weight, *tensors):
+    if _TAPS is not None:
+        for i, t in enumerate(tensors):
+            if t is not None:
+                _TAPS.append((f"{tag}{i}", tuple(weight.shape), t.detach() if _TAPS_PIN else t.detach().clone()))
 
 
 def _direct(p):
@@ -162,6 +183,15 @@ def _cre_stream(device):
     return s
 
 
+def _pack_stream(device):
+    """the stream of the per-step weight packing (WeightCache.prepack_async)"""
+    key = ("pack", device)
+    s = _ASYNC["side"].get(key)
+    if s is None:
+        s = _ASYNC["side"][key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _side_stream(device):
     s = _ASYNC["side"].get(device)
     if s is None:
@@ -186,8 +216,11 @@ def _release_wgrads(keep):
         q.pop(0)()
 
 
-def join_side_streams():
-    """Launch what is still queued, then make the current stream wait for every async weight-gradient launch issued so far."""
+def join_side_streams(final=True):
+    """Launch what is still queued, then make the current stream wait for every async weight-gradient launch issued so far.
+    final=False (the gradient bucket's hooks, in the middle of a backward pass): the tensors kept alive for the side streams
+    stay alive — only the CALLING stream has waited, and a block freed now could be handed to another stream of the pass (the
+    CRE branch, the encoder's second chain) while a weight gradient still reads it."""
     _release_wgrads(0)
     for dev in list(_ASYNC["pending"]):
         torch.cuda.current_stream(dev).wait_stream(_ASYNC["side"][dev])
@@ -197,7 +230,10 @@ def join_side_streams():
         cre = _ASYNC["side"].get(("cre", dev))      # the CRE's second branch writes its BatchNorm parameter gradients there
         if cre is not None:
             torch.cuda.current_stream(dev).wait_stream(cre)
+    if not final:
+        return
     _ASYNC["pending"].clear()
+    _ASYNC["keep"].clear()        # freed behind the waits above: whatever reuses their blocks is ordered after the side streams
     _ASYNC["queued"] = False
 
 
@@ -466,6 +502,23 @@ _EVAL_SPLITK = os.environ.get("RPNET_EVAL_SPLITK", "1") == "1"
 _POOL_FUSE = os.environ.get("RPNET_POOL_FUSE", "1") == "1"
 # A/B switch: the BatchNorm-backward apply pass of Conv1.conv.0 inside its direct weight gradient (rpnet_conv1_wgrad_bn)
 _CONV1_BN_FUSE = os.environ.get("RPNET_CONV1_BN_FUSE", "1") == "1"
+# Conv1.conv.0 (Cin = 1) in training on fp16 planes: its pre-BatchNorm tensor is never written — the statistics launch only
+# sums it, BatchNorm + ReLU and the backward's reduction pass / weight gradient make it again from the image (nine
+# multiply-adds per value against eight bytes written and re-read; csrc/conv_first.hip).  RPNET_CONV1_RECOMPUTE=0: A/B switch
+_CONV1_RECOMP = os.environ.get("RPNET_CONV1_RECOMPUTE", "1") == "1"
+# w_k(x * mask) / w_q(x * (1 - mask)) (net/rp_net.py:275,283): output tiles whose masked input is zero on the tile and its halo
+# (forward) or whose factor is zero on the tile (input gradient) skip their K loop (rpnet_conv_desc.skip_*) — same bits as the
+# dense launch.  The support mask covers 2 - 15 % of the pixels, so most tiles of w_k go.  bench.py keeps the HEADLINE dense
+# (the roofline accounting is algorithmic) and reports this as its own leg.  RPNET_MASK_SKIP=0: off
+_MASK_SKIP = os.environ.get("RPNET_MASK_SKIP", "1") == "1"
+
+
+def _set_skip(d, mask, mode, halo, N, H, W):
+    """lend a launch the mask and the flag scratch of the tile skip (only the LDS-DMA patch kernels use them)"""
+    if _MASK_SKIP and mask is not None and mode in (1, 2):
+        d._skip_ws = torch.empty(max(N * H * W // 128, 16), device=mask.device, dtype=torch.uint8)
+        d.skip_mask, d.skip_mode, d.skip_halo, d.skip_ws = ptr(mask), mode, halo, ptr(d._skip_ws)
+        ARITH[("zero_tile_skip", "armed")] += 1
 
 
 def as_operand(t):
@@ -627,11 +680,33 @@ class WeightCache:
 
     def __init__(self):
         self._d = {}
+        self._ready = None          # (event, streams that already wait for it): the packs of prepack_async
 
     def clear(self):
         self._d.clear()
+        self._ready = None
+
+    def prepack_async(self, weights, planes, device):
+        """prepack() on the pack stream, beside whatever the caller's stream does next (the first-layer convolution and its
+        BatchNorm passes need no pack: 0.2 ms of HBM-bound packing at the head of every training step with nothing else on
+        the machine); every stream that fetches a layer's pack afterwards (get) first waits for the event recorded here.
+        The pack stream starts behind everything the caller's stream holds (the optimizer's update of the weights, the
+        previous backward pass's reads of the old packs)."""
+        main = torch.cuda.current_stream(device)
+        ps = _pack_stream(device)
+        ps.wait_stream(main)
+        with torch.cuda.stream(ps):
+            self.prepack(weights, planes)
+            ev = torch.cuda.Event()
+            ev.record(ps)
+        self._ready = (ev, set())
 
     def get(self, weight, split=None):
+        if self._ready is not None:
+            sid = hip.stream()
+            if sid not in self._ready[1]:
+                torch.cuda.current_stream(weight.device).wait_event(self._ready[0])
+                self._ready[1].add(sid)
         # the split (channel ranges of the gathered sources) is part of what a pack IS: a layer fetched once without and
         # once with its ranges must not share one
         key = (weight.data_ptr(), weight._version, None if split is None else tuple(split))
@@ -753,6 +828,8 @@ class ConvBnRelu(Function):
                     d.split_planes = fp
                     d.acc_scale_col, d.acc_scale_x, d.acc_scale_x1 = ptr(t_row), ptr(f16[2]), ptr(f16[3])
                     d._keep = f16
+                    if pw.taps == 9 and x1 is None and not upsample:
+                        _set_skip(d, in_scale, in_mode, 1, N, H, W)
                 else:
                     np_ = _MATH["planes"]
                     d = _desc(_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_),
@@ -794,7 +871,11 @@ class ConvBnRelu(Function):
                     produced["scale"] = sz
             ctx.eval_mode = True
             return z
-        y = _empty((N, H, W, cout), x0)
+        # the first layer on fp16 planes whose only consumer reads the planes: y is summed, never written (see _CONV1_RECOMP)
+        recomp = bool(first and _CONV1_RECOMP and f16_mode() and cout % 8 == 0 and 256 % (cout // 8) == 0 and out_split is True
+                      and produced.get("z_unused") and not produced.get("pool_req") and _CONV1_BN_FUSE
+                      and query("rpnet_conv1_stats_blocks", N, H, W, cout, groups) > 0)
+        y = None if recomp else _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
         fused, xs, sx, sx1 = 0, None, None, None
         if first:      # batch statistics out of the same launch (one partial row per block and group)
@@ -817,6 +898,8 @@ class ConvBnRelu(Function):
                 d = _desc(xs[0], xs[1], wps, bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
                 d.split_planes = fp
                 d.acc_scale_col, d.acc_scale_x, d.acc_scale_x1 = ptr(t_row), ptr(sx), ptr(sx1)
+                if pw.taps == 9 and x1 is None and not upsample:
+                    _set_skip(d, in_scale, in_mode, 1, N, H, W)
             elif _use_split(pw, x0, x1):
                 np_ = _MATH["planes"]
                 xs = (_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_))
@@ -864,12 +947,19 @@ class ConvBnRelu(Function):
             # max-pool reads it)
             z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, Hz, Wz, cout)
             produced["planes_only"] = True
-            if not pool and out_split is True:
+            if not pool and out_split is True and not recomp:
                 produced["bn_ref"] = BnRef(y, stats, groups)
-        # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
-        call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
-             np_out, ptr(gamma), ptr(beta),
-             ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0)
+        if recomp:
+            if not (produced.get("planes_only") and want16 and np_out):
+                raise RuntimeError("rpnet_amd: the first layer was run without its pre-BatchNorm tensor but its output is not planes-only")
+            call("rpnet_conv1_bn_relu", ptr(x0), ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), None, ptr(zs), np_out,
+                 ptr(gamma), ptr(beta), ptr(sz), N, H, W, cout, groups)
+            ARITH[("bn_relu", "first layer made again from the image")] += 1
+        else:
+            # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
+            call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
+                 np_out, ptr(gamma), ptr(beta),
+                 ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0)
         if pool:
             ARITH[("bn_relu", "with the 2x2 max-pool")] += 1
         if want16 and np_out:
@@ -878,7 +968,9 @@ class ConvBnRelu(Function):
             produced["pbf"] = zs
         if want16:
             produced["scale"] = sz
+        _tap("fwd:y,stats", weight, y, stats)
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
+        ctx.yshape = (N, H, W, cout)
         ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
         ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
@@ -895,10 +987,34 @@ class ConvBnRelu(Function):
         pw = ctx.pw
         groups, upsample, in_mode, first = ctx.cfg
         dz = dz.contiguous()
-        N, H, W, cout = y.shape
+        _tap("bwd_in:y,stats,dz", weight, y, stats, dz)
+        N, H, W, cout = ctx.yshape
         wsb = query("rpnet_bn_workspace_bytes", cout, groups)
-        ws = _ws(wsb, y)
+        ws = _ws(wsb, dz)
         beta, bias = ctx.beta, ctx.bias
+        if y is None:
+            # the first layer without its pre-BatchNorm tensor: reduction pass and weight gradient make y again from the image
+            direct = _direct(gamma) and _direct(beta)
+            dgamma, dbeta = (None, None) if direct else (_empty((cout,), dz), _empty((cout,), dz))
+            rows = query("rpnet_conv1_bn_bwd_rows", N, H, W, cout, groups)
+            part = torch.empty(groups * rows * cout * 2, device=dz.device, dtype=torch.float64)
+            call("rpnet_conv1_bn_bwd_partial", ptr(x0), ptr(weight), ptr(bias), ptr(dz), ptr(stats), ptr(part), N, H, W, cout, groups)
+            ARITH[("bn_bwd", "first layer made again from the image")] += 1
+            if direct:
+                _order_wait(gamma.data_ptr())
+            call("rpnet_bn_bwd", ptr(dz), None, ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), None, None, 0,
+                 None, ptr(gamma.grad if direct else dgamma), ptr(beta.grad if direct else dbeta), N, H * W, cout, groups,
+                 1 if direct else 0, ptr(part), None, rows, 0, ptr(ws), wsb)
+            if direct:
+                _order_done(gamma.data_ptr())
+            dw = torch.empty_like(weight)
+            wb = query("rpnet_conv1_wgrad_workspace_bytes", N, H, W, cout)
+            ws2 = _ws(wb, dz)
+            coef = ws.data_ptr() + query("rpnet_bn_bwd_coef_offset", cout, groups)
+            call("rpnet_conv1_wgrad_bn", ptr(x0), ptr(dz), None, ptr(stats), coef, ptr(dw), N, H, W, cout, groups, ptr(ws2), wb,
+                 ptr(weight), ptr(bias))
+            db = None if _direct(bias) else torch.zeros_like(gamma)
+            return None, None, None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         # which forms of dy the two consumers (wgrad, dgrad) want: split-bf16 planes and / or fp32
         np_ = ctx.xs[0].shape[0] if ctx.xs is not None else 0
         need_d = not first and (ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]))
@@ -934,6 +1050,7 @@ class ConvBnRelu(Function):
              W if ctx.pool else 0, ptr(ws), wsb)
         if direct:
             _order_done(gamma.data_ptr())
+        _tap("bn_bwd:dz,dy,dys,sdy,ws", weight, dz, dy, dys, sdy, ws)
         dw = torch.empty_like(weight)
         dx0 = dx1 = dscale = None
         if first:
@@ -942,7 +1059,7 @@ class ConvBnRelu(Function):
             if fuse1:
                 coef = ws.data_ptr() + query("rpnet_bn_bwd_coef_offset", cout, groups)
                 call("rpnet_conv1_wgrad_bn", ptr(x0), ptr(dz), ptr(y), ptr(stats), coef, ptr(dw), N, H, W, cout, groups,
-                     ptr(ws2), wb)
+                     ptr(ws2), wb, None, None)
             else:
                 call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
         else:
@@ -976,18 +1093,24 @@ class ConvBnRelu(Function):
                             _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
                             red = _reduce_stream(dev)
                             red.wait_stream(side)
-                            for tns in (ws2, ctx.sx, ctx.sx1, sdy):           # read by the reduce (partials, the operand scales)
-                                if tns is not None:
-                                    tns.record_stream(red)
+                            if _KEEPALIVE:
+                                _ASYNC["keep"].append(ws2)
+                            else:
+                                for tns in (ws2, ctx.sx, ctx.sx1, sdy):       # read by the reduce (partials, the operand scales)
+                                    if tns is not None:
+                                        tns.record_stream(red)
                             with torch.cuda.stream(red):
                                 _cconv("rpnet_conv_wgrad", d, None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                                      ptr(ws2), wb)
                         else:
                             _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
                                  ptr(ws2), wb)
-                    for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
-                        if tns is not None:
-                            tns.record_stream(side)
+                    if _KEEPALIVE:       # alive until join_side_streams (the saved tensors outlive this node anyway)
+                        _ASYNC["keep"].append((x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy, ctx.xs))
+                    else:
+                        for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
+                            if tns is not None:
+                                tns.record_stream(side)
                     if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
                         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
                         _ASYNC["queued"] = True
@@ -1020,6 +1143,8 @@ class ConvBnRelu(Function):
                     dd.split_planes = np_
                     if np_ <= 2:
                         dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
+                        if pw.taps == 9 and x1 is None and not upsample and not need_s:
+                            _set_skip(dd, in_scale, in_mode, 0, N, H, W)
                     sb = ctx.src_bn
                     if sb is not None and x1 is None and in_scale is None and not upsample and sb.y.shape == g0.shape:
                         dd.groups = sb.groups
@@ -1036,6 +1161,7 @@ class ConvBnRelu(Function):
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
                 _cconv("rpnet_conv_fwd", dd)
+                _tap("dgrad:g0,g1", weight, g0, g1)
                 if deferred:
                     _release_wgrads(_WGRAD_DEFER - 1)
                     deferred = None

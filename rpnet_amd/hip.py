@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ("ep_shift", vp), ("ep_relu", ci), ("out_scale", vp), ("out_scale_mode", ci), ("accumulate", ci),
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
                 ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("bnb_y", vp), ("bnb_stats", vp), ("bnb_partial", vp), ("bnb_pmax", vp), ("bnb_groups", ci),
-                ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci), ("y_split_scale", vp), ("splitk_ws", vp), ("splitk_ws_bytes", cs)]
+                ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci), ("y_split_scale", vp), ("splitk_ws", vp), ("splitk_ws_bytes", cs),
+                ("skip_mask", vp), ("skip_mode", ci), ("skip_halo", ci), ("skip_ws", vp), ("tile_skip", vp)]
 
 
 PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
@@ -56,7 +57,10 @@ _SIGS = {
     "rpnet_predict_scales": (ci, [vp, vp, vp, ci, cf, ci, vp, vp]),
     "rpnet_conv1_wgrad_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_conv1_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
-    "rpnet_conv1_wgrad_bn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_conv1_wgrad_bn": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp, vp, vp]),
+    "rpnet_conv1_bn_relu": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_conv1_bn_bwd_rows": (ci, [ci, ci, ci, ci, ci]),
+    "rpnet_conv1_bn_bwd_partial": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_bn_bwd_coef_offset": (cs, [ci, ci]),
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
     "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),

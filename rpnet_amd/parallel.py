@@ -85,7 +85,7 @@ class FlatGradBucket:
             if not self._active() or not self.hooks_enabled:
                 return
             from .functional import join_side_streams
-            join_side_streams()      # async weight gradients of the segment must have landed in the bucket
+            join_side_streams(final=False)      # async weight gradients of the segment must have landed in the bucket
             for s in range(len(self.bounds) - 2, seg - 1, -1):
                 if s not in self._work:
                     self._work[s] = dist.all_reduce(self.flat[self.bounds[s]:self.bounds[s + 1]], op=dist.ReduceOp.SUM,

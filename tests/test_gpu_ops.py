@@ -365,6 +365,55 @@ def test_conv_masked_inputs(RF, conv_math):
         assert rel_err(nchw(xg.grad), xr.grad) < TOL and rel_err(conv.weight.grad, c_ref.weight.grad) < TOL
 
 
+@pytest.mark.parametrize("math", ["f16x2", "f16"])
+@pytest.mark.parametrize("training", [True, False])
+def test_masked_conv_zero_tile_skip_is_bit_identical(RF, math, training):
+    """w_k(x * mask) / w_q(x * (1 - mask)) on the LDS-DMA patch kernel with the zero-tile skip (rpnet_conv_desc.skip_*: tiles whose
+    masked input is zero on the tile and its halo — forward — or whose factor is zero on the tile — input gradient — run no K
+    loop) against the same launches dense: output, input gradient, weight gradient, BatchNorm gradients and running statistics
+    BIT-identical; the launch counters show that the skip was armed; a mask that is zero nowhere skips nothing and is also equal."""
+    from rpnet_amd import modules as RM
+    N, H, W, Cc = 2, 64, 64, 256
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, H, W, Cc, generator=g)
+    blob = torch.zeros(N, H, W)
+    blob[0, 10:22, 30:41] = torch.rand(12, 11, generator=g) * 0.9 + 0.1          # 3 % of the pixels, image 1 empty
+    go = torch.randn(N, H, W, Cc, generator=g)
+    old_math, old_min, old_skip = RF.conv_math(), RM._F16_MIN_PIXELS, RF._MASK_SKIP
+    RF.set_conv_math(math)
+    RF.set_f16_active(True)
+    try:
+        for mask in (blob, blob * 0 + 0.5):
+            for mode in (1, 2):
+                res = []
+                for skip in (False, True):
+                    RF._MASK_SKIP = skip
+                    conv, bn = _mk_layer(Cc, Cc, 3, 40 + mode)
+                    conv, bn = conv.to(DEV), bn.to(DEV).train(training)
+                    xg = x.to(DEV).requires_grad_(training)
+                    RF.reset_arith()
+                    scale = torch.full((1,), 2.0 ** -12, device=DEV)        # |x| < 2^3: x / scale < 2^15
+                    with torch.set_grad_enabled(training):
+                        out = RF.conv_bn_relu_op(RF.Operand(xg, scale=scale), conv, bn, RF.WeightCache(), training, in_scale=mask.to(DEV),
+                                                 in_mode=mode, out_split=False)
+                    z = out.x
+                    armed = RF.arith_counts().get("zero_tile_skip", {}).get("armed", 0)
+                    assert (armed > 0) == skip, (skip, RF.arith_counts())
+                    got = [z.detach().clone()]
+                    if training:
+                        z.backward(go.to(DEV))
+                        got += [xg.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                                bn.running_mean.clone(), bn.running_var.clone()]
+                    torch.cuda.synchronize()
+                    res.append(got)
+                for a, b in zip(*res):
+                    assert torch.equal(a, b), (mode, float((a - b).abs().max()))
+    finally:
+        RF._MASK_SKIP = old_skip
+        RF.set_conv_math(old_math)
+        RM._F16_MIN_PIXELS = old_min
+
+
 @pytest.mark.parametrize("training", [False, True])
 def test_first_conv_cin1(RF, training):
     N, H, W = 2, 16, 24

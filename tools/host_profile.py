@@ -33,6 +33,8 @@ if a.eval:
         with torch.no_grad():
             net(si, fg, bg, qi, appr_query_labels=appr)
 else:
+    import rpnet_amd.functional as RF
+    RF.set_async_wgrad(True)          # the bench's step: weight gradients on the side streams, straight into the bucket
     bucket = FlatGradBucket(net)
     inp = bench.make_inputs(1234, a.batch or 8, 256, dev)
 

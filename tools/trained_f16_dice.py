@@ -4,7 +4,7 @@ arithmetic) and amplifies the few thresholded pixels that differ between two ari
 <= 1e-3" is about a model that segments.  This tool trains the model with train_rpnet.train (synthetic episodes, Adam) for a
 few hundred steps, then runs configs[4]'s call (2-way 1-shot, 512^2, T = 10, batch 4; also 1-way 256^2 T = 5 batch 8) under
 both arithmetics WITHOUT teacher forcing and reports per-iteration Dice / foreground fraction and their deviations.
-    python tools/trained_f16_dice.py [steps] [train_size] [lr]      -> one JSON line"""
+    python tools/trained_f16_dice.py [steps] [train_size] [lr] [train_ways] [train_T]      -> one JSON line"""
 import json
 import os
 import sys
@@ -15,21 +15,42 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rpnet_amd.functional as RF  # noqa: E402
 import rpnet_amd.modules as RM  # noqa: E402
 import train_rpnet as T  # noqa: E402
-from tests.helpers import episode_tensors, load_cfg  # noqa: E402
+from rpnet_amd.utils.synth import make_episode  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def dice_fg(lg, ql, cls=1):
-    pred = (lg.argmax(1) == cls).long()
-    lab = (ql == cls).long()
-    return float(2.0 * (pred * lab).sum() / (pred.sum() + lab.sum() + 1e-7)), float(pred.float().mean())
+def load_cfg(T):
+    import yaml
+    cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
+    cfg["n_iter_refinement"] = T
+    return cfg
 
 
-def train_weights(steps, size, lr, dev, batch=4, seed=7):
+def episode_tensors(seed, B, size, device, n_shots=1, n_ways=1):
+    ep = make_episode(seed, B, size, n_shots=n_shots, n_ways=n_ways)
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    return ([[t(s) for s in way] for way in ep["support_images"]], [[t(s) for s in way] for way in ep["support_fg"]],
+            [[t(s) for s in way] for way in ep["support_bg"]], [t(ep["query_images"])], t(ep["query_labels"]),
+            t(ep["appr_query_labels"]))
+
+
+def dice_fg(lg, ql):
+    """(mean Dice over the foreground classes, foreground fraction) of the argmax prediction"""
+    am = lg.argmax(1)
+    ds = []
+    for cls in range(1, lg.shape[1]):
+        pred, lab = (am == cls).long(), (ql == cls).long()
+        ds.append(float(2.0 * (pred * lab).sum() / (pred.sum() + lab.sum() + 1e-7)))
+    return sum(ds) / len(ds), float((am > 0).float().mean())
+
+
+def train_weights(steps, size, lr, dev, batch=4, seed=7, n_ways=1, iters=4):
     RM._F16_MIN_PIXELS = 0
     RF.set_conv_math("f16x2")
     torch.manual_seed(1234)
-    cfg = load_cfg(4)
-    net, hist = T.train(cfg, steps, batch, size, dev, lr=lr, log_every=0, seed=seed)
+    cfg = load_cfg(iters)
+    net, hist = T.train(cfg, steps, batch, size, dev, lr=lr, log_every=0, seed=seed, n_ways=n_ways)
     RF.set_async_wgrad(False)
     return net, hist
 
@@ -37,7 +58,7 @@ def train_weights(steps, size, lr, dev, batch=4, seed=7):
 def free_running(net, case, dev, train_mode):
     """{math: [(dice, fg) per iteration]} of one call under f16x2 and f16, the loop running on its own masks"""
     size, B, Tn, ways, seed = case
-    (si, fg, bg, qi, ql, appr), _ = episode_tensors(seed, B, size, dev, n_shots=1, n_ways=ways)
+    si, fg, bg, qi, ql, appr = episode_tensors(seed, B, size, dev, n_shots=1, n_ways=ways)
     net.num_iter = Tn
     net.train(train_mode)
     state = {k: v.clone() for k, v in net.state_dict().items()}
@@ -67,10 +88,12 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     lr = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
+    ways = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     dev = torch.device("cuda", 0)
-    net, hist = train_weights(steps, size, lr, dev)
-    out = {"train": {"steps": steps, "size": size, "batch": 4, "lr": lr, "arithmetic": "f16x2", "first_loss": round(hist[0], 4),
-                     "mean_last_20": round(sum(hist[-20:]) / 20, 4)}}
+    net, hist = train_weights(steps, size, lr, dev, n_ways=ways, iters=iters)
+    out = {"train": {"steps": steps, "size": size, "batch": 4, "lr": lr, "ways": ways, "T": iters, "arithmetic": "f16x2",
+                     "first_loss": round(hist[0], 4), "mean_last_20": round(sum(hist[-20:]) / 20, 4)}}
     for name, case in CASES.items():
         for mode in (True, False):
             res = free_running(net, case, dev, mode)

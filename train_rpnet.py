@@ -48,7 +48,7 @@ def episode(seed, batch, size, dev):
             [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"]))
 
 
-def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, seed=0, steps_per_epoch=50):
+def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, seed=0, steps_per_epoch=50, n_ways=1, n_shots=1):
     rank = dist.get_rank() if dist.is_initialized() else 0
     net = model_factory[config.get("net", "RP_Net")](pretrained_path=config.get("pretrained_path"),
                                                     cfg={"align": True, "backbone": config.get("backbone", "UNet")},
@@ -71,17 +71,19 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
     # step (~32 ms at batch 8) is not waiting for the generator (~70 ms)
     import concurrent.futures
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
-    pending = [pool.submit(make_episode, seed + 1000 * rank + k, batch, size) for k in range(min(4, steps))]
+    gen = lambda k: pool.submit(make_episode, seed + 1000 * rank + k, batch, size, n_shots=n_shots, n_ways=n_ways)  # noqa: E731
+    pending = [gen(k) for k in range(min(4, steps))]
 
     def to_dev(ep):
         t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)  # noqa: E731
-        return ([[t(ep["support_images"][0][0])]], [[t(ep["support_fg"][0][0])]], [[t(ep["support_bg"][0][0])]],
-                [t(ep["query_images"])], t(ep["query_labels"]), t(ep["appr_query_labels"]))
+        return ([[t(s) for s in way] for way in ep["support_images"]], [[t(s) for s in way] for way in ep["support_fg"]],
+                [[t(s) for s in way] for way in ep["support_bg"]], [t(ep["query_images"])], t(ep["query_labels"]),
+                t(ep["appr_query_labels"]))
 
     for it in range(steps):
         si, fg, bg, qi, ql, appr = to_dev(pending.pop(0).result())
         if it + 4 < steps:
-            pending.append(pool.submit(make_episode, seed + 1000 * rank + it + 4, batch, size))
+            pending.append(gen(it + 4))
         bucket.zero()                       # gradients live in the flat bucket: one memset instead of zero_grad
         out = net(si, fg, bg, qi, appr_query_labels=appr)
         loss = objective(out, ql, scaler)
