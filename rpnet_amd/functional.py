@@ -513,10 +513,17 @@ _CONV1_RECOMP = os.environ.get("RPNET_CONV1_RECOMPUTE", "1") == "1"
 _MASK_SKIP = os.environ.get("RPNET_MASK_SKIP", "1") == "1"
 
 
+_SKIP_STATS = None     # diagnostic (bench.py): a list that receives every launch's flag buffer (preset to 255 = "no tile here")
+
+
 def _set_skip(d, mask, mode, halo, N, H, W):
     """lend a launch the mask and the flag scratch of the tile skip (only the LDS-DMA patch kernels use them)"""
     if _MASK_SKIP and mask is not None and mode in (1, 2):
-        d._skip_ws = torch.empty(max(N * H * W // 128, 16), device=mask.device, dtype=torch.uint8)
+        if _SKIP_STATS is not None:
+            d._skip_ws = torch.full((max(N * H * W // 128, 16),), 255, device=mask.device, dtype=torch.uint8)
+            _SKIP_STATS.append(d._skip_ws)
+        else:
+            d._skip_ws = torch.empty(max(N * H * W // 128, 16), device=mask.device, dtype=torch.uint8)
         d.skip_mask, d.skip_mode, d.skip_halo, d.skip_ws = ptr(mask), mode, halo, ptr(d._skip_ws)
         ARITH[("zero_tile_skip", "armed")] += 1
 

@@ -123,10 +123,14 @@ class GraphedTrainStep:
         # Under a process group on RCCL the collective library's watchdog THREAD polls its events (hipEventQuery) at any time;
         # in the default (global) capture mode that call from another thread is an error while this thread captures and takes
         # the process down ("operation not permitted when stream is capturing").  Thread-local mode restricts only this thread.
-        # Only there: with gloo (the one-GPU plumbing tests) thread-local mode ended two of three captures in a segmentation fault
-        # inside hipStreamEndCapture (nodes recorded from autograd's thread; measured round 4), global mode none.
+        # Under gloo (the one-GPU plumbing backend) neither mode is usable on this ROCm: thread-local mode ended three of five
+        # captures in a segmentation fault inside hipStreamEndCapture, global mode hung five of five — refuse instead of crashing.
         import torch.distributed as dist
-        mode = "thread_local" if (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl") else "global"
+        ddp = dist.is_available() and dist.is_initialized()
+        if ddp and dist.get_backend() != "nccl" and dist.get_world_size() > 1:
+            raise RuntimeError("rpnet_amd.graph.GraphedTrainStep: HIP stream capture under a gloo process group is not supported "
+                               "(gloo's helper threads touch the device while the step is captured); use the eager step or RCCL")
+        mode = "thread_local" if ddp else "global"
         with torch.cuda.graph(g, capture_error_mode=mode):
             loss = self._run(st)
         self._graphs[key] = (g, st, loss)

@@ -215,9 +215,9 @@ def test_bench_two_ranks_on_one_gpu():
     dinfo = res["distributed"]
     assert dinfo["rccl_ranks_seen"] == 2 and dinfo["world_size"] == 2 and dinfo["backend"].startswith("gloo")
     assert dinfo["allreduce_exposed_ms"] >= 0 and len(dinfo["bucket_segments_mb"]) == 3
-    # both ways of issuing the step are in the line: eager + overlapped exchange, graph replay + one exposed all-reduce
-    assert {dinfo["issued"], dinfo["other_issue_mode"]["issued"]} == {"eager", "hip_graph_replay"}
-    assert dinfo["other_issue_mode"]["value"] > 0
+    # eager + overlapped exchange here; the graph-replay form is measured under RCCL only (test_bench_forced_rccl_group_on_one_gpu):
+    # a HIP stream capture beside gloo's helper threads crashes or hangs on this ROCm (bench.py)
+    assert dinfo["issued"] == "eager" and dinfo["other_issue_mode"] is None
 
 
 def _train_worker(rank, world, port, q):

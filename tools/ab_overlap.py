@@ -45,7 +45,10 @@ if True:
         ms = 1e3 * (time.perf_counter() - t0) / steps
         best = ms if best is None else min(best, ms)
 batch = 4 if c5 else (16 if c2 else 8)
-print(f"{'configs[4]' if c5 else ('configs[2]' if c2 else 'configs[1]')} enc_streams={os.environ.get('RPNET_ENC_STREAMS', 'default')} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
+r4 = " ".join(f"{k[6:].lower()}={v}" for k, v in sorted(os.environ.items())
+              if k in ("RPNET_MASK_SKIP", "RPNET_WGRAD_KEEPALIVE", "RPNET_PACK_STREAM", "RPNET_CONV1_RECOMPUTE", "RPNET_BN_POOL_ALONE",
+                       "RPNET_BN_POOL_DRAIN", "RPNET_BNBWD_FUSE"))
+print(f"{'configs[4]' if c5 else ('configs[2]' if c2 else 'configs[1]')} [{r4 or 'round-4 defaults'}] enc_streams={os.environ.get('RPNET_ENC_STREAMS', 'default')} BN_LDS={os.environ.get('RPNET_BN_LDS', 'window')} main_priority={prio} "
       f"wgrad_defer={os.environ.get('RPNET_WGRAD_DEFER', '1')} cre_streams_train={os.environ.get('RPNET_CRE_STREAMS_TRAIN', '1')} "
       f"dice_multi={os.environ.get('RPNET_DICE_MULTI', '1')} async={os.environ.get('RPNET_ASYNC_WGRAD', '1')}: "
       f"best of 3 x {steps} steps {best:.3f} ms/step = {batch / best * 1e3:.1f} pairs/s", flush=True)

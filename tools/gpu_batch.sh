@@ -1,8 +1,11 @@
 # scratch batch for one gpurun call (edited per call; outputs under gpurun_out/)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04_dist_debug4.txt
-run() { echo "=== $*"; env "$@" RPNET_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python bench.py --gpus 2 --steps 2 --warmup 1 --batch 2 --size 128 --iters 2 --no-cpu-baseline 2>&1 | grep -E "SIGSEGV|^\{" | cut -c1-120 | head -3; }
-( for i in 1 2 3 4 5; do run A=$i; done ) > $O 2>&1
-cat $O
-python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/r04_gputest_e.log
-tail -15 gpurun_out/r04_gputest_e.log
+python -m pytest tests/test_gpu_dist.py tests/test_gpu_model.py -m gpu -q --timeout 600 --tb=short -k "forced_rccl or reduction_in_dgrad or maxpool_in_one_pass or (extension_rows and bf16x3)" 2>&1 | grep -v "UserWarning\|run_backward" | tail -60 > gpurun_out/r04_gputest_g.log
+tail -60 gpurun_out/r04_gputest_g.log
+( RPNET_BN_POOL_ALONE=0 python tools/ab_overlap.py | tail -1
+  python tools/ab_overlap.py | tail -1
+  RPNET_BN_POOL_ALONE=0 python tools/ab_overlap.py | tail -1
+  python tools/ab_overlap.py | tail -1
+  AB_CONFIG=c5 RPNET_BNBWD_FUSE=1 python tools/ab_overlap.py 10 | tail -1
+  AB_CONFIG=c5 python tools/ab_overlap.py 10 | tail -1 ) 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu.ids" > gpurun_out/r04_ab2.txt
+cat gpurun_out/r04_ab2.txt

@@ -3,7 +3,7 @@
 # the bench lines of the same tree.  Run on the GPU box through gpurun:   bash tools/profile_all.sh r02
 # Raw outputs stay in gpurun_out/prof_<tag>/raw (scratch, deleted at the end); the summaries made by tools/*.py land
 # in gpurun_out/prof_<tag>/ and are copied into profiles/<tag>_* by hand.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$TAG
 R=$O/raw
@@ -31,6 +31,25 @@ python tools/pmc_sq.py $(csvc $R/pmc_sq) $O/${TAG}_pmc_sq_wave_cycles.json > $O/
 ./tools/probe/lds_mfma_probe > $O/${TAG}_lds_mfma_probe.txt 2>&1
 # host enqueue cost and launch counts of the headline step
 python tools/cpu_overhead.py 2>/dev/null | grep -v Warning > $O/${TAG}_cpu_overhead.txt
+# configs[4] (one fp16 plane, 2-way 512^2): HBM traffic of its conv launches (two PMC passes; bench.py picks the file up as
+# roofline.traffic of other_configs.configs[4])
+S5="env RPNET_BENCH_GRAPH=0 python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 2 --warmup 1 --no-cpu-baseline"
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/pmc_fetch5 -o p --output-format csv -- $S5 > $R/pmc_fetch5.log 2>&1
+RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/pmc_write5 -o p --output-format csv -- $S5 > $R/pmc_write5.log 2>&1
+python tools/pmc_traffic.py $(csvc $R/pmc_fetch5) $(csvc $R/pmc_write5) $O/${TAG}_pmc_traffic_f16_512.json > $O/${TAG}_pmc_traffic_f16_512.txt
+# round 4's switches, each against the default, one process per variant, back to back on this box (the tool's step has the
+# zero-tile skip at its library default, ON; bench.py's headline is measured with it OFF)
+( python tools/ab_overlap.py | tail -1
+  RPNET_MASK_SKIP=0 python tools/ab_overlap.py | tail -1
+  RPNET_WGRAD_KEEPALIVE=0 python tools/ab_overlap.py | tail -1
+  RPNET_PACK_STREAM=0 python tools/ab_overlap.py | tail -1
+  RPNET_CONV1_RECOMPUTE=0 python tools/ab_overlap.py | tail -1
+  RPNET_BN_POOL_ALONE=0 RPNET_BN_POOL_DRAIN=0 python tools/ab_overlap.py | tail -1
+  RPNET_ENC_STREAMS=3 python tools/ab_overlap.py | tail -1
+  python tools/ab_overlap.py | tail -1
+  AB_CONFIG=c5 python tools/ab_overlap.py 10 | tail -1
+  AB_CONFIG=c5 RPNET_MASK_SKIP=0 python tools/ab_overlap.py 10 | tail -1
+  AB_CONFIG=c5 RPNET_BNBWD_FUSE=1 python tools/ab_overlap.py 10 | tail -1 ) 2>/dev/null | sed 's/^configs/    configs/' > $O/${TAG}_ab_round4.txt
 # A/B of the step's scheduling switches, one process per variant, back to back on this box
 ( RPNET_WGRAD_DEFER=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_BN_LDS=big RPNET_DICE_MULTI=0 python tools/ab_overlap.py | tail -1
   RPNET_WGRAD_DEFER=0 python tools/ab_overlap.py | tail -1
