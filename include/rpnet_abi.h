@@ -201,6 +201,14 @@ typedef struct rpnet_conv_desc {
        unless a weight or gradient is Inf / NaN. */
     const float* skip_mask; int skip_mode; int skip_halo; unsigned char* skip_ws;
     const unsigned char* tile_skip;    /* internal (set by the launcher): flags [M tiles], 0 = skip */
+    /* Optional (round 4, the one-plane fp16 arithmetic of BASELINE configs[4]): the pre-BatchNorm output y0 is written as 2-byte
+       codes instead of fp32 — y0 then points to Co0-channel fp16 rows, code = fp16((y - a[c]) * b[c]) with a = y_enc[c],
+       b = y_enc[y_enc_stride + c] per output channel (the caller derives them from the layer's RUNNING statistics before the
+       launch: a = running_mean, b = a power of two near 2^-4 / sqrt(running_var + eps), so that codes are O(1) whatever the
+       batch and fp16 cannot overflow below ~1e6 standard deviations; saturating).  BatchNorm is invariant under a per-channel
+       affine map of its input, so rpnet_bn_relu / rpnet_bn_bwd decode with (a, 1 / b) (their y_dec argument) and nothing else
+       changes; the fused statistics (stats_partial) still come from the fp32 accumulators.  Single destination, no eval affine. */
+    const float* y_enc; int y_enc_stride;
 } rpnet_conv_desc;
 
 int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
@@ -308,9 +316,11 @@ int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* run
  * [N, H/2, W/2, C], the full-resolution z is never written; rpnet_bn_bwd with the same pool_w takes dz of that pooled
  * shape, finds each window's first maximum (row, column scan order, as rpnet_maxpool2_bwd) again from y and writes dy at
  * full resolution (dy_split required, no given_partial). */
+/* y_dec != NULL (round 4): `y` holds the 2-byte codes a convolution wrote with rpnet_conv_desc.y_enc = (a, b); y_dec = (a, 1 / b):
+ * a at [0 .. C), 1 / b at [y_dec_stride .. y_dec_stride + C) */
 int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
                   const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
-                  int pool_w, rpnet_stream_t stream);
+                  int pool_w, const float* y_dec, int y_dec_stride, rpnet_stream_t stream);
 /* the fp16 tensor scale of a BatchNorm + ReLU output alone (same value rpnet_bn_relu writes with planes == 2) */
 int rpnet_bn_act_scale(const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
                        rpnet_stream_t stream);
@@ -319,7 +329,8 @@ int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const floa
                  float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
                  const double* given_partial, const float* given_pmax, int given_rows /* NULL, NULL, 0: the reduction pass
                  runs here; else it already ran in the epilogue that produced dz (rpnet_conv_desc.bnb_*) */,
-                 int pool_w, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
+                 int pool_w, void* workspace, size_t workspace_bytes, const float* y_dec /* as rpnet_bn_relu */, int y_dec_stride,
+                 rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:
  * dy = dz * [z > 0] (z may be NULL: no ReLU behind the conv) and db[c] = sum_pixels dy[p][c] */

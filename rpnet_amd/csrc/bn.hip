@@ -16,6 +16,27 @@ struct BnGeom {
     int rows_blk;  // rows per block
 };
 
+// The pre-BatchNorm tensor as the passes read it: fp32, or (round 4, the one-plane fp16 arithmetic) 2-byte codes
+// (y - a[c]) * b[c] written by the convolution's epilogue (rpnet_conv_desc.y_enc) and decoded here with dec = (a, 1 / b):
+// a [0 .. C), 1 / b [stride .. stride + C).  `off` = element offset of 4 consecutive channels starting at channel c.
+struct YSrc {
+    const float* y;      // fp32 tensor, or the fp16 codes (dec != nullptr)
+    const float* dec;
+    int stride;
+};
+__device__ __forceinline__ f32x4 load_y4(const YSrc s, const size_t off, const int c) {
+    if (s.dec) {
+        using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
+        const h16x4 hv = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(s.y) + off);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s.dec + c), ib = *reinterpret_cast<const f32x4*>(s.dec + s.stride + c);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)hv[k] * ib[k] + a[k];
+        return v;
+    }
+    return *reinterpret_cast<const f32x4*>(s.y + off);
+}
+
 // most blocks (= partial-sum rows) per group: the reduction passes keep two 16-byte loads per thread in flight, so the
 // 64- and 128-channel levels (0.13 - 0.5 M rows per group) need ~8 blocks per CU to cover the HBM latency (bn_bwd_partial:
 // 28.7 -> 23.8 us per launch against 2 per CU); bounded by the workspace, 131072 partial sums per group
@@ -167,7 +188,7 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_relu_kernel(const YSrc ysrc, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ z,
                                                        size_t total4, int C4, size_t group4, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float sqrt_n,
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
         const int g = (int)(i / group4);
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 v = load_y4(ysrc, i * 4, c4 * 4);
         const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[g * C4 + c4];
         const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[g * C4 + c4];
         f32x4 o;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_act_scale_kernel(const float* __restri
 }
 
 template <int NP>
-__global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_relu_split_kernel(const YSrc ysrc, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ z,
                                                              unsigned short* __restrict__ zs, size_t total8, int C8,
                                                              size_t group8, size_t plane_elems, const float* __restrict__ gamma,
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
         float v[8];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 a = reinterpret_cast<const f32x4*>(y)[i * 2 + hh];
+            const f32x4 a = load_y4(ysrc, i * 8 + hh * 4, c8 * 8 + hh * 4);
             const f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
             f32x4 o;
 #pragma unroll
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* __restr
 
 // partial[(g*nblk + blk)][C][2] doubles: s1 = sum dz*m, s2 = sum dz*m*xhat; pmax[(g*nblk + blk)][C] = max |dz*m| (optional)
 template <int WIN>
-__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dz, const YSrc ysrc,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        double* __restrict__ partial, float* __restrict__ pmax, long R, int C,
@@ -300,15 +321,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
         const long stride = (long)gm.nblk * gm.rows_it;
         long r = (long)blk * gm.rows_it + tr;
         for (; r + stride < R; r += 2 * stride) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C);
+            const f32x4 v0 = load_y4(ysrc, base + (size_t)r * C, tc * 4);
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(y + base + (size_t)(r + stride) * C);
+            const f32x4 v1 = load_y4(ysrc, base + (size_t)(r + stride) * C, tc * 4);
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(dz + base + (size_t)(r + stride) * C);
             take(v0, d0);
             take(v1, d1);
         }
         if (r < R)
-            take(*reinterpret_cast<const f32x4*>(y + base + (size_t)r * C), *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C));
+            take(load_y4(ysrc, base + (size_t)r * C, tc * 4), *reinterpret_cast<const f32x4*>(dz + base + (size_t)r * C));
     }
     rows_reduce<WIN, true>(s1, s2, mx, red, redm, t, tc, tr, gm.C4, gm.rows_it);
     if (tr == 0) {
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz, const YSrc ysrc,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ coef, float* __restrict__ dy,
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
         const int c4 = (int)(i % C4);
         const int g = (int)(i / group4);
         const int o = g * C + c4 * 4;
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 v = load_y4(ysrc, i * 4, c4 * 4);
         const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i];
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
@@ -392,7 +413,7 @@ template <int NP>
 // the 128 registers per lane a resident LDS-DMA GEMM wave leaves free on its SIMD (one at 68): the pass runs beside the
 // weight-gradient launches of the side stream — 18.09 -> 18.05 ms per batch-8 step, configs[4] 33.34 -> 33.11 ms (the
 // three-plane form, bf16x3, pays for the cap with two spilled dwords)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_bwd_apply_split(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_bwd_apply_split(const float* __restrict__ dz, const YSrc ysrc,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dy,
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int o = g * C + c8 * 8 + hh * 4;
-            const f32x4 v = reinterpret_cast<const f32x4*>(y)[i * 2 + hh];
+            const f32x4 v = load_y4(ysrc, i * 8 + hh * 4, c8 * 8 + hh * 4);
             const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i * 2 + hh];
             const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
@@ -455,7 +476,7 @@ struct PoolGeom {
 
 // thread = one pooled pixel x 8 channels; planes [NP][N, Ho, Wo, C] of relu(max) / s (and the fp32 pooled tensor when zp != NULL)
 template <int NP>
-__global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const YSrc ysrc, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, float* __restrict__ zp,
                                                                   unsigned short* __restrict__ zs, size_t total8, int C8,
                                                                   PoolGeom pg, size_t plane_elems, const float* __restrict__ gamma,
@@ -480,14 +501,15 @@ __global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const float* __
         const int g = n / pg.imgs_per_group;
         const float* sc = scale + (size_t)(g * C8 + c8) * 8;
         const float* sh = shift + (size_t)(g * C8 + c8) * 8;
-        const float* src = y + (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C8 * 8 + c8 * 8;
+        const size_t src = (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C8 * 8 + c8 * 8;
         float v[8];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + hh * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(src + C8 * 8 + hh * 4);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(src + rowC + hh * 4);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(src + rowC + C8 * 8 + hh * 4);
+            const int cc = c8 * 8 + hh * 4;
+            const f32x4 a = load_y4(ysrc, src + hh * 4, cc);
+            const f32x4 b = load_y4(ysrc, src + C8 * 8 + hh * 4, cc);
+            const f32x4 c = load_y4(ysrc, src + rowC + hh * 4, cc);
+            const f32x4 d = load_y4(ysrc, src + rowC + C8 * 8 + hh * 4, cc);
             const f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
             f32x4 o;
 #pragma unroll
@@ -521,7 +543,7 @@ __device__ __forceinline__ int pool_argmax(const float a0, const float a1, const
 // reduction pass over POOLED rows (Rp = R / 4 per group): dz is zero off the window maxima, so
 // s1 = sum dp [z_max > 0], s2 = sum dp [z_max > 0] xhat(argmax); same partial layout as bn_bwd_partial
 template <int WIN>
-__global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restrict__ dp, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restrict__ dp, const YSrc ysrc,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             double* __restrict__ partial, float* __restrict__ pmax, long Rp, int C,
@@ -548,9 +570,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
         for (long r = r0 + tr; r < r1; r += gm.rows_it) {
             const int nl = (int)(r / hw), rem = (int)(r - (long)nl * hw);
             const int oy = rem / pg.Wo, ox = rem - oy * pg.Wo;
-            const float* src = y + gbase + (size_t)nl * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + C);
-            f32x4 v2 = *reinterpret_cast<const f32x4*>(src + rowC), v3 = *reinterpret_cast<const f32x4*>(src + rowC + C);
+            const size_t src = gbase + (size_t)nl * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C;
+            f32x4 v0 = load_y4(ysrc, src, tc * 4), v1 = load_y4(ysrc, src + C, tc * 4);
+            f32x4 v2 = load_y4(ysrc, src + rowC, tc * 4), v3 = load_y4(ysrc, src + rowC + C, tc * 4);
             f32x4 d = *reinterpret_cast<const f32x4*>(dp + ((size_t)g * Rp + r) * C + tc * 4);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(d) : : "memory");
 #pragma unroll
@@ -591,7 +613,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
 // depending on what else is resident; with the full wait: 0 of 16.  The wrong decisions moved the gradients of the
 // layers below by 1e-4 ... 5e-2 (relative, max norm) in those steps.
 template <int NP, bool DRAIN = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const YSrc ysrc,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, float* __restrict__ dy,
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __re
             const int o = g * C + c8 * 8 + hh * 4;
             f32x4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(y + offs[q] + hh * 4);
+            for (int q = 0; q < 4; ++q) v[q] = load_y4(ysrc, offs[q] + hh * 4, c8 * 8 + hh * 4);
             f32x4 d = reinterpret_cast<const f32x4*>(dp)[i * 2 + hh];
             f32x4 sc = *reinterpret_cast<const f32x4*>(scale + o);
             f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
@@ -738,9 +760,11 @@ extern "C" int rpnet_bn_eval_affine(const float* gamma, const float* beta, const
 
 extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
                              const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
-                             int pool_w, rpnet_stream_t stream) {
+                             int pool_w, const float* y_dec, int y_dec_stride, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && scale && shift && (z || z_split), RPNET_ERR_ARG, "bn_relu: null pointer");
+    RPNET_REQUIRE(!y_dec || y_dec_stride >= C, RPNET_ERR_ARG, "bn_relu: y_dec_stride=%d < C=%d", y_dec_stride, C);
+    const YSrc ysrc{y, y_dec, y_dec_stride};      // y_dec != NULL: y holds fp16 codes (rpnet_conv_desc.y_enc)
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
     if (pool_w > 0) {      // + MaxPool2d(2, 2): z / z_split are [N, H/2, W/2, C]
         RPNET_REQUIRE(z_split && planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_ARG, "bn_relu: the pooled form writes split planes (planes=%d C=%d)", planes, C);
@@ -750,7 +774,7 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * (HW / 4) * C;
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
 #define RPNET_BN_POOL(NP_)                                                                                                  \
-    hipLaunchKernelGGL(bn_relu_pool_split_kernel<NP_>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z, \
+    hipLaunchKernelGGL(bn_relu_pool_split_kernel<NP_>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale, shift, z, \
                        (unsigned short*)z_split, total8, C / 8, pg, pe, gamma, beta, sqrt_n, split_scale)
         if (planes == 3) RPNET_BN_POOL(3);
         else if (planes == 2) RPNET_BN_POOL(2);
@@ -766,18 +790,18 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
                       "bn_relu: fp16 planes (1 or 2) need gamma, beta and the scale output");
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
         if (planes == 3)
-            hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+            hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         else if (planes == 2)
-            hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+            hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         else
-            hipLaunchKernelGGL(bn_relu_split_kernel<1>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, y, scale,
+            hipLaunchKernelGGL(bn_relu_split_kernel<1>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
                                shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
         return check_launch("bn_relu_split");
     }
     RPNET_REQUIRE(!split_scale || (gamma && beta), RPNET_ERR_ARG, "bn_relu: the tensor scale needs gamma and beta");
-    hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, z,
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, ysrc, scale, shift, z,
                        total4, C / 4, group4, gamma, beta, sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f, split_scale);
     return check_launch("bn_relu");
 }
@@ -795,9 +819,11 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
                             const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
                             float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
                             const double* given_partial, const float* given_pmax, int given_rows, int pool_w, void* workspace,
-                            size_t workspace_bytes, rpnet_stream_t stream) {
+                            size_t workspace_bytes, const float* y_dec, int y_dec_stride, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
+    RPNET_REQUIRE(!y_dec || y_dec_stride >= C, RPNET_ERR_ARG, "bn_bwd: y_dec_stride=%d < C=%d", y_dec_stride, C);
+    const YSrc ysrc{y, y_dec, y_dec_stride};      // y_dec != NULL: y holds fp16 codes (rpnet_conv_desc.y_enc)
     RPNET_REQUIRE(dz && scale && shift && mean && invstd && dgamma && dbeta && workspace, RPNET_ERR_ARG, "bn_bwd: null pointer");
     // y may be NULL only where nothing reads it: the reduction already ran elsewhere (given_partial) and no dy is asked for
     RPNET_REQUIRE(y || (given_partial && !dy && !dy_split), RPNET_ERR_ARG, "bn_bwd: y is NULL but a pass that reads it was asked for");
@@ -826,10 +852,10 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         // share a CU with a block of the LDS-DMA GEMM kernels (147 - 156 of 160 KB) — see bn_bwd_apply_pool_split
         static const size_t alone = [] { const char* e = getenv("RPNET_BN_POOL_ALONE"); return (e && e[0] == '0') ? (size_t)0 : (size_t)24576; }();
         if (bn_lds_window() == 64)
-            hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);
         else
-            hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
@@ -837,9 +863,9 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         // DRAIN (default; RPNET_BN_POOL_DRAIN=0: the A/B switch that brings the fault back): see bn_bwd_apply_pool_split
         static const bool drain = [] { const char* e = getenv("RPNET_BN_POOL_DRAIN"); return !(e && e[0] == '0'); }();
 #define RPNET_BN_POOL_BWD(NP_)                                                                                              \
-    do { if (drain) hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, true>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, \
+    do { if (drain) hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, true>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, \
                        (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale); \
-    else hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, false>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, y, scale, shift, mean, invstd, \
+    else hipLaunchKernelGGL((bn_bwd_apply_pool_split<NP_, false>), dim3(elt_grid(total8)), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, \
                        (const float*)coef, dy, (unsigned short*)dy_split, total8, C, pg, pe, (const float*)bound, split_scale); } while (0)
         if (planes == 3) RPNET_BN_POOL_BWD(3);
         else if (planes == 2) RPNET_BN_POOL_BWD(2);
@@ -855,10 +881,10 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
                            accumulate, f16 ? given_pmax : (const float*)nullptr, scale, bound);
     } else {
         if (bn_lds_window() == 64)
-            hipLaunchKernelGGL(bn_bwd_partial<64>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial<64>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, R, C, gm);
         else
-            hipLaunchKernelGGL(bn_bwd_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, y, scale, shift, mean, invstd, partial,
+            hipLaunchKernelGGL(bn_bwd_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, R, C, gm);
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
@@ -870,20 +896,20 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     if (dy_split) {
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
         if (planes == 3)
-            hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+            hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
                                split_scale);
         else if (planes == 2)
-            hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+            hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
                                split_scale);
         else
-            hipLaunchKernelGGL(bn_bwd_apply_split<1>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+            hipLaunchKernelGGL(bn_bwd_apply_split<1>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
                                split_scale);
         return check_launch("bn_bwd");
     }
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, y, scale, shift, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                        (const float*)coef, dy, total4, C, group4);
     return check_launch("bn_bwd");
 }

@@ -156,11 +156,29 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
                 }
             }
         }
+        if (d.y_enc) {
+            // the pre-BatchNorm tensor as fp16 codes (rpnet_conv_desc.y_enc): (v - a[c]) * b[c], saturating, 8-byte stores
+            _Float16* dst16 = reinterpret_cast<_Float16*>(dstb);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c4 = (q * 64 + lane) % (WN * 8);
+                const f32x4 ea = *reinterpret_cast<const f32x4*>(d.y_enc + cd0 + c4 * 4);
+                const f32x4 eb = *reinterpret_cast<const f32x4*>(d.y_enc + d.y_enc_stride + cd0 + c4 * 4);
+                if (RowMap::kAlwaysValid || orow[q] >= 0) {
+                    using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
+                    h16x4 hv;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hv[k] = (_Float16)fminf(fmaxf((v4[q][k] - ea[k]) * eb[k], -65504.f), 65504.f);
+                    *reinterpret_cast<h16x4*>(dst16 + (size_t)orow[q] * Cd + cd0 + c4 * 4) = hv;
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c4 = (q * 64 + lane) % (WN * 8);
             if (RowMap::kAlwaysValid || orow[q] >= 0)
                 *reinterpret_cast<f32x4*>(dstb + (size_t)orow[q] * Cd + cd0 + c4 * 4) = v4[q];
+        }
         }
         __builtin_amdgcn_wave_barrier();
         if (ROWOPS && d.y_split) {

@@ -513,6 +513,42 @@ _CONV1_RECOMP = os.environ.get("RPNET_CONV1_RECOMPUTE", "1") == "1"
 _MASK_SKIP = os.environ.get("RPNET_MASK_SKIP", "1") == "1"
 
 
+# The one-plane fp16 arithmetic (BASELINE configs[4]) stores the pre-BatchNorm tensor of a conv + BatchNorm + ReLU layer as 2-byte
+# codes (rpnet_conv_desc.y_enc): code = fp16((y - a[c]) * b[c]) with a = the layer's running mean and b = a power of two near
+# 2^-4 / sqrt(running variance + eps), both taken BEFORE the forward pass — so the codes are O(1) whatever the batch (fp16 cannot
+# overflow below ~1e6 standard deviations, and saturates there), with no data-dependent scale and nothing to redo.  BatchNorm does
+# not care about a per-channel affine map of its input: the passes decode with (a, 1 / b) and everything else — the statistics
+# from the fp32 accumulators, the ReLU mask, the gradients — is as before.  What it buys: the tensor is written once and read
+# three times (BatchNorm + ReLU, both passes of the backward) at 2 instead of 4 bytes.
+# MEASURED AND OFF (round 4): configs[4] 34.11 / 34.32 ms per step with the codes against 34.21 / 34.22 without (one box, two
+# alternations: the passes it shortens already run beside the other chain's convolutions), and the decoded tensor flips
+# enough ReLU / window decisions to move a layer's input gradient by 9e-3 (relative L2) against the fp32 tensor.  RPNET_Y16=1
+# switches it on.
+_Y16 = os.environ.get("RPNET_Y16", "0") == "1"
+_YCODE = {}            # running_mean.data_ptr() -> (enc [2, S], dec [2, S], offset, S); rebuilt by y_codes_begin per forward
+
+
+def y_codes_begin(bns):
+    """RP_Net.forward (training, "f16" arithmetic): the codes of every BatchNorm module of `bns` from its running statistics as
+    they are NOW, a handful of small launches for the whole model; y_codes_end() drops them."""
+    _YCODE.clear()
+    bns = [b for b in bns if getattr(b, "running_mean", None) is not None and b.running_mean.is_cuda]
+    if not (_Y16 and bns):
+        return
+    rm = torch.cat([b.running_mean.detach().float() for b in bns])
+    rv = torch.cat([b.running_var.detach().float() for b in bns])
+    b2 = torch.exp2(torch.round(torch.log2(0.0625 * torch.rsqrt(rv + BN_EPS))))
+    enc, dec = torch.stack([rm, b2]), torch.stack([rm, 1.0 / b2])
+    off, S = 0, rm.numel()
+    for b in bns:
+        _YCODE[b.running_mean.data_ptr()] = (enc, dec, off, S)
+        off += b.running_mean.numel()
+
+
+def y_codes_end():
+    _YCODE.clear()
+
+
 _SKIP_STATS = None     # diagnostic (bench.py): a list that receives every launch's flag buffer (preset to 255 = "no tile here")
 
 
@@ -882,7 +918,11 @@ class ConvBnRelu(Function):
         recomp = bool(first and _CONV1_RECOMP and f16_mode() and cout % 8 == 0 and 256 % (cout // 8) == 0 and out_split is True
                       and produced.get("z_unused") and not produced.get("pool_req") and _CONV1_BN_FUSE
                       and query("rpnet_conv1_stats_blocks", N, H, W, cout, groups) > 0)
-        y = None if recomp else _empty((N, H, W, cout), x0)
+        # fp16 codes of y (see _YCODE): the one-plane arithmetic, a module whose codes RP_Net.forward prepared, fused statistics
+        ycode = _YCODE.get(running_mean.data_ptr()) if (not first and running_mean is not None and _MATH["f16_planes"] == 1
+                                                         and f16_mode() and cout % 64 == 0) else None
+        y = None if recomp else (torch.empty((N, H, W, cout), device=x0.device, dtype=torch.float16) if ycode is not None
+                                 else _empty((N, H, W, cout), x0))
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
         fused, xs, sx, sx1 = 0, None, None, None
         if first:      # batch statistics out of the same launch (one partial row per block and group)
@@ -918,6 +958,13 @@ class ConvBnRelu(Function):
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
+            if ycode is not None and (not fused or d.split_planes != 1):
+                ycode = None          # the separate statistics pass (rpnet_bn_stats) reads fp32: this layer keeps its fp32 tensor
+                y = _empty((N, H, W, cout), x0)
+                d.y0 = ptr(y)
+            if ycode is not None:
+                d.y_enc, d.y_enc_stride = ycode[0].data_ptr() + 4 * ycode[2], ycode[3]
+                ARITH[("pre_bn_tensor", "fp16 codes")] += 1
             _cconv("rpnet_conv_fwd", d)
         _order_wait(gamma.data_ptr())      # the running statistics: after the other chain's update of this module
         if fused:
@@ -954,7 +1001,7 @@ class ConvBnRelu(Function):
             # max-pool reads it)
             z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, Hz, Wz, cout)
             produced["planes_only"] = True
-            if not pool and out_split is True and not recomp:
+            if not pool and out_split is True and not recomp and ycode is None:
                 produced["bn_ref"] = BnRef(y, stats, groups)
         if recomp:
             if not (produced.get("planes_only") and want16 and np_out):
@@ -964,9 +1011,10 @@ class ConvBnRelu(Function):
             ARITH[("bn_relu", "first layer made again from the image")] += 1
         else:
             # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
+            ydec = (ycode[1].data_ptr() + 4 * ycode[2], ycode[3]) if ycode is not None else (None, 0)
             call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
                  np_out, ptr(gamma), ptr(beta),
-                 ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0)
+                 ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0, ydec[0], ydec[1])
         if pool:
             ARITH[("bn_relu", "with the 2x2 max-pool")] += 1
         if want16 and np_out:
@@ -978,6 +1026,7 @@ class ConvBnRelu(Function):
         _tap("fwd:y,stats", weight, y, stats)
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.yshape = (N, H, W, cout)
+        ctx.ycode = None if (recomp or ycode is None) else (ycode[1], ycode[2], ycode[3])      # the decode pair outlives _YCODE
         ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
         ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
@@ -1011,7 +1060,7 @@ class ConvBnRelu(Function):
                 _order_wait(gamma.data_ptr())
             call("rpnet_bn_bwd", ptr(dz), None, ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]), None, None, 0,
                  None, ptr(gamma.grad if direct else dgamma), ptr(beta.grad if direct else dbeta), N, H * W, cout, groups,
-                 1 if direct else 0, ptr(part), None, rows, 0, ptr(ws), wsb)
+                 1 if direct else 0, ptr(part), None, rows, 0, ptr(ws), wsb, None, 0)
             if direct:
                 _order_done(gamma.data_ptr())
             dw = torch.empty_like(weight)
@@ -1029,7 +1078,7 @@ class ConvBnRelu(Function):
         dsplit = bool(np_) and cout % 32 == 0 and need_d
         dys = torch.empty((np_,) + tuple(y.shape), device=y.device, dtype=torch.bfloat16) if (wsplit or dsplit) else None
         sdy = torch.empty(1, device=y.device, dtype=torch.float32) if (dys is not None and np_ <= 2) else None   # fp16: tensor scale
-        dy = torch.empty_like(y) if (first or not wsplit or (need_d and not dsplit)) else None
+        dy = _empty(ctx.yshape, dz) if (first or not wsplit or (need_d and not dsplit)) else None
         # Conv1.conv.0 (Cin = 1) has no input gradient: its direct weight gradient forms dy itself from dz, y and the
         # coefficients of the reduction pass, so the apply pass (12 bytes per element of the largest tensor) is not run
         fuse1 = first and _CONV1_BN_FUSE and stats.is_contiguous()
@@ -1054,7 +1103,7 @@ class ConvBnRelu(Function):
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
              ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(gp), ptr(gm_), grows,
-             W if ctx.pool else 0, ptr(ws), wsb)
+             W if ctx.pool else 0, ptr(ws), wsb, *((ctx.ycode[0].data_ptr() + 4 * ctx.ycode[1], ctx.ycode[2]) if ctx.ycode else (None, 0)))
         if direct:
             _order_done(gamma.data_ptr())
         _tap("bn_bwd:dz,dy,dys,sdy,ws", weight, dz, dy, dys, sdy, ws)

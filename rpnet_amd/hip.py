@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                 ("N", ci), ("H", ci), ("W", ci), ("taps", ci), ("upsample", ci), ("groups", ci), ("dilation", ci), ("stats_partial", vp), ("split_planes", ci), ("y_split", vp), ("split_out_planes", ci),
                 ("acc_scale_col", vp), ("acc_scale_x", vp), ("acc_scale_dy", vp), ("bnb_y", vp), ("bnb_stats", vp), ("bnb_partial", vp), ("bnb_pmax", vp), ("bnb_groups", ci),
                 ("acc_scale_x1", vp), ("out_absmax", vp), ("tune", ci), ("y_split_scale", vp), ("splitk_ws", vp), ("splitk_ws_bytes", cs),
-                ("skip_mask", vp), ("skip_mode", ci), ("skip_halo", ci), ("skip_ws", vp), ("tile_skip", vp)]
+                ("skip_mask", vp), ("skip_mode", ci), ("skip_halo", ci), ("skip_ws", vp), ("tile_skip", vp),
+                ("y_enc", vp), ("y_enc_stride", ci)]
 
 
 PACK_MAX = 24     # layers per rpnet_pack_conv_weights_split call
@@ -65,9 +66,9 @@ _SIGS = {
     "rpnet_bn_workspace_bytes": (cs, [ci, ci]),
     "rpnet_bn_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, cs, vp]),
     "rpnet_bn_eval_affine": (ci, [vp, vp, vp, vp, cf, vp, vp, ci, vp]),
-    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "rpnet_bn_relu": (ci, [vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
     "rpnet_bn_act_scale": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
-    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp, cs, vp]),
+    "rpnet_bn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, vp, cs, vp, ci, vp]),
     "rpnet_bias_relu_bwd_workspace_bytes": (cs, [ci]),
     "rpnet_bias_relu_bwd": (ci, [vp, vp, vp, vp, cs, ci, vp, cs, vp]),
     "rpnet_maxpool3_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

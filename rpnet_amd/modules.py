@@ -509,6 +509,11 @@ class RP_Net(nn.Module):
                 pred_key = (self._serial, RF.conv_math(), ns, B, H, W, self.num_iter, n_ways, n_shots, self.forced_masks is not None)
                 RF.pred_begin(supp.device, pred_key, allow=not getattr(self, "_pred_redo", False))
         planes = RF.pack_planes()
+        # the one-plane fp16 arithmetic in training: the pre-BatchNorm tensors as 2-byte codes (RF._YCODE)
+        if self.training and supp.is_cuda and RF.f16_mode() and planes == 1:
+            RF.y_codes_begin(self._bn_modules())
+        else:
+            RF.y_codes_end()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
             if _PACK_STREAM and self.training and supp.is_cuda:
@@ -631,6 +636,13 @@ class RP_Net(nn.Module):
             finally:
                 self._pred_redo = False
         return {"output": output, "align_loss": align_loss, "refinement": refinement}
+
+    def _bn_modules(self):
+        bl = getattr(self, "_bn_list", None)
+        if bl is None:
+            bl = self._bn_list = [m for m in list(self.encoder.modules()) + [self.cre.w_k[1], self.cre.w_q[1], self.cre.q[1]]
+                                  if isinstance(m, nn.BatchNorm2d)]
+        return bl
 
     def _pack_weights(self):
         ws = getattr(self, "_pack_list", None)

@@ -289,3 +289,23 @@ def test_literal_reference_driver_reaches_the_model_through_the_launcher():
     assert r.returncode != 0 and "No HIP GPUs are available" in r.stderr, r.stderr[-1500:]
     assert "net = net.cuda()" in r.stderr and "no-op torch.utils.tensorboard.SummaryWriter registered" in r.stderr
     assert "ModuleNotFoundError" not in r.stderr and "ImportError" not in r.stderr
+
+
+def test_kept_alive_tensors_outlive_a_mid_backward_join():
+    """The tensors an asynchronous weight gradient reads are kept alive in RF._ASYNC["keep"] until the side streams are joined at
+    the END of the backward pass; the gradient bucket's hooks join in the middle of it (`final=False`): the calling stream waits,
+    the list stays — a block freed there could be handed to another stream of the pass while a weight gradient still reads it."""
+    import rpnet_amd.functional as RF
+    saved = (list(RF._ASYNC["keep"]), set(RF._ASYNC["pending"]), RF._ASYNC["queued"])
+    try:
+        RF._ASYNC["keep"][:] = [object(), object()]
+        RF._ASYNC["pending"].clear()
+        RF._ASYNC["queued"] = True
+        RF.join_side_streams(final=False)
+        assert len(RF._ASYNC["keep"]) == 2 and RF._ASYNC["queued"] is True
+        RF.join_side_streams()
+        assert RF._ASYNC["keep"] == [] and RF._ASYNC["queued"] is False
+    finally:
+        RF._ASYNC["keep"][:] = saved[0]
+        RF._ASYNC["pending"].update(saved[1])
+        RF._ASYNC["queued"] = saved[2]

@@ -54,11 +54,7 @@ python tools/pmc_traffic.py $(csvc $R/pmc_fetch5) $(csvc $R/pmc_write5) $O/${TAG
 ( RPNET_WGRAD_DEFER=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_BN_LDS=big RPNET_DICE_MULTI=0 python tools/ab_overlap.py | tail -1
   RPNET_WGRAD_DEFER=0 python tools/ab_overlap.py | tail -1
   RPNET_CRE_STREAMS_TRAIN=0 python tools/ab_overlap.py | tail -1
-  RPNET_BN_LDS=big python tools/ab_overlap.py | tail -1
-  python tools/ab_overlap.py | tail -1
-  AB_CONFIG=c5 RPNET_WGRAD_DEFER=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 RPNET_BN_LDS=big RPNET_DICE_MULTI=0 python tools/ab_overlap.py 10 | tail -1
-  AB_CONFIG=c5 RPNET_ENC_STREAMS=0 python tools/ab_overlap.py 10 | tail -1
-  AB_CONFIG=c5 python tools/ab_overlap.py 10 | tail -1 ) > $O/${TAG}_ab_overlap.txt 2>/dev/null
+  python tools/ab_overlap.py | tail -1 ) > $O/${TAG}_ab_overlap.txt 2>/dev/null
 # configs[4] (one fp16 plane, 2-way 512^2 T=10 batch 4): kernel trace of the same command as its bench line
 C5="env RPNET_BENCH_GRAPH=0 python bench.py --size 512 --iters 10 --ways 2 --batch 4 --conv-math f16 --steps 4 --warmup 2 --no-cpu-baseline"
 RPNET_ASYNC_WGRAD=0 RPNET_CRE_STREAMS_TRAIN=0 RPNET_ENC_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/trace_c5 -o t -- $C5 > $R/trace_c5.log 2>&1
