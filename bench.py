@@ -538,6 +538,9 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
     return res
 
 
+DDP_GRAPH = os.environ.get("RPNET_BENCH_DDP_GRAPH", "0") == "1"
+
+
 def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
     """Times `steps` steps of workload w = dict(ways, shots, size, iters, batch, conv_math) after `warmup` untimed ones
     (barrier + synchronize on both sides, MAX over ranks), then one extra profiled step (HIP events per C-ABI call,
@@ -586,8 +589,11 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
             flag = torch.tensor([1.0 if bound else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             probe["host_bound_ranks_any"] = bound = bool(flag.item() > 0)
-        if bound and ddp and dist.get_backend() != "nccl":
-            bound = False       # HIP stream capture beside gloo's helper threads ends in a segmentation fault or hangs (measured round 4)
+        if bound and ddp and not DDP_GRAPH:
+            # HIP stream capture in a process that holds a collective communicator is crash-prone on this ROCm (gloo: segmentation
+            # fault or hang; RCCL: segmentation fault in hipStreamEndCapture in 3 of 12 runs, either capture mode — tools/cap_try.sh):
+            # under a process group the timed steps stay eager unless RPNET_BENCH_DDP_GRAPH=1 asks for the replay form
+            bound = False
         if bound:
             mode = "hip_graph_replay"
     exposed = [] if ddp else None
@@ -640,10 +646,12 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
         # the OTHER way of issuing the step, 5 steps, so that the line carries both (eager + overlapped exchange / graph replay
         # + exposed exchange) whichever the probe chose
         other_ex = []
-        if dist.get_backend() != "nccl":
-            # the graph-replay form is exercised under RCCL only (one-rank group on one GPU: tests/test_gpu_dist.py): a HIP stream
-            # capture beside gloo's helper threads ended in a segmentation fault (thread-local capture mode, 3 of 5 runs) or hung
-            # (global mode, 5 of 5) on this ROCm; gloo is the one-GPU plumbing backend, never the measured one
+        if dist.get_backend() != "nccl" or not DDP_GRAPH:
+            # the graph-replay form of the N > 1 step is OPT-IN (RPNET_BENCH_DDP_GRAPH=1, RCCL only): capturing the step in a
+            # process that holds a communicator ended in a segmentation fault inside hipStreamEndCapture in 3 of 12 one-rank RCCL
+            # runs (thread-local and global capture mode alike) and in 3 of 5 / hung 5 of 5 under gloo — eight ranks taking that
+            # chance would cost the whole line.  When it runs, its gradients equal the eager step's bit for bit
+            # (tests/test_gpu_dist.py with RPNET_TEST_DDP_GRAPH=1)
             other = None
         else:
             if mode == "eager":

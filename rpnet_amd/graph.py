@@ -82,7 +82,9 @@ class GraphedTrainStep:
     the replay is followed by `bucket.allreduce()` — one all-reduce of the whole flat bucket on the collective library's
     stream, exposed behind the step instead of overlapped with backward (what eight eager Python processes on one shared
     host trade for one graph launch per step each).  `exposed`: a list that receives a HIP-event pair around that
-    exchange (bench.py)."""
+    exchange (bench.py).  CAUTION (measured round 4, tools/cap_try.sh): on this ROCm a stream capture in a process that holds an RCCL
+    communicator ended in a segmentation fault inside hipStreamEndCapture in 3 of 12 one-rank runs, in thread-local and in global
+    capture mode alike — under a process group this class is opt-in for bench.py and the tests."""
 
     def __init__(self, net, bucket, loss_fn, warmup=2, exposed=None):
         self.net, self.bucket, self.loss_fn, self.warmup = net, bucket, loss_fn, warmup
@@ -131,6 +133,17 @@ class GraphedTrainStep:
             raise RuntimeError("rpnet_amd.graph.GraphedTrainStep: HIP stream capture under a gloo process group is not supported "
                                "(gloo's helper threads touch the device while the step is captured); use the eager step or RCCL")
         mode = "thread_local" if ddp else "global"
+        import os
+        forced = os.environ.get("RPNET_GRAPH_CAPTURE_MODE")      # A/B: "global" | "thread_local" | "quiesce" (global after a pause)
+        if forced == "quiesce" and ddp:
+            # no collective in flight and the watchdog has seen the last one complete (it polls every 100 ms): nothing left for it
+            # to query while the step is captured, so the global mode's prohibition cannot hit it
+            import time
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            mode = "global"
+        elif forced in ("global", "thread_local"):
+            mode = forced
         with torch.cuda.graph(g, capture_error_mode=mode):
             loss = self._run(st)
         self._graphs[key] = (g, st, loss)
