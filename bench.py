@@ -185,16 +185,29 @@ def profile_step(net, bucket, inp, scaler):
     def timed(name, *args):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         flops = nbytes = 0.0
+        key = name
         if name in ("rpnet_conv_fwd", "rpnet_conv_wgrad"):
             d = args[0]._obj
             m, ci, co = d.N * d.H * d.W, d.C0 + d.C1, d.Co0 + d.Co1
             flops = 2.0 * m * ci * co * d.taps
             esz = 2.0 * d.split_planes if d.split_planes else 4.0                # operand bytes per element
             nbytes = esz * ((m >> (2 * d.upsample)) * ci + d.taps * ci * co) + 4.0 * m * co   # read x, w; write y
+        elif name in ("rpnet_conv_up4", "rpnet_conv_wgrad_up4"):
+            # the collapsed up_conv layers (Up5, Up4): FOUR products per (output pixel, cin, cout) are executed, not the nine the
+            # reference's operator sequence implies (SURVEY.md 8d counts 9.664 GF per image and layer) — the EXECUTED count goes
+            # into `achieved`, so that the roofline fraction is not flattered by work that was removed
+            d = args[0]._obj
+            m = d.N * d.H * d.W                                                    # high-resolution pixels
+            if name == "rpnet_conv_up4" or args[1] is not None:                    # (the reduce-only phase of a weight gradient: no GEMM)
+                flops = 2.0 * m * d.C0 * d.Co0 * 4
+            esz = 2.0 * d.split_planes
+            lo, hi = (d.C0, d.Co0) if (name == "rpnet_conv_up4" and args[1] == 1) else (d.Co0, d.C0)
+            nbytes = esz * ((m >> 2) * lo + 16 * d.C0 * d.Co0) + 4.0 * m * hi if name == "rpnet_conv_up4" else 0.0
+            key = "rpnet_conv_fwd" if name == "rpnet_conv_up4" else "rpnet_conv_wgrad"      # same groups as the nine-tap launches
         a.record()
         orig(name, *args)
         b.record()
-        records.append((name, flops, nbytes, a, b))
+        records.append((key, flops, nbytes, a, b))
 
     hip.call = timed
     import rpnet_amd.functional as RF
@@ -447,31 +460,53 @@ def _cpu_leg(cfg, size, T, B, as_written, seconds_budget, max_steps, threads=Non
 
 
 def _cpu_worker(argv):
-    """hidden mode `bench.py --cpu-worker THREADS SIZE T SECONDS INDEX`: one process of the concurrent CPU leg — the
-    oracle's as-written fwd+bwd on its own batch-1 episode, THREADS threads, for about SECONDS; prints one JSON line"""
-    threads, size, T, seconds, index = int(argv[0]), int(argv[1]), int(argv[2]), float(argv[3]), int(argv[4])
-    try:      # a disjoint block of cores per worker where the numbering allows it
-        os.sched_setaffinity(0, set(range(index * threads, (index + 1) * threads)) & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+    """hidden mode `bench.py --cpu-worker THREADS SIZE T SECONDS CPULIST`: one process of the concurrent CPU leg — the
+    oracle's as-written fwd+bwd on its own batch-1 episode, THREADS threads pinned to the comma-separated CPULIST (a slice of
+    the PARENT's allowed set, chosen by the parent so that the slices are disjoint), for about SECONDS; prints one JSON line"""
+    threads, size, T, seconds = int(argv[0]), int(argv[1]), int(argv[2]), float(argv[3])
+    cpus = {int(c) for c in argv[4].split(",")} if len(argv) > 4 and argv[4] else set()
+    pinned = False
+    try:
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            pinned = os.sched_getaffinity(0) == cpus
     except (AttributeError, OSError):
         pass
     torch.set_num_threads(threads)
     cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
     leg, _ = _cpu_leg(cfg, size, T, 1, True, seconds, 64)
-    print(json.dumps({"steps": leg["steps"], "median_s_per_step": leg["median_s_per_step"], "threads": threads}))
+    print(json.dumps({"steps": leg["steps"], "median_s_per_step": leg["median_s_per_step"], "threads": threads, "pinned": pinned}))
+
+
+def _allowed_cpus():
+    """the CPUs this process may run on (the lease's affinity mask / cgroup cpuset), sorted — NOT os.cpu_count(), which is the
+    machine's: round 4's whole-host leg sized itself from the latter on a box whose lease was narrower, and seven of its eight
+    workers fell back to the whole allowed set and fought the first one"""
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return list(range(os.cpu_count() or 1))
 
 
 def _cpu_aggregate_leg(size, T, threads, seconds):
-    """The host's real throughput on this workload: episodes are independent, so floor(hardware threads / 2 / threads)
-    processes of `threads` threads each run the as-written oracle CONCURRENTLY (one episode each); the aggregate is the sum
-    of their rates.  (One process cannot use the host: PyTorch's CPU operators at these sizes get slower beyond ~16 threads.)"""
+    """The host's real throughput on this workload: episodes are independent, so floor(allowed CPUs / 2 / threads) processes of
+    `threads` threads each run the as-written oracle CONCURRENTLY (one episode each, each pinned to its own DISJOINT, contiguous
+    slice of the sorted allowed-CPU list: contiguous CPU numbers share a NUMA node / CCD on these hosts); the aggregate is the sum of
+    their rates.  (One process cannot use the host: PyTorch's CPU operators at these sizes get slower beyond ~16 threads.)
+    The leg is REJECTED (consistent = False; the caller then reports the single-process figure) when the processes' rates differ by
+    more than 2x — the signature of workers sharing cores."""
     import subprocess
-    nproc = os.cpu_count() or 1
-    procs_n = max(1, nproc // 2 // max(threads, 1))
+    allowed = _allowed_cpus()
+    # every second allowed CPU is left idle (SMT siblings / the rest of the box's tenants): slices of 2 x threads CPUs, the
+    # worker pinned to the whole slice (the kernel places its `threads` threads on it)
+    width = 2 * max(threads, 1)
+    procs_n = max(1, len(allowed) // width)
+    slices = [allowed[i * width:(i + 1) * width] for i in range(procs_n)]
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker"]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-    procs = [subprocess.Popen(cmd + [str(threads), str(size), str(T), str(seconds), str(i)], stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, text=True, env=env) for i in range(procs_n)]
-    rates, steps = [], 0
+    procs = [subprocess.Popen(cmd + [str(threads), str(size), str(T), str(seconds), ",".join(map(str, sl))], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=env) for sl in slices]
+    rates, steps, pinned = [], 0, 0
     for p in procs:
         out, _ = p.communicate(timeout=60 + 20 * seconds)
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -479,11 +514,15 @@ def _cpu_aggregate_leg(size, T, threads, seconds):
             r = json.loads(lines[-1])
             rates.append(1.0 / r["median_s_per_step"])
             steps += r["steps"]
+            pinned += int(bool(r.get("pinned")))
     if not rates:
         return None
     return {"value": round(sum(rates), 4), "unit": "pairs/s", "processes": len(rates), "threads_per_process": threads,
-            "cores": len(rates) * threads, "steps_total": steps, "per_process_pairs_per_s": [round(r, 3) for r in rates],
-            "mode": "as-written oracle, one batch-1 episode per process, all processes concurrent"}
+            "cores": len(rates) * threads, "allowed_cpus": len(allowed), "machine_cpus": os.cpu_count(), "cpus_per_process": width,
+            "processes_pinned": pinned, "steps_total": steps, "per_process_pairs_per_s": [round(r, 3) for r in rates],
+            "consistent": bool(max(rates) <= 2.0 * min(rates)),
+            "mode": "as-written oracle, one batch-1 episode per process, all processes concurrent, each pinned to its own contiguous "
+                    "slice of the allowed CPUs"}
 
 
 def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=None, full=False):
@@ -503,7 +542,11 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
                      f"(reference operator sequence), {main_leg['median_s_per_step']:.2f} s/step", "legs": [main_leg]}
     # the honest figure: the whole host, not one process of it
     agg = _cpu_aggregate_leg(size, T, main_leg["threads"], 12.0)
-    if agg is not None and agg["value"] > res["value"]:
+    res["allowed_cpus"] = len(_allowed_cpus())
+    if agg is not None and not agg["consistent"]:
+        res["note"] = ("the whole-host leg was rejected (its processes' rates differ by more than 2x: workers shared cores); `value` is "
+                       "the single-process figure")
+    if agg is not None and agg["consistent"] and agg["value"] > res["value"]:
         res["single_process_value"] = res["value"]
         res["value"], res["cores"] = agg["value"], agg["cores"]
         res["sample"] = (f"{agg['processes']} concurrent processes x {agg['threads_per_process']} threads, each the as-written oracle "
@@ -745,6 +788,8 @@ def roofline_of(m, w, world):
     """the `roofline` object of a measured workload: the rpnet_conv_fwd launches (forward + input gradient) of the profiled step"""
     agg, math, value = m["agg"], m["math"], m["value"]
     products, peak = MATH[math]
+    # (rpnet_conv_up4 / rpnet_conv_wgrad_up4, the collapsed up_conv layers, are booked into the same two groups with their
+    # EXECUTED FLOPs: profile_step)
     conv = agg.get("rpnet_conv_fwd", [0, 1e-9, 0.0, 0.0])
     wg = agg.get("rpnet_conv_wgrad", [0, 1e-9, 0.0, 0.0])
     achieved = conv[2] / conv[1] / 1e12
@@ -766,6 +811,9 @@ def roofline_of(m, w, world):
             "algorithmic_bytes_per_launch": round(conv[3] / max(conv[0], 1)),
             "launches_per_step": conv[0], "avg_launch_ms": round(1e3 * conv[1] / max(conv[0], 1), 4),
             "algorithmic_gflop_per_step": round(conv[2] / 1e9, 1),
+            "flop_accounting": "executed multiply-adds of the launches (the two up_conv layers run 4 of the 9 products per output the "
+                               "reference's operator sequence implies: their taps collapse onto the 2 x 2 source pixels an output "
+                               "phase reads); whole_step_frac / gflop_per_pair keep SURVEY.md 8d's count of the reference's sequence",
             "wgrad_tflops": round(wg[2] / wg[1] / 1e12, 2),
             "whole_step_frac": round(value / world * gf_pair * 1e9 / (peak * 1e12), 4),
             "whole_step_tflops": round(value / world * gf_pair / 1e3, 1),

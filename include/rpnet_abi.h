@@ -45,6 +45,13 @@ enum rpnet_status {
     RPNET_ERR_WORKSPACE = -3
 };
 
+/* Version of this header.  History: 100 rounds 1 - 3; 104 round 4 (rpnet_bn_relu / rpnet_bn_bwd / rpnet_conv1_wgrad_bn gained
+ * arguments in front of `stream`, rpnet_conv_desc grew skip_*, tile_skip, y_enc — a caller built against 100 would pass its stream
+ * where a pointer is expected: hence the number); 105 round 5 (rpnet_refine_glue_*, rpnet_conv_up4*, rpnet_conv_wgrad_up4*,
+ * rpnet_upconv_collapse_weights added; nothing existing changed).  A caller MUST zero-initialise rpnet_conv_desc (fields added
+ * later are optional features that are off at zero) and SHOULD compare rpnet_version() with the RPNET_ABI_VERSION it was built
+ * against. */
+#define RPNET_ABI_VERSION 105
 int rpnet_version(void);
 const char* rpnet_last_error_string(void);
 
@@ -104,7 +111,7 @@ int rpnet_pack_conv_weight_split(const float* w, void* wp, void* wd, int cout, i
 typedef struct rpnet_pack_item {
     const float* w; void* wp; void* wd;        /* as rpnet_pack_conv_weight_split; wd may be NULL */
     float* row_scale_wp; float* row_scale_wd;  /* planes 1 / 2: [cout] / [cin_pad] outputs; NULL for planes == 3 */
-    int cout, cin, taps, cin_off0, cin_split, cin_off1, cin_pad;
+    int cout, cin, taps, cin_off0, cin_split, cin_off1, cin_pad;   /* taps: 9, 1, or 4 (the collapsed up_conv weights) */
 } rpnet_pack_item;
 int rpnet_pack_conv_weights_split(const rpnet_pack_item* items, int n, int planes, rpnet_stream_t stream);
 
@@ -223,6 +230,34 @@ int rpnet_conv_tile_variant(const rpnet_conv_desc* d);
  * grid fills the machine, or the descriptor asks for an epilogue feature the reduce launch does not have: batch statistics,
  * BatchNorm-backward sums, accumulate, per-row output scales, a second output tensor) */
 size_t rpnet_conv_splitk_workspace_bytes(const rpnet_conv_desc* d);
+
+/* ------------------------------------------------------------- up_conv without its redundant products (round 5)
+ * nn.Upsample(scale_factor=2) -> nn.Conv2d 3x3 (net/modules.py:61-75: Up5, Up4 of net/unet.py:457-465).  A 3x3 convolution over a
+ * nearest-x2 up-sampled image reads only a 2 x 2 block of SOURCE pixels per output pixel; with the weights of coinciding taps
+ * added up front the layer is 4 / 9 of its multiply-adds, forward, input gradient and weight gradient (csrc/conv_up4_dma.hip,
+ * csrc/conv_wgrad_up4.hip).  Result: the reference's to the rounding of the weight sums (2^-24 relative).
+ *   rpnet_upconv_collapse_weights: w [Cout][Cin][3][3] -> wc [4 Cout][Cin][2][2], row (py * 2 + px) * Cout + co = the weights of
+ *     output phase (py, px) = (Y & 1, X & 1); pack wc with rpnet_pack_conv_weights_split (taps = 4, cout = 4 Cout).
+ *   rpnet_conv_up4(d, mode): fp16 planes (split_planes 2).  d.N / d.H / d.W: the HIGH-resolution tensor.
+ *     mode 1, forward: x0 = planes of the low-resolution input [N][H/2][W/2][C0], w = the `wp` pack of wc, y0 [N][H][W][Co0];
+ *       bias, ep_scale / ep_shift / ep_relu, stats_partial (rpnet_conv_up4_stats_blocks rows per group), accumulate,
+ *       out_absmax, acc_scale_col = the pack's row scales [4 Co0], acc_scale_x as in rpnet_conv_fwd.
+ *     mode 2, input gradient: x0 = planes of dy [N][H][W][C0], w = the `wd` pack of wc, y0 = dx [N][H/2][W/2][Co0] (low resolution:
+ *       the 2 x 2 sum of rpnet_upsample2_bwd is part of the launch); acc_scale_col = the pack's wd row scales [Co0].
+ *   rpnet_conv_up4_supported: 1 when the shapes fit (whole 256-pixel low-resolution patches, one source / destination). */
+int rpnet_upconv_collapse_weights(const float* w, float* wc, int Cout, int Cin, rpnet_stream_t stream);
+int rpnet_conv_up4_supported(const rpnet_conv_desc* d, int mode);
+int rpnet_conv_up4_stats_blocks(const rpnet_conv_desc* d);
+int rpnet_conv_up4(const rpnet_conv_desc* d, int mode, rpnet_stream_t stream);
+/* weight gradient of the same layer on the collapsed form (csrc/conv_wgrad_up4.hip): x0 = planes of the low-resolution input
+ * [N][H/2][W/2][C0], dy = planes of the high-resolution output gradient [N][H][W][Co0], dw [Co0][C0][3][3] (state_dict layout);
+ * acc_scale_x / acc_scale_dy: the operands' tensor scales; `accumulate` adds into dw.  Two-phase form as rpnet_conv_wgrad
+ * (dw == NULL: the split-K GEMM only; dy == NULL: the reduce only).  Power-of-two low-resolution images >= 8 pixels wide, C0 and
+ * Co0 multiples of 64 (rpnet_conv_wgrad_up4_supported); otherwise rpnet_conv_wgrad with d->upsample. */
+int rpnet_conv_wgrad_up4_supported(const rpnet_conv_desc* d);
+size_t rpnet_conv_wgrad_up4_workspace_bytes(int N, int H, int W, int cin, int cout);
+int rpnet_conv_wgrad_up4(const rpnet_conv_desc* d, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                         rpnet_stream_t stream);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d wrt weight):
  * dW[cout][cin][kh][kw] = sum_pixels A[pixel+tap][cin] * dy[pixel][cout], A gathered
@@ -423,6 +458,33 @@ int rpnet_bilinear_up_bwd(const float* dout, float* din, int planes, int h, int 
  * logits [B][K][H][W] -> next mask [B][H/scale][W/scale] */
 int rpnet_softmax_thresh_pool(const float* logits, float* mask, int B, int K, int H, int W, int scale, int soft,
                               rpnet_stream_t stream);
+
+/* The glue between two refinement iterations as ONE launch (round 5; csrc/refine.hip) — replaces, per iteration of
+ * net/rp_net.py:281-312, the chain  cre.q's BatchNorm + ReLU (:65-69)  ->  calDist x (1 + Wa) (:301,353-363)  ->  stack +
+ * F.interpolate(bilinear) (:302-303)  ->  softmax(1)[:, 1] (:308)  ->  > 0.5 unless soft (:309-310)  ->  avg_pool2d(4) (:311)
+ * and the next iteration's  x * mask, x * (1 - mask)  (:283) as the operand planes of its two 3x3 convolutions:
+ *   y [B][h][w][F]       cre.q's 1x1-convolution output; with bn_scale / bn_shift [F] (the batch affine of
+ *                        rpnet_bn_stats_from_partial) z = relu(y * scale + shift) is written to z [B][h][w][F]; bn_scale == NULL:
+ *                        y IS the feature map (eval mode: the convolution's epilogue applied the folded BatchNorm), z is not touched
+ *   proto [B][K][F]      -> pred [B][K][h][w] = scaler * cos(z, proto), logits [B][K][4h][4w]
+ *   mask_next [B][h][w]  (NULL: the last iteration, nothing behind logits is computed)
+ *   x [B][h][w][C] (NULL: no planes), x_scale (device scalar, fp16 planes), xk_planes / xq_planes [planes][B][h][w][C]:
+ *                        the 16-bit operand planes (rpnet_split_f16 / rpnet_split_bf16 formats) of x * mask_next and
+ *                        x * (1 - mask_next)
+ * Same bits as the separate entry points (rpnet_bn_relu, rpnet_cosine_match_fwd, rpnet_bilinear_up_fwd,
+ * rpnet_softmax_thresh_pool, rpnet_split_f16 / rpnet_split_bf16).  rpnet_refine_glue_supported: 1 when the shapes fit the kernel
+ * (F == 64, 2 <= K <= 4, h and w multiples of 8; planes: 0 or C a multiple of 8 with 256 % (C / 8) == 0) — the caller otherwise
+ * runs the separate entry points.
+ * rpnet_refine_glue_bwd: autograd of pred / logits wrt the feature map and the prototypes (the adjoint of the up-sampling and
+ * the cosine backward in one launch + the prototype-gradient reduce): df [B][h][w][F], dproto [B][K][F]. */
+int rpnet_refine_glue_supported(int K, int h, int w, int F, int C, int planes);
+int rpnet_refine_glue_fwd(const float* y, const float* bn_scale, const float* bn_shift, const float* proto, float scaler,
+                          float* z, float* pred, float* logits, float* mask_next, int soft, const float* x,
+                          const float* x_scale, void* xk_planes, void* xq_planes, int planes, int B, int K, int h, int w,
+                          int F, int C, rpnet_stream_t stream);
+size_t rpnet_refine_glue_bwd_workspace_bytes(int B, int K, int h, int w, int F);
+int rpnet_refine_glue_bwd(const float* dlogits, const float* f, const float* proto, float scaler, float* df, float* dproto,
+                          int B, int K, int h, int w, int F, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 
 /* soft_mask: True (yaml) — the fed-back mask stays differentiable (net/rp_net.py:309 skips the threshold):
  *   rpnet_rowdot_scale     autograd of x*s / x*(1-s) wrt BOTH factors given g = d/d(x*f(s)):

@@ -25,5 +25,7 @@ int check_launch(const char* what) {
 
 }  // namespace rpnet
 
-extern "C" int rpnet_version(void) { return 100; }
+// RPNET_ABI_VERSION (include/rpnet_abi.h): bumped whenever an entry point's arguments or struct rpnet_conv_desc change; the ctypes
+// binding (rpnet_amd/hip.py) refuses a library of another version
+extern "C" int rpnet_version(void) { return RPNET_ABI_VERSION; }
 extern "C" const char* rpnet_last_error_string(void) { return rpnet::g_err; }

@@ -47,7 +47,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int WM, int WN, typename RowMap, bool AFF, bool ROWOPS>
 __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows, const int M,
                                                      const int Cout, const int per_group, const int n0, const int wm,
-                                                     const int wn, const int li, const int h, float* slab) {
+                                                     const int wn, const int li, const int h, float* slab, const int cso = 0) {
     constexpr int SW = WN * 32 + 4;
     const int lane = li + 32 * h;
     const int colbase = n0 + wn * WN * 32;
@@ -65,7 +65,7 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
     for (int j = 0; j < WN; ++j) {
         const int col = colbase + j * 32 + li;
         bvv[j] = d.bias ? d.bias[col] : 0.f;
-        asv[j] = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
+        asv[j] = d.acc_scale_col ? d.acc_scale_col[col + cso] * xs : xs;
         es[j] = 1.f;
         eh[j] = 0.f;
         if (AFF && d.ep_scale) {
@@ -226,7 +226,9 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
 template <int WM, int WN, int WGM = 2, typename RowMap = LinearRows, bool WIDE = false>
 __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (&acc)[WM][WN], const RowMap rows,
                                               const int M, const int Cout, const int HW, const int n0, const int tm,
-                                              const int wm, const int wn, const int li, const int h, void* lds) {
+                                              const int wm, const int wn, const int li, const int h, void* lds, const int cso = 0) {
+    // cso: offset of this tile's columns inside acc_scale_col beyond their output column (conv_up4_dma.hip: the packed weight
+    // rows are (phase, cout), the output columns cout)
     const int per_group = d.groups > 0 ? (d.N / d.groups) * HW : M;
     const float xs = d.acc_scale_x ? *d.acc_scale_x : 1.f;     // fp16 split operands: power-of-two tensor / row scales
     if (d.stats_partial) {
@@ -248,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
         for (int j = 0; j < WN; ++j) {
             const int col = n0 + wn * WN * 32 + j * 32 + li;
             const float bv = d.bias ? d.bias[col] : 0.f;
-            const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
+            const float as = d.acc_scale_col ? d.acc_scale_col[col + cso] * xs : xs;
             // fp64 from the first add on: the variance is formed as E[y^2] - mean^2, and an fp32 running sum of squares
             // would carry ~1e-7 mean^2 of error into it (channels with |mean| >> std)
             double sm = 0.0, sq = 0.0;
@@ -281,10 +283,10 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
     const bool aff = d.ep_scale != nullptr || d.ep_relu != 0;
     const bool rowops = d.out_scale_mode != 0 || d.accumulate != 0 || d.out_absmax != nullptr || d.y_split != nullptr;
     float amax = 0.f;
-    if (!aff && !rowops) conv_epilogue_store<WM, WN, RowMap, false, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
-    else if (!aff) amax = conv_epilogue_store<WM, WN, RowMap, false, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
-    else if (!rowops) conv_epilogue_store<WM, WN, RowMap, true, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
-    else amax = conv_epilogue_store<WM, WN, RowMap, true, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab);
+    if (!aff && !rowops) conv_epilogue_store<WM, WN, RowMap, false, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
+    else if (!aff) amax = conv_epilogue_store<WM, WN, RowMap, false, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
+    else if (!rowops) conv_epilogue_store<WM, WN, RowMap, true, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
+    else amax = conv_epilogue_store<WM, WN, RowMap, true, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
     if (d.bnb_y) {
         // This launch is the input gradient dz of a layer whose source is the output of a train-mode BatchNorm + ReLU with
         // no other consumer: the reduction pass of THAT BatchNorm's backward (sum dz m, sum dz m xhat, max |dz m| per

@@ -1114,7 +1114,7 @@ extern "C" int rpnet_pack_conv_weights_split(const rpnet_pack_item* items, int n
         RPNET_REQUIRE(q.w && q.wp, RPNET_ERR_ARG, "pack_conv_weights_split: null pointer (item %d)", i);
         RPNET_REQUIRE(planes == 3 || (q.row_scale_wp && q.row_scale_wd), RPNET_ERR_ARG,
                       "pack_conv_weights_split: fp16 planes (1 or 2) need the row scale outputs (item %d)", i);
-        RPNET_REQUIRE(q.cout % 32 == 0 && q.cin_pad % 32 == 0 && (q.taps == 9 || q.taps == 1), RPNET_ERR_SHAPE,
+        RPNET_REQUIRE(q.cout % 32 == 0 && q.cin_pad % 32 == 0 && (q.taps == 9 || q.taps == 1 || q.taps == 4), RPNET_ERR_SHAPE,
                       "pack_conv_weights_split: cout %d cin_pad %d taps %d (item %d)", q.cout, q.cin_pad, q.taps, i);
         RPNET_REQUIRE(q.cin_off0 + q.cin_split <= q.cin_pad && q.cin_off1 + (q.cin - q.cin_split) <= q.cin_pad, RPNET_ERR_SHAPE,
                       "pack_conv_weights_split: channel ranges exceed cin_pad (item %d)", i);

@@ -3,26 +3,9 @@
 // fp32 kernels; features are NHWC [B][hw][C], logits are the reference's NCHW [B][K][H][W].
 // Replaces getFeatures / getPrototype / calDist / F.interpolate / softmax / threshold /
 // avg_pool2d of net/rp_net.py:288-311,353-391 and their autograd.
-#include "common.h"
+#include "matcher.h"
 
 namespace rpnet {
-
-// source taps of F.interpolate(mode='bilinear', align_corners=False) for destination index d
-__device__ __forceinline__ void bl_taps(int d, float rscale, int in_size, int& i0, int& i1, float& w0, float& w1) {
-    float src = rscale * ((float)d + 0.5f) - 0.5f;
-    if (src < 0.f) src = 0.f;
-    i0 = (int)src;
-    if (i0 > in_size - 1) i0 = in_size - 1;
-    i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
-    w1 = src - (float)i0;
-    w0 = 1.f - w1;
-}
-// weight with which destination d reads source s
-__device__ __forceinline__ float bl_weight(int d, int s, float rscale, int in_size) {
-    int i0, i1; float w0, w1;
-    bl_taps(d, rscale, in_size, i0, i1, w0, w1);
-    return (s == i0 ? w0 : 0.f) + (s == i1 ? w1 : 0.f);
-}
 
 // am[b,k,y,x] = sum_{Y,X} mask_k[b,Y,X] * wy(Y->y) * wx(X->x)
 __global__ void mask_adjoint_kernel(const float* __restrict__ masks, float* __restrict__ am, int B, int nmask, int H,
@@ -130,17 +113,7 @@ __global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __res
     }
 }
 
-// ---- cosine match: a group of C/4 lanes owns one pixel (float4 each), xor-shuffle reduce
-constexpr float kCosEps = 1e-8f;
-constexpr int kMaxK = 4;
-
-template <int L>  // lanes per pixel = C/4, power of two <= 64
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
+// ---- cosine match: a group of C/4 lanes owns one pixel (float4 each), xor-shuffle reduce (helpers: matcher.h)
 template <int L>
 __global__ __launch_bounds__(256) void cosine_match_fwd_kernel(const float* __restrict__ f, const float* __restrict__ proto,
                                                                 float* __restrict__ pred, int B, int K, int hw, float scaler) {
@@ -254,6 +227,10 @@ __global__ __launch_bounds__(256) void cosine_dproto_final(const float* __restri
         }
         __syncthreads();
     }
+}
+
+void launch_cosine_dproto_final(const float* dpart, float* dproto, int B, int nblk, int K, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(cosine_dproto_final, dim3(B * K), dim3(256), 0, stream, dpart, dproto, B, nblk, K, C);
 }
 
 // blocks per episode of the cosine-match backward: enough for ~8 blocks per CU whatever the batch (a fixed 32 left the

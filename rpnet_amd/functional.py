@@ -275,6 +275,24 @@ def _cconv(name, d, *rest):
     call(name, C.byref(d), *rest)
 
 
+def _cup4(d, mode):
+    """rpnet_conv_up4 with the launch counted (kind conv3x3_up4: four products per output instead of nine)"""
+    ARITH[("conv3x3_up4", _PLANE_NAME[d.split_planes])] += 1
+    call("rpnet_conv_up4", C.byref(d), mode)
+
+
+def _up4_ok(pw, planes, upsample, x1, in_scale, xs0, N, H, W, cout):
+    """does this launch take the collapsed form of an up_conv layer (see _UP4): two fp16 planes, a single unmasked source, a
+    plain 3x3 layer whose shapes fit the kernel"""
+    if not (_UP4 and upsample and planes == 2 and x1 is None and in_scale is None and pw is not None and pw.taps == 9
+            and pw.cin_pad == pw.cin and pw.cin % 32 == 0 and cout % 64 == 0):
+        return False
+    probe = ConvDesc()
+    probe.N, probe.H, probe.W, probe.C0, probe.Co0, probe.split_planes = N, H, W, pw.cin, cout, 2
+    probe.x0, probe.y0 = ptr(xs0), ptr(xs0)
+    return bool(query("rpnet_conv_up4_supported", C.byref(probe), 1))
+
+
 # zeroed device scalars for rpnet_conv_desc.out_absmax (eval-mode f16 scales): one pool per device, handed out slot by slot,
 # re-zeroed with ONE fill at the start of every RP_Net.forward (reset_absmax_pool); a call outside a forward that runs
 # out of slots gets a fresh pool
@@ -450,10 +468,16 @@ class Operand:
              f16x2 / f16 mode runs on three bf16 planes, and the launch counters (arith_counts) show it.
     A tensor derived from x whose values are a subset of x's (max-pool, a batch slice, an alias) keeps the bound:
     `derive`."""
-    __slots__ = ("x", "p16", "pbf", "scale", "planes_only", "bn_ref")
+    __slots__ = ("x", "p16", "pbf", "scale", "planes_only", "bn_ref", "deferred", "masked")
 
-    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False, bn_ref=None):
+    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False, bn_ref=None, deferred=None, masked=None):
         self.x, self.p16, self.pbf, self.scale = x, p16, pbf, scale
+        # deferred (train-mode cre.q, conv_bn_relu_op(defer_act=True)): (y, batch scale, batch shift) — x is still UNWRITTEN, the
+        # consumer (CosineMatchUp's fused launch) applies BatchNorm + ReLU and fills it
+        self.deferred = deferred
+        # masked: (mask tensor, mode, planes) — the operand planes of x * mask (mode 1) / x * (1 - mask) (mode 2) already exist
+        # (written by the previous iteration's fused glue launch); a convolution gathering x with that very mask takes them
+        self.masked = masked
         # bn_ref (only on a planes_only operand, i.e. a BatchNorm output with exactly one consumer): the producer's saved
         # pre-BatchNorm tensor and statistics, so that the consumer's input-gradient launch can run the reduction pass of
         # the producer's BatchNorm backward in its epilogue (BnRef)
@@ -506,6 +530,12 @@ _CONV1_BN_FUSE = os.environ.get("RPNET_CONV1_BN_FUSE", "1") == "1"
 # sums it, BatchNorm + ReLU and the backward's reduction pass / weight gradient make it again from the image (nine
 # multiply-adds per value against eight bytes written and re-read; csrc/conv_first.hip).  RPNET_CONV1_RECOMPUTE=0: A/B switch
 _CONV1_RECOMP = os.environ.get("RPNET_CONV1_RECOMPUTE", "1") == "1"
+# up_conv (nn.Upsample(scale_factor=2) -> Conv2d 3x3, net/modules.py:61-75: Up5, Up4) on its COLLAPSED weights: a 3x3 convolution over a
+# nearest-x2 up-sampled image reads a 2 x 2 block of source pixels per output pixel, so with the weights of coinciding taps added
+# up front the layer needs 4 / 9 of its multiply-adds — forward, input gradient and weight gradient (csrc/conv_up4_dma.hip,
+# rpnet_conv_up4; the two layers are 17 % of the step's FLOPs as the reference writes them).  Differs from the nine-product
+# form by the rounding of the weight sums (2^-24 relative).  RPNET_UPCONV_COLLAPSE=0: the nine-product form (A/B switch).
+_UP4 = os.environ.get("RPNET_UPCONV_COLLAPSE", "1") == "1"
 # w_k(x * mask) / w_q(x * (1 - mask)) (net/rp_net.py:275,283): output tiles whose masked input is zero on the tile and its halo
 # (forward) or whose factor is zero on the tile (input gradient) skip their K loop (rpnet_conv_desc.skip_*) — same bits as the
 # dense launch.  The support mask covers 2 - 15 % of the pixels, so most tiles of w_k go.  bench.py keeps the HEADLINE dense
@@ -582,6 +612,9 @@ def split_bf16(x, planes, scale=None, mode=0):
 def _split_operand(op, planes, scale=None, mode=0):
     """bf16 planes of a conv operand; an unmasked operand remembers its split (skip connections ask for it again)."""
     if scale is not None and mode:
+        pre = op.masked
+        if pre is not None and pre[0] is scale and pre[1] == mode and pre[2].shape[0] == planes and pre[2].dtype == torch.bfloat16:
+            return pre[2]
         return split_bf16(op.values(), planes, scale, mode)
     if op.pbf is not None and op.pbf.shape[0] == planes and op.pbf.shape[1:] == op.x.shape:
         return op.pbf
@@ -637,6 +670,10 @@ def _f16_sources(op0, op1, in_scale, in_mode, two_scales=False):
 
     if op1 is None and not masked and ready(op0):
         return op0.p16, None, s0, None
+    pre = op0.masked
+    if (op1 is None and masked and pre is not None and pre[0] is in_scale and pre[1] == in_mode and pre[2].shape[0] == fp
+            and pre[2].dtype == torch.float16):
+        return pre[2], None, s0, None      # x * f(mask) / s0 split by the launch that made the mask (rpnet_refine_glue_fwd)
     if two_scales and op1 is not None and not masked and ready(op0) and ready(op1):
         return op0.p16, op1.p16, s0, s1
     xs0, s = split_f16(op0.values(), s0, s1, in_scale if masked else None, in_mode if masked else 0)
@@ -697,6 +734,28 @@ class PackedWeight:
                  ptr(pk[3]) if planes <= 2 else None)
         return pk
 
+    def up4_packs(self, planes):
+        """packs of the COLLAPSED weights of an up_conv layer (nn.Upsample(2) -> Conv2d 3x3, net/modules.py:61-75): the nine taps
+        summed onto the 2 x 2 source pixels each output phase really reads (rpnet_upconv_collapse_weights: [4 cout][cin][2][2]), then
+        the ordinary four-tap pack -> (wp4, wd4, row scale of wp4 [4 cout], row scale of wd4 [cin]); fp16 planes (1 / 2)"""
+        up = getattr(self, "_up4", None)
+        if up is None:
+            up = self._up4 = {}
+        pk = up.get(planes)
+        if pk is None:
+            w = self._weight
+            wc = torch.empty((4 * self.cout, self.cin, 2, 2), device=w.device, dtype=torch.float32)
+            call("rpnet_upconv_collapse_weights", ptr(w), ptr(wc), self.cout, self.cin)
+            n = 4 * self.cin * 4 * self.cout
+            wp4 = torch.empty((planes, n), device=w.device, dtype=torch.float16)
+            wd4 = torch.empty((planes, n), device=w.device, dtype=torch.float16)
+            t4 = torch.empty(4 * self.cout, device=w.device, dtype=torch.float32)
+            u4 = torch.empty(self.cin, device=w.device, dtype=torch.float32)
+            call("rpnet_pack_conv_weight_split", ptr(wc), ptr(wp4), ptr(wd4), 4 * self.cout, self.cin, 4, 0, self.cin, self.cin, self.cin,
+                 planes, ptr(t4), ptr(u4))
+            pk = up[planes] = (wp4, wd4, t4, u4)
+        return pk
+
     def alloc_split(self, planes):
         """buffers of the split pack (registered as this layer's pack; the caller fills them)"""
         if self.wps is None:
@@ -729,7 +788,7 @@ class WeightCache:
         self._d.clear()
         self._ready = None
 
-    def prepack_async(self, weights, planes, device):
+    def prepack_async(self, weights, planes, device, up4=()):
         """prepack() on the pack stream, beside whatever the caller's stream does next (the first-layer convolution and its
         BatchNorm passes need no pack: 0.2 ms of HBM-bound packing at the head of every training step with nothing else on
         the machine); every stream that fetches a layer's pack afterwards (get) first waits for the event recorded here.
@@ -739,7 +798,7 @@ class WeightCache:
         ps = _pack_stream(device)
         ps.wait_stream(main)
         with torch.cuda.stream(ps):
-            self.prepack(weights, planes)
+            self.prepack(weights, planes, up4)
             ev = torch.cuda.Event()
             ev.record(ps)
         self._ready = (ev, set())
@@ -759,10 +818,19 @@ class WeightCache:
             self._d[key] = pw
         return pw
 
-    def prepack(self, weights, planes):
+    def prepack(self, weights, planes, up4=()):
         """The split packs of many layers in ONE launch per kernel (rpnet_pack_conv_weights_split) instead of two
         launches per layer on first use: RP_Net.forward hands in the 3x3 weights of the whole model right after
-        clearing the cache.  `planes`: 3 (bf16), 2 / 1 (fp16 planes with row scales)."""
+        clearing the cache.  `planes`: 3 (bf16), 2 / 1 (fp16 planes with row scales).
+        up4: the weights among them that belong to up_conv layers (nn.Upsample -> Conv2d): on two fp16 planes their forward and
+        input gradient run on the COLLAPSED four-tap pack (PackedWeight.up4_packs, see _UP4), which is made here instead of
+        the nine-tap pack (a launch that falls back to the nine-tap form packs it on first use)."""
+        up4 = list(up4) if (_UP4 and planes == 2) else []
+        if up4:
+            skip = {id(w) for w in up4}
+            weights = [w for w in weights if id(w) not in skip]
+            for w in up4:
+                self.get(w).up4_packs(planes)
         pws = [self.get(w) for w in weights]
         pws = [pw for pw in pws if pw.taps == 9 and pw.cin_pad == pw.cin and pw.cin % 32 == 0 and pw.cout % 32 == 0
                and not (pw.wps and planes in pw.wps)]
@@ -938,10 +1006,12 @@ class ConvBnRelu(Function):
                                                             and cout % 64 == 0 and x0.shape[-1] % 64 == 0):
                 raise RuntimeError("rpnet_amd: a planes-only second source reached a convolution that does not read its "
                                    "fp16 planes as they are (forward and weight gradient)")
+            up4 = False
             if f16 is not None:      # fp16 planes (two, or one in "f16" mode) with a tensor scale; weights with row scales
                 xs, sx, sx1 = (f16[0], f16[1]), f16[2], f16[3]
                 fp = _MATH["f16_planes"]
-                wps, _, t_row, _ = pw.split_packs(fp)
+                up4 = _up4_ok(pw, fp, upsample, x1, in_scale, xs[0], N, H, W, cout)
+                wps, t_row = (pw.up4_packs(fp)[0], pw.up4_packs(fp)[2]) if up4 else (pw.split_packs(fp)[0], pw.split_packs(fp)[2])
                 d = _desc(xs[0], xs[1], wps, bias, None, 0, y, None, N, H, W, pw.taps, upsample, groups)
                 d.split_planes = fp
                 d.acc_scale_col, d.acc_scale_x, d.acc_scale_x1 = ptr(t_row), ptr(sx), ptr(sx1)
@@ -954,7 +1024,7 @@ class ConvBnRelu(Function):
                 d.split_planes = np_
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, y, None, N, H, W, pw.taps, upsample, groups)
-            fused = query("rpnet_conv_stats_blocks", C.byref(d))
+            fused = query("rpnet_conv_up4_stats_blocks" if up4 else "rpnet_conv_stats_blocks", C.byref(d))
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
@@ -965,7 +1035,10 @@ class ConvBnRelu(Function):
             if ycode is not None:
                 d.y_enc, d.y_enc_stride = ycode[0].data_ptr() + 4 * ycode[2], ycode[3]
                 ARITH[("pre_bn_tensor", "fp16 codes")] += 1
-            _cconv("rpnet_conv_fwd", d)
+            if up4:
+                _cup4(d, 1)
+            else:
+                _cconv("rpnet_conv_fwd", d)
         _order_wait(gamma.data_ptr())      # the running statistics: after the other chain's update of this module
         if fused:
             call("rpnet_bn_stats_from_partial", ptr(part), fused, N, H * W, cout, groups, ptr(gamma), ptr(beta),
@@ -1003,7 +1076,12 @@ class ConvBnRelu(Function):
             produced["planes_only"] = True
             if not pool and out_split is True and not recomp and ycode is None:
                 produced["bn_ref"] = BnRef(y, stats, groups)
-        if recomp:
+        defer = (bool(produced.get("defer_act")) and not pool and not np_out and not want16 and not recomp and ycode is None
+                 and groups == 1 and not produced.get("planes_only"))
+        if defer:
+            # BatchNorm + ReLU are applied by the consumer's fused launch (CosineMatchUp, rpnet_refine_glue_fwd), which fills z
+            produced["deferred"] = (y, stats[0], stats[1])
+        elif recomp:
             if not (produced.get("planes_only") and want16 and np_out):
                 raise RuntimeError("rpnet_amd: the first layer was run without its pre-BatchNorm tensor but its output is not planes-only")
             call("rpnet_conv1_bn_relu", ptr(x0), ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), None, ptr(zs), np_out,
@@ -1028,6 +1106,7 @@ class ConvBnRelu(Function):
         ctx.yshape = (N, H, W, cout)
         ctx.ycode = None if (recomp or ycode is None) else (ycode[1], ycode[2], ycode[3])      # the decode pair outlives _YCODE
         ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
+        ctx.up4 = (not first) and up4
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
         ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
         ctx.src_bn = op0.bn_ref if (op0.planes_only and _BNBWD_FUSE) else None   # this layer as the single consumer
@@ -1131,6 +1210,19 @@ class ConvBnRelu(Function):
                 dyp = dy
                 d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample, wgrad=True)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
+            # the collapsed up_conv (see _UP4): sixteen tap products per source pixel instead of thirty-six
+            wup4 = bool(getattr(ctx, "up4", False)) and wsplit and np_ == 2 and bool(query("rpnet_conv_wgrad_up4_supported", C.byref(d)))
+            if wup4:
+                wb = query("rpnet_conv_wgrad_up4_workspace_bytes", N, H, W, pw.cin, cout)
+
+            def wgrad(dy_ptr, dw_ptr, ws_t):
+                """the weight-gradient entry point of this layer: GEMM phase (dw_ptr None), reduce phase (dy_ptr None) or both"""
+                if wup4:
+                    if dy_ptr is not None:
+                        ARITH[("wgrad3x3_up4", _PLANE_NAME[d.split_planes])] += 1
+                    call("rpnet_conv_wgrad_up4", C.byref(d), dy_ptr, dw_ptr, ptr(ws_t), wb)
+                else:
+                    _cconv("rpnet_conv_wgrad", d, dy_ptr, dw_ptr, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws_t), wb)
             deferred = None
             if _direct(weight):
                 # the stream this backward node runs on (the one that produced dy and will run this layer's dgrad), taken NOW:
@@ -1146,7 +1238,7 @@ class ConvBnRelu(Function):
                     with torch.cuda.stream(side):
                         ws2 = _ws(wb, y)
                         if wsplit:   # GEMM on the side stream, its HBM-bound reduce on a third one under the next layer's GEMM
-                            _cconv("rpnet_conv_wgrad", d, ptr(dyp), None, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                            wgrad(ptr(dyp), None, ws2)
                             red = _reduce_stream(dev)
                             red.wait_stream(side)
                             if _KEEPALIVE:
@@ -1156,11 +1248,9 @@ class ConvBnRelu(Function):
                                     if tns is not None:
                                         tns.record_stream(red)
                             with torch.cuda.stream(red):
-                                _cconv("rpnet_conv_wgrad", d, None, ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
-                                     ptr(ws2), wb)
+                                wgrad(None, ptr(weight.grad), ws2)
                         else:
-                            _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(weight.grad), pw.cin, pw.off0, pw.split, pw.off1,
-                                 ptr(ws2), wb)
+                            wgrad(ptr(dyp), ptr(weight.grad), ws2)
                     if _KEEPALIVE:       # alive until join_side_streams (the saved tensors outlive this node anyway)
                         _ASYNC["keep"].append((x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy, ctx.xs))
                     else:
@@ -1183,16 +1273,28 @@ class ConvBnRelu(Function):
                 dw = None
             else:
                 ws2 = _ws(wb, y)
-                _cconv("rpnet_conv_wgrad", d, ptr(dyp), ptr(dw), pw.cin, pw.off0, pw.split, pw.off1, ptr(ws2), wb)
+                wgrad(ptr(dyp), ptr(dw), ws2)
             need0 = ctx.needs_input_grad[0]
             need1 = x1 is not None and ctx.needs_input_grad[1]
             if need0 or need1:
                 c0, c1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-                g0 = _empty((N, H, W, c0), y)
-                g1 = _empty((N, H, W, c1), y) if x1 is not None else None
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
                 need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
-                if dsplit:
+                up4 = bool(getattr(ctx, "up4", False)) and dsplit and np_ == 2
+                if up4:
+                    # the collapsed up_conv: the input gradient comes out at the SOURCE resolution (the 2 x 2 sum is in the launch)
+                    pk4 = pw.up4_packs(np_)
+                    g0, g1 = _empty(x0.shape, y), None
+                    dd = _desc(dys, None, pk4[1], None, None, 0, g0, None, N, H, W, pw.taps, 1)
+                    dd.split_planes = np_
+                    dd.acc_scale_col, dd.acc_scale_x = ptr(pk4[3]), ptr(sdy)
+                    up4 = bool(query("rpnet_conv_up4_supported", C.byref(dd), 2))
+                if not up4:
+                    g0 = _empty((N, H, W, c0), y)
+                    g1 = _empty((N, H, W, c1), y) if x1 is not None else None
+                if up4:
+                    pass
+                elif dsplit:
                     pk = pw.split_packs(np_)
                     dd = _desc(dys, None, pk[1], None, None, 0, g0, g1, N, H, W,
                                pw.taps, 0, out_scale=None if need_s else in_scale, out_mode=in_mode)
@@ -1216,7 +1318,10 @@ class ConvBnRelu(Function):
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
-                _cconv("rpnet_conv_fwd", dd)
+                if up4:
+                    _cup4(dd, 2)
+                else:
+                    _cconv("rpnet_conv_fwd", dd)
                 _tap("dgrad:g0,g1", weight, g0, g1)
                 if deferred:
                     _release_wgrads(_WGRAD_DEFER - 1)
@@ -1226,7 +1331,7 @@ class ConvBnRelu(Function):
                     call("rpnet_rowdot_scale", ptr(g0), ptr(x0), ptr(in_scale), ptr(gx), ptr(dscale), N * H * W, c0,
                          in_mode, 0)
                     g0 = gx
-                if upsample:
+                if upsample and not up4:
                     h0 = _empty(x0.shape, y)
                     call("rpnet_upsample2_bwd", ptr(g0), ptr(h0), N, H, W, c0)
                     g0 = h0
@@ -1240,7 +1345,7 @@ class ConvBnRelu(Function):
 
 
 def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mode=0, groups=1, upsample=False, split=None,
-                    out_split=True, z_unused=False, pool=False):
+                    out_split=True, z_unused=False, pool=False, defer_act=False):
     """Conv -> BatchNorm -> ReLU on Operands (tensors are wrapped: no planes, no bound); returns the output Operand.
     out_split: also write the output as the operand planes of its consumer (when the split arithmetic is on): True = a
     3x3 convolution reads it as is, "corr" = the local correlation, "scale" = no planes, only the fp16 tensor scale (a
@@ -1251,16 +1356,20 @@ def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mo
     pool: the caller wants MaxPool2d(2, 2) of the output and nothing else of it (net/unet.py:442-448): returns the POOLED
     Operand — in train mode on split planes out of the BatchNorm + ReLU pass itself (rpnet_bn_relu(pool_w): the
     full-resolution activation is never written, the backward finds the window maxima again from the conv output),
-    otherwise through the separate max-pool launch."""
+    otherwise through the separate max-pool launch.
+    defer_act (train mode, out_split False): BatchNorm + ReLU are NOT applied here — the returned Operand's tensor is unwritten
+    and its `deferred` = (y, batch scale, batch shift); the consumer's fused launch applies them and fills the tensor
+    (CosineMatchUp over cre.q's output: the refinement loop's glue, rpnet_refine_glue_fwd)."""
     op0, op1 = as_operand(x0), as_operand(x1)
     pw = cache.get(conv.weight, split) if (conv.weight.shape[1] >= 32 or split is not None) else None
     produced = {"z_unused": bool(z_unused) and training and conv.weight.shape[0] % 64 == 0,
-                "pool": bool(pool) and training and _POOL_FUSE, "pool_req": bool(pool)}
+                "pool": bool(pool) and training and _POOL_FUSE, "pool_req": bool(pool),
+                "defer_act": bool(defer_act) and training and not out_split}
     z = ConvBnRelu.apply(op0.x, None if op1 is None else op1.x, in_scale, conv.weight, conv.bias, bn.weight, bn.bias,
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
                          1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
     out = Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")),
-                  produced.get("bn_ref"))
+                  produced.get("bn_ref"), produced.get("deferred"))
     if pool and not produced.get("pooled"):
         out = maxpool2(out)
     return out
@@ -1561,20 +1670,61 @@ class MaskedPool(Function):
         return df, None, None
 
 
+# the refinement loop's glue as one launch per iteration (rpnet_refine_glue_fwd / _bwd, csrc/refine.hip): BatchNorm + ReLU of
+# cre.q, cosine match, bilinear x4, softmax / threshold / 4x4 average and the next call's masked operand planes.
+# RPNET_GLUE_FUSE=0: the separate launches of rounds 1 - 4 (A/B switch; same bits)
+_GLUE_FUSE = os.environ.get("RPNET_GLUE_FUSE", "1") == "1"
+
+
+def glue_supported(K, h, w, H, W, F, C=0, planes=0):
+    return bool(_GLUE_FUSE and H == 4 * h and W == 4 * w and query("rpnet_refine_glue_supported", K, h, w, F, C, planes))
+
+
 class CosineMatchUp(Function):
     """calDist x (1+Wa) -> stack -> F.interpolate(bilinear) (net/rp_net.py:301-303):
-    f [B,h,w,C], proto [B,K,C] -> (logits [B,K,H,W], pred [B,K,h,w] (not differentiable here))."""
+    f [B,h,w,C], proto [B,K,C] -> (logits [B,K,H,W], pred [B,K,h,w] (not differentiable here)).
+    One launch where the shapes fit the fused kernel (glue_supported), and then optionally more of the loop's glue in the same
+    launch — `extra` (a dict, or None):
+      "deferred": (y, scale, shift)  f is still unwritten: f = relu(y * scale + shift) is formed and written here
+                                     (conv_bn_relu_op(defer_act=True), net/rp_net.py:65-69)
+      "mask": True, "soft": bool     also softmax(1)[:, 1] -> > 0.5 unless soft -> avg_pool2d(4) (net/rp_net.py:308-311);
+                                     the next mask [B,h,w] comes back as extra["mask_out"]
+      "x": tensor [B,h,w,Cx], "x_scale": device scalar or None, "planes": 1 / 2 (fp16) or 3 (bf16)
+                                     also the operand planes of x * mask and x * (1 - mask) (net/rp_net.py:283) ->
+                                     extra["xk"], extra["xq"] [planes,B,h,w,Cx]"""
 
     @staticmethod
-    def forward(ctx, f, proto, H, W, scaler):
+    def forward(ctx, f, proto, H, W, scaler, extra=None):
         ctx.set_materialize_grads(False)      # `pred` is not differentiable: no zero tensor for it in backward
         B, h, w, Cc = f.shape
         K = proto.shape[1]
         proto = proto.contiguous()
         pred = _empty((B, K, h, w), f)
-        call("rpnet_cosine_match_fwd", ptr(f), ptr(proto), ptr(pred), B, K, h * w, Cc, float(scaler))
         logits = _empty((B, K, H, W), f)
-        call("rpnet_bilinear_up_fwd", ptr(pred), ptr(logits), B * K, h, w, H, W)
+        ex = extra if extra is not None else {}
+        x = ex.get("x")
+        planes = int(ex.get("planes") or 0) if x is not None else 0
+        ctx.fused = glue_supported(K, h, w, H, W, Cc, x.shape[-1] if x is not None else 0, planes)
+        if ctx.fused:
+            d = ex.get("deferred")
+            mask = _empty((B, h, w), f) if ex.get("mask") else None
+            xk = xq = None
+            if x is not None and mask is not None:
+                dt = torch.bfloat16 if planes == 3 else torch.float16
+                xk = torch.empty((planes,) + tuple(x.shape), device=f.device, dtype=dt)
+                xq = torch.empty((planes,) + tuple(x.shape), device=f.device, dtype=dt)
+            call("rpnet_refine_glue_fwd", ptr(d[0] if d else f), ptr(d[1]) if d else None, ptr(d[2]) if d else None, ptr(proto),
+                 float(scaler), ptr(f) if d else None, ptr(pred), ptr(logits), ptr(mask), 1 if ex.get("soft") else 0,
+                 ptr(x) if xk is not None else None, ptr(ex.get("x_scale")), ptr(xk), ptr(xq), planes, B, K, h, w, Cc,
+                 x.shape[-1] if x is not None else 0)
+            if mask is not None:
+                ex["mask_out"], ex["xk"], ex["xq"] = mask, xk, xq
+        else:
+            if ex.get("deferred") or ex.get("mask"):
+                raise RuntimeError("rpnet_amd: CosineMatchUp was asked for the fused glue on shapes the kernel does not take "
+                                   "(check glue_supported before deferring the activation)")
+            call("rpnet_cosine_match_fwd", ptr(f), ptr(proto), ptr(pred), B, K, h * w, Cc, float(scaler))
+            call("rpnet_bilinear_up_fwd", ptr(pred), ptr(logits), B * K, h, w, H, W)
         ctx.save_for_backward(f, proto)
         ctx.cfg = (H, W, float(scaler))
         ctx.mark_non_differentiable(pred)
@@ -1584,19 +1734,25 @@ class CosineMatchUp(Function):
     @once_differentiable
     def backward(ctx, dlogits, _dpred):
         if dlogits is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         f, proto = ctx.saved_tensors
         H, W, scaler = ctx.cfg
         B, h, w, Cc = f.shape
         K = proto.shape[1]
+        df, dproto = torch.empty_like(f), torch.empty_like(proto)
+        if ctx.fused:
+            wb = query("rpnet_refine_glue_bwd_workspace_bytes", B, K, h, w, Cc)
+            ws = _ws(wb, f)
+            call("rpnet_refine_glue_bwd", ptr(dlogits.contiguous()), ptr(f), ptr(proto), scaler, ptr(df), ptr(dproto), B, K, h, w,
+                 Cc, ptr(ws), wb)
+            return df, dproto, None, None, None, None
         dpred = _empty((B, K, h, w), f)
         call("rpnet_bilinear_up_bwd", ptr(dlogits.contiguous()), ptr(dpred), B * K, h, w, H, W)
-        df, dproto = torch.empty_like(f), torch.empty_like(proto)
         wb = query("rpnet_cosine_match_bwd_workspace_bytes", B, K, h * w, Cc)
         ws = _ws(wb, f)
         call("rpnet_cosine_match_bwd", ptr(f), ptr(proto), ptr(dpred), ptr(df), ptr(dproto), B, K, h * w, Cc, scaler, 0,
              ptr(ws), wb)
-        return df, dproto, None, None, None
+        return df, dproto, None, None, None, None
 
 
 class SoftmaxPool(Function):

@@ -46,6 +46,13 @@ _SIGS = {
     "rpnet_pack_conv_weight_split": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "rpnet_pack_conv_weights_split": (ci, [C.POINTER(PackItem), ci, ci, vp]),
     "rpnet_conv_fwd": (ci, [C.POINTER(ConvDesc), vp]),
+    "rpnet_upconv_collapse_weights": (ci, [vp, vp, ci, ci, vp]),
+    "rpnet_conv_up4_supported": (ci, [C.POINTER(ConvDesc), ci]),
+    "rpnet_conv_up4_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
+    "rpnet_conv_up4": (ci, [C.POINTER(ConvDesc), ci, vp]),
+    "rpnet_conv_wgrad_up4_supported": (ci, [C.POINTER(ConvDesc)]),
+    "rpnet_conv_wgrad_up4_workspace_bytes": (cs, [ci, ci, ci, ci, ci]),
+    "rpnet_conv_wgrad_up4": (ci, [C.POINTER(ConvDesc), vp, vp, vp, cs, vp]),
     "rpnet_conv_stats_blocks": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_conv_tile_variant": (ci, [C.POINTER(ConvDesc)]),
     "rpnet_conv_splitk_workspace_bytes": (cs, [C.POINTER(ConvDesc)]),
@@ -99,6 +106,10 @@ _SIGS = {
     "rpnet_bilinear_up_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_bilinear_up_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_softmax_thresh_pool": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_refine_glue_supported": (ci, [ci, ci, ci, ci, ci, ci]),
+    "rpnet_refine_glue_fwd": (ci, [vp, vp, vp, vp, cf, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "rpnet_refine_glue_bwd_workspace_bytes": (cs, [ci, ci, ci, ci, ci]),
+    "rpnet_refine_glue_bwd": (ci, [vp, vp, vp, cf, vp, vp, ci, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_rowdot_scale": (ci, [vp, vp, vp, vp, vp, cs, ci, ci, ci, vp]),
     "rpnet_softmax_pool_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "rpnet_loss_workspace_bytes": (cs, [ci, ci, ci, ci]),
@@ -110,6 +121,7 @@ _SIGS = {
     "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
+ABI_VERSION = 105      # RPNET_ABI_VERSION of include/rpnet_abi.h
 
 
 def lib_path():
@@ -124,6 +136,10 @@ def load():
             raise RuntimeError(f"{_LIB_PATH} not found: build it with `make -C rpnet_amd/csrc` "
                                "(or __graft_entry__.build()); rpnet_amd has no CPU fallback")
         lib = C.CDLL(_LIB_PATH)
+        lib.rpnet_version.restype = ci
+        if lib.rpnet_version() != ABI_VERSION:
+            raise RuntimeError(f"{_LIB_PATH} has ABI version {lib.rpnet_version()}, this binding was written for {ABI_VERSION} "
+                               "(include/rpnet_abi.h RPNET_ABI_VERSION): rebuild it with `make -C rpnet_amd/csrc`")
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -371,10 +371,14 @@ class ContextCorrelationEncoder(nn.Module):
             raise NotImplementedError("mask_refinement_correlation_radius outside 1..7 (the window kernels hold 2 r + 1 <= 15 "
                                       "vertical offsets per block; the yaml ships 5)")
 
-    def forward_masked(self, fts, mask, cache, fts_scale=None):
+    def forward_masked(self, fts, mask, cache, fts_scale=None, defer_act=False, pre=None):
         """cre(fts*mask, fts*(1-mask)) with the mask multiply fused into the conv gather
         (net/rp_net.py:275,283).  fts [B,h,w,C] NHWC (or a pair of aliases of it, one per convolution: RF.FanOut),
-        mask [B,h,w] or None."""
+        mask [B,h,w] or None.
+        defer_act: return the RF.Operand of the output with cre.q's BatchNorm + ReLU still to be applied by the consumer's
+        fused launch (train mode; RF.conv_bn_relu_op(defer_act)) instead of the output tensor.
+        pre: (xk, xq) — the operand planes of fts * mask and fts * (1 - mask), already made by the launch that made `mask`
+        (RF.CosineMatchUp's fused glue); the two convolutions then take them as they are."""
         t = self.training
         fk, fq = fts if isinstance(fts, tuple) else (fts, fts)
         m1, m2 = (1, 2) if mask is not None else (0, 0)
@@ -385,12 +389,14 @@ class ContextCorrelationEncoder(nn.Module):
         # values would raise)
         zu = _ZSKIP and sp == "corr" and RF._CORR16 and RF._CONV1X1_SPLIT and self.w_k[0].weight.shape[0] % 128 == 0
 
+        mk, mq = ((mask, 1, pre[0]), (mask, 2, pre[1])) if (pre is not None and mask is not None) else (None, None)
+
         def w_k():
-            return RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale), self.w_k[0], self.w_k[1], cache, t, in_scale=mask,
+            return RF.conv_bn_relu_op(RF.Operand(fk, scale=fts_scale, masked=mk), self.w_k[0], self.w_k[1], cache, t, in_scale=mask,
                                       in_mode=m1, out_split=sp, z_unused=zu)
 
         def w_q():
-            return RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale), self.w_q[0], self.w_q[1], cache, t, in_scale=mask,
+            return RF.conv_bn_relu_op(RF.Operand(fq, scale=fts_scale, masked=mq), self.w_q[0], self.w_q[1], cache, t, in_scale=mask,
                                       in_mode=m2, out_split=sp, z_unused=zu)
 
         # inference on a few slices (test_rpnet.py: 2 per call): either convolution is 256 four-wave blocks of a machine
@@ -415,13 +421,14 @@ class ContextCorrelationEncoder(nn.Module):
                     tns.record_stream(main)
         else:
             fm1, fm2 = w_k(), w_q()
-        return self._tail(fm1, fm2, cache)
+        out = self._tail(fm1, fm2, cache, defer_act)
+        return out if defer_act else out.x
 
-    def _tail(self, fm1, fm2, cache):
+    def _tail(self, fm1, fm2, cache, defer_act=False):
         corr, fm1b = RF.local_corr(fm1, fm2, self.radius)     # fm1b: alias of fm1, gradient fan-in fused (RF.LocalCorr)
         kk = (2 * self.radius + 1) ** 2
-        return RF.conv_bn_relu(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.corr_stride(self.radius)),
-                               out_split=False)
+        return RF.conv_bn_relu_op(corr, self.q[0], self.q[1], cache, self.training, x1=fm1b, split=(kk, RF.corr_stride(self.radius)),
+                                  out_split=False, defer_act=defer_act)
 
     def forward(self, fm1, fm2):
         cache = RF.WeightCache()
@@ -429,7 +436,7 @@ class ContextCorrelationEncoder(nn.Module):
         sp = "corr" if self.radius == 5 else False
         a = RF.conv_bn_relu_op(_to_nhwc(fm1), self.w_k[0], self.w_k[1], cache, t, out_split=sp)
         b = RF.conv_bn_relu_op(_to_nhwc(fm2), self.w_q[0], self.w_q[1], cache, t, out_split=sp)
-        return _to_nchw(self._tail(a, b, cache))
+        return _to_nchw(self._tail(a, b, cache).x)
 
 
 class RP_Net(nn.Module):
@@ -516,10 +523,12 @@ class RP_Net(nn.Module):
             RF.y_codes_end()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
+            # (training: the two up_conv layers on their collapsed four-tap packs, RF._UP4)
+            ups = (self.encoder.Up5.up[1].weight, self.encoder.Up4.up[1].weight) if self.training else ()
             if _PACK_STREAM and self.training and supp.is_cuda:
-                cache.prepack_async(self._pack_weights(), planes, supp.device)
+                cache.prepack_async(self._pack_weights(), planes, supp.device, ups)
             else:
-                cache.prepack(self._pack_weights(), planes)
+                cache.prepack(self._pack_weights(), planes, ups)
         # both encoder calls of the reference get the SUPPORT foreground mask of way 0 / shot 0 (net/rp_net.py:248,257)
         enc_mask = fore_mask[0][0].float() if self.encoder.mask_feature_map else None
         if enc_mask is not None and ns != B:
@@ -607,17 +616,46 @@ class RP_Net(nn.Module):
         # the query features feed 2 T convolutions: one-pass gradient fan-in instead of autograd's chain of adds
         T = self.num_iter
         qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
+        # the loop's glue — cre.q's BatchNorm + ReLU, the cosine match, the bilinear x4, softmax / threshold / 4x4 average and the
+        # operand planes of qry * mask, qry * (1 - mask) for the next iteration — is ONE launch per iteration where the shapes
+        # fit (RF.CosineMatchUp / rpnet_refine_glue_fwd); a differentiable mask (soft_mask in training) keeps the separate path
+        K = 1 + n_ways
+        soft_grad = soft and torch.is_grad_enabled()
+        fuse = qry_d4.is_cuda and RF.glue_supported(K, h, w, H, W, 64) and not soft_grad
+        # planes of the masked query features the two 3x3 convolutions of the NEXT call read: fp16 (the feature scale is known)
+        # or three bf16; 0 = they gather fp32 values with the mask factor themselves
+        xplanes = 0
+        if fuse and RF.pack_planes() and qry_d4.shape[-1] % 64 == 0:
+            xplanes = RF.pack_planes() if (RF.f16_mode() and s_qry is not None) else RF._MATH["planes"]
+            if not RF.glue_supported(K, h, w, H, W, 64, qry_d4.shape[-1], xplanes):
+                xplanes = 0
+        pre = None
         for i in range(T):
             if self.forced_masks is not None and i in self.forced_masks:
-                qry_mask = self.forced_masks[i].float().contiguous()
-            inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
-            logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
+                qry_mask, pre = self.forced_masks[i].float().contiguous(), None
+            if fuse:
+                io = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry, defer_act=True, pre=pre)
+                inter = io.x
+                last = i + 1 == T
+                forced_next = self.forced_masks is not None and (i + 1) in self.forced_masks
+                ex = {"deferred": io.deferred, "mask": not last, "soft": bool(soft)}
+                if not last and xplanes and not forced_next:
+                    ex.update(x=qry_d4, x_scale=s_qry if xplanes <= 2 else None, planes=xplanes)
+                logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0, ex)
+                if not last:
+                    qry_mask = ex["mask_out"]
+                    pre = (ex["xk"], ex["xq"]) if ex.get("xk") is not None else None
+            else:
+                inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
+                logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
             if taps is not None:
                 taps[f"inter_{i}"] = _to_nchw(inter.detach())
             refinement[i] = logits
             if i + 1 == T:
                 break              # the mask of the last iteration's output feeds nothing (net/rp_net.py:308-311 computes it; unused)
-            if soft and torch.is_grad_enabled():   # soft_mask: the gradient flows through the fed-back mask
+            if fuse:
+                continue
+            if soft_grad:   # soft_mask: the gradient flows through the fed-back mask
                 qry_mask = RF.SoftmaxPool.apply(logits, self.scale)
             else:
                 qry_mask = RF.softmax_thresh_pool(logits, self.scale, soft)

@@ -31,6 +31,8 @@ def _run(RF, monkeypatch, tile, layer, a, b, go, ups, groups):
     `tile` forced; -> (z, da, db, running_var, the variants rpnet_conv_fwd actually chose)"""
     from rpnet_amd import hip
     monkeypatch.setitem(RF.TUNE, "tile", tile + 1)
+    if tile >= 0:       # a forced tile variant of rpnet_conv_fwd: the up-sampling layers on their nine-product form
+        monkeypatch.setattr(RF, "_UP4", False)
     chosen = []
     orig = RF.call
 
@@ -343,4 +345,154 @@ def test_dma_patch_kernel_split_k(RF, N, H, W, c0, c1, cout, ups):
         assert rel_err(nchw(z1), ref) < 1e-3
     finally:
         RF._EVAL_SPLITK = old_sk
+        RF.set_conv_math(old)
+
+
+UP4_CASES = [
+    (2, 32, 32, 128, 128),      # low resolution 16 x 16: one 16 x 16 patch per image, 128-wide column tiles (one per phase)
+    (2, 16, 64, 64, 64),        # low resolution 8 x 32: 8 x 32 patches, 64-wide tiles, two channel chunks
+    (4, 32, 64, 256, 128),      # 16 x 32: two patches per image (top / bottom borders inside the image), 8 chunks; 32 blocks in the
+                                # input gradient: every start chunk / start phase of the rotated K loop, with wrap-around
+    (1, 64, 64, 128, 256),      # 32 x 32: four patches, two column tiles per phase
+    (3, 32, 32, 128, 192),      # 64-wide column tiles (192 = 3 x 64 per phase), 24 K chunks in the input gradient; odd image count
+    (8, 32, 32, 512, 256),      # the input gradient in 128-wide tiles (256 blocks), 16 chunks per phase
+]
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", UP4_CASES)
+def test_upconv_collapsed_kernels_against_nine_tap_form_and_fp64(RF, N, H, W, cin, cout):
+    """rpnet_conv_up4 (csrc/conv_up4_dma.hip) through the C ABI, without a BatchNorm behind it (no ReLU decisions that a 1e-7
+    difference could flip): nn.Upsample(2) -> Conv2d 3x3 (net/modules.py:66-67) with the nine taps collapsed onto the 2 x 2 source
+    pixels an output phase reads.  Forward (+ bias, + fused BatchNorm statistics) and input gradient (at the source resolution)
+    against the nine-product kernels (rpnet_conv_fwd with the up-sampling in its gather, rpnet_upsample2_bwd) to 1e-5 of the tensor's
+    maximum — the two differ by the rounding of the weight sums — and against torch in float64 to the 1e-3 bar (measured: 1e-6)."""
+    from rpnet_amd.hip import call, ptr, query
+    g = torch.Generator().manual_seed(77)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_((torch.rand(conv.weight.shape, generator=g) - 0.5) * (2.0 / (cin * 9) ** 0.5))
+        conv.bias.copy_((torch.rand(cout, generator=g) - 0.5) * 0.2)
+    a, go = rnd(192, N, cin, H // 2, W // 2), rnd(194, N, cout, H, W)
+    # fp64
+    cr = copy.deepcopy(conv).double()
+    ar = a.double().requires_grad_(True)
+    yr = cr(F.interpolate(ar, scale_factor=2, mode="nearest"))
+    yr.backward(go.double())
+    w, b = conv.weight.detach().to(DEV), conv.bias.detach().to(DEV)
+    x, dy = nhwc(a).to(DEV), nhwc(go).to(DEV)
+    sx = torch.tensor([2.0 ** -13], device=DEV)
+    sdy = torch.tensor([2.0 ** -13], device=DEV)
+    xs = RF.split_f16(x, sx, want_scale=False, planes=2)[0]
+    dys = RF.split_f16(dy, sdy, want_scale=False, planes=2)[0]
+    pw = RF.PackedWeight(w)
+    wp9, wd9, t9, u9 = pw.split_packs(2)
+    wp4, wd4, t4, u4 = pw.up4_packs(2)
+    groups = 2 if N % 2 == 0 else 1
+
+    def fwd(up4):
+        y = torch.empty(N, H, W, cout, device=DEV)
+        d = RF._desc(xs, None, wp4 if up4 else wp9, b, None, 0, y, None, N, H, W, 9, 1, groups)
+        d.split_planes = 2
+        d.acc_scale_col, d.acc_scale_x = ptr(t4 if up4 else t9), ptr(sx)
+        rows = query("rpnet_conv_up4_stats_blocks" if up4 else "rpnet_conv_stats_blocks", C.byref(d))
+        part = torch.zeros(groups * max(rows, 1) * cout * 2, device=DEV, dtype=torch.float64)
+        if rows:
+            d.stats_partial = ptr(part)
+        if up4:
+            assert query("rpnet_conv_up4_supported", C.byref(d), 1)
+            call("rpnet_conv_up4", C.byref(d), 1)
+        else:
+            call("rpnet_conv_fwd", C.byref(d))
+        return y, part.reshape(groups, max(rows, 1), cout, 2).sum(1), rows
+
+    def dgrad(up4):
+        if up4:
+            dx = torch.empty(N, H // 2, W // 2, cin, device=DEV)
+            d = RF._desc(dys, None, wd4, None, None, 0, dx, None, N, H, W, 9, 1)
+            d.split_planes = 2
+            d.acc_scale_col, d.acc_scale_x = ptr(u4), ptr(sdy)
+            assert query("rpnet_conv_up4_supported", C.byref(d), 2)
+            call("rpnet_conv_up4", C.byref(d), 2)
+            return dx
+        gh = torch.empty(N, H, W, cin, device=DEV)
+        d = RF._desc(dys, None, wd9, None, None, 0, gh, None, N, H, W, 9, 0)
+        d.split_planes = 2
+        d.acc_scale_col, d.acc_scale_x = ptr(u9), ptr(sdy)
+        call("rpnet_conv_fwd", C.byref(d))
+        dx = torch.empty(N, H // 2, W // 2, cin, device=DEV)
+        call("rpnet_upsample2_bwd", ptr(gh), ptr(dx), N, H, W, cin)
+        return dx
+
+    y4, st4, rows4 = fwd(True)
+    y9, st9, rows9 = fwd(False)
+    assert rows4 == (N // groups) * H * W // 256
+    assert rel_err(y4, y9) < 1e-5 and rel_err(nchw(y4), yr) < 1e-3
+    # the fused statistics: per group and channel (sum, sum of squares) of the launch's own output
+    per = N // groups
+    yg = y4.double().reshape(groups, per * H * W, cout)
+    assert rel_err(st4[..., 0], yg.sum(1)) < 1e-9 and rel_err(st4[..., 1], (yg * yg).sum(1)) < 1e-9
+    dx4, dx9 = dgrad(True), dgrad(False)
+    assert rel_err(dx4, dx9) < 1e-5 and rel_err(nchw(dx4), ar.grad) < 1e-3
+    e4, e9 = rel_err(nchw(y4), yr), rel_err(nchw(y9), yr)
+    assert e4 < 2 * e9 + 1e-6, (e4, e9)
+
+    # weight gradient (csrc/conv_wgrad_up4.hip): sixteen tap products per source pixel, the phases summed back onto the nine taps
+    def wgrad(up4, two_phase=False):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        d = RF._desc(xs, None, None, None, None, 0, None, None, N, H, W, 9, 1, co_split=(cout, 0), wgrad=True)
+        d.split_planes = 2
+        d.acc_scale_x, d.acc_scale_dy = ptr(sx), ptr(sdy)
+        if up4:
+            assert query("rpnet_conv_wgrad_up4_supported", C.byref(d))
+            wb = query("rpnet_conv_wgrad_up4_workspace_bytes", N, H, W, cin, cout)
+            ws = torch.empty(wb // 4 + 4, device=DEV)
+            if two_phase:
+                call("rpnet_conv_wgrad_up4", C.byref(d), ptr(dys), None, ptr(ws), wb)
+                call("rpnet_conv_wgrad_up4", C.byref(d), None, ptr(dw), ptr(ws), wb)
+            else:
+                call("rpnet_conv_wgrad_up4", C.byref(d), ptr(dys), ptr(dw), ptr(ws), wb)
+        else:
+            wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, cin, cout, 9)
+            ws = torch.empty(wb // 4 + 4, device=DEV)
+            call("rpnet_conv_wgrad", C.byref(d), ptr(dys), ptr(dw), cin, 0, cin, cin, ptr(ws), wb)
+        return dw
+
+    dw4, dw9 = wgrad(True), wgrad(False)
+    assert rel_err(dw4, dw9) < 1e-5 and rel_err(dw4, cr.weight.grad) < 1e-3
+    assert torch.equal(wgrad(True, two_phase=True), dw4)
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", UP4_CASES[:3])
+def test_upconv_layer_on_the_collapsed_form(RF, monkeypatch, N, H, W, cin, cout):
+    """the same through the layer (conv + BatchNorm + ReLU, forward and backward, RF.conv_bn_relu_op(upsample=True)): both launches
+    counted as collapsed; output, running statistics and weight gradient against the nine-product form and float64; the input
+    gradient in relative L2 (one pre-activation within 1e-7 of zero may take the other side of its ReLU between two roundings of
+    the same layer, which moves a 3 x 3 neighbourhood of the gradient by 1e-2 of its maximum: DESIGN.md section 4)."""
+    from tests.helpers import rel_l2
+    old = RF.conv_math()
+    RF.set_conv_math("f16x2")
+    try:
+        groups = 2 if N % 2 == 0 else 1
+        layer = _mk_layer(cin, cout, 3, 191)
+        a = rnd(192, N, cin, H // 2, W // 2)
+        go = rnd(194, N, cout, H, W)
+        c_ref, b_ref = copy.deepcopy(layer[0]).double(), copy.deepcopy(layer[1]).double().train()
+        ar = a.double().requires_grad_(True)
+        xin = F.interpolate(ar, scale_factor=2, mode="nearest")
+        per = N // groups
+        ref = torch.cat([F.relu(b_ref(c_ref(xin[g * per:(g + 1) * per]))) for g in range(groups)], 0)
+        ref.backward(go.double())
+        RF.reset_arith()
+        monkeypatch.setattr(RF, "_UP4", True)
+        z4, da4, _, rv4, dw4, _ = _run(RF, monkeypatch, -1, layer, a, None, go, True, groups)
+        counts = RF.arith_counts()
+        assert counts.get("conv3x3_up4", {}).get("f16x2", 0) == 2, counts       # forward + input gradient on the collapsed form
+        monkeypatch.setattr(RF, "_UP4", False)
+        z9, da9, _, rv9, dw9, _ = _run(RF, monkeypatch, -1, layer, a, None, go, True, groups)
+        assert da4.shape == da9.shape == (N, H // 2, W // 2, cin)
+        assert rel_err(z4, z9) < 1e-5 and rel_err(rv4, rv9) < 1e-6
+        assert rel_err(nchw(z4), ref) < 1e-3 and rel_err(rv4, b_ref.running_var) < 1e-5
+        assert rel_l2(da4, da9) < 2e-3 and rel_l2(nchw(da4), ar.grad) < 2e-3
+        assert rel_l2(dw4, dw9) < 2e-3 and rel_l2(dw4, c_ref.weight.grad) < 2e-3
+    finally:
         RF.set_conv_math(old)

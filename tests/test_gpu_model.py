@@ -253,7 +253,9 @@ def test_full_size_properties():
     out_c = net(si, fg, bg, qi, appr_query_labels=appr)
     total_loss(out_c, ql, 1.0).backward()
     counts = RF.arith_counts()
-    assert counts["conv3x3"] == {"f16x2": 54} and counts["wgrad3x3"] == {"f16x2": 27}, counts
+    # (Up5 / Up4 — forward, input gradient, weight gradient — on their collapsed four-product form: RF._UP4)
+    assert counts["conv3x3"] == {"f16x2": 50} and counts["conv3x3_up4"] == {"f16x2": 4}, counts
+    assert counts["wgrad3x3"] == {"f16x2": 25} and counts["wgrad3x3_up4"] == {"f16x2": 2}, counts
     assert counts["corr"] == {"f16x2": 6} and counts["corr_bwd"] == {"f16x2": 6}, counts
     # (Conv1.conv.0 of both... of the one encoder launch: its reduction pass makes the pre-BatchNorm tensor again from the image)
     assert counts["bn_bwd"] == {"own reduction pass": 33, "first layer made again from the image": 1}, counts

@@ -585,6 +585,76 @@ def test_cosine_match_upsample(RF, golden):
     assert rel_err(lo2[0, 0], g["cd_bg"][0]) < 1e-4 and rel_err(lo2[0, 1], g["cd_fg"][0]) < 1e-4
 
 
+@pytest.mark.parametrize("B,K,h,w,Cx,planes,soft", [(2, 2, 16, 24, 256, 2, False), (1, 3, 8, 8, 128, 1, False), (2, 2, 8, 16, 64, 3, True),
+                                                    (3, 2, 24, 8, 256, 0, False)])
+def test_refine_glue_is_the_separate_launches_bit_for_bit(RF, B, K, h, w, Cx, planes, soft):
+    """rpnet_refine_glue_fwd (one launch per refinement iteration: cre.q's BatchNorm + ReLU, cosine match, bilinear x4,
+    softmax / threshold / 4x4 average, the masked operand planes of the next call; net/rp_net.py:65-69,283,301-311) against the
+    separate entry points it replaces: every output must have the same BITS; its backward: same bits for the feature gradient,
+    the prototype gradient (another summation order over the pixels) to fp32 round-off."""
+    import ctypes as C
+    from rpnet_amd.hip import call, ptr, query
+    H, W, Fc = 4 * h, 4 * w, 64
+    assert RF.glue_supported(K, h, w, H, W, Fc, Cx, planes)
+    y = (rnd(51, B, h, w, Fc) * 2).to(DEV)
+    y[0, 0, 0] = -5.0                                            # relu -> a zero feature vector (cosine 0)
+    sc, sh = (0.5 + torch.rand(Fc, generator=torch.Generator().manual_seed(1))).to(DEV), (rnd(52, Fc) * 0.3).to(DEV)
+    proto = rnd(53, B, K, Fc).to(DEV)
+    x = rnd(54, B, h, w, Cx).to(DEV)
+    xs = torch.tensor([2.0 ** -13], device=DEV)
+    # --- separate launches
+    z0 = torch.empty_like(y)
+    call("rpnet_bn_relu", ptr(y), ptr(sc), ptr(sh), ptr(z0), None, 0, None, None, None, B, h * w, Fc, 1, 0, None, 0)
+    pred0, logits0 = torch.empty(B, K, h, w, device=DEV), torch.empty(B, K, H, W, device=DEV)
+    call("rpnet_cosine_match_fwd", ptr(z0), ptr(proto), ptr(pred0), B, K, h * w, Fc, 20.0)
+    call("rpnet_bilinear_up_fwd", ptr(pred0), ptr(logits0), B * K, h, w, H, W)
+    mask0 = RF.softmax_thresh_pool(logits0, 4, soft)
+    if planes in (1, 2):
+        xk0, xq0 = (RF.split_f16(x, xs, None, mask0, m, want_scale=False, planes=planes)[0] for m in (1, 2))
+    elif planes == 3:
+        xk0, xq0 = (RF.split_bf16(x, 3, mask0, m) for m in (1, 2))
+    # --- the fused launch, through the autograd Function (deferred activation: z is filled by it)
+    z1 = torch.full_like(y, float("nan")).requires_grad_(True)
+    pg = proto.clone().requires_grad_(True)
+    ex = {"deferred": (y, sc, sh), "mask": True, "soft": soft}
+    if planes:
+        ex.update(x=x, x_scale=xs if planes <= 2 else None, planes=planes)
+    logits1, pred1 = RF.CosineMatchUp.apply(z1, pg, H, W, 20.0, ex)
+    assert torch.equal(z1.detach(), z0) and torch.equal(pred1, pred0) and torch.equal(logits1.detach(), logits0)
+    assert torch.equal(ex["mask_out"], mask0)
+    assert 0 < float(mask0.mean()) < 1 and (soft or set(torch.unique(mask0 * 16).tolist()) <= set(range(17)))
+    if planes in (1, 2):      # the same VALUES (an x * 0 may come out as -0 here and +0 there: the planes are compared as numbers)
+        assert torch.equal(ex["xk"], xk0) and torch.equal(ex["xq"], xq0)
+    elif planes == 3:
+        # three bf16 planes: x * f(mask) exactly (24 significand bits); the two kernels may round the product x * (1 - m) of a SOFT
+        # mask differently by one ulp (a multiply-subtract contracted or not), so the planes are compared through their sums
+        for got, want, f in ((ex["xk"], xk0, mask0), (ex["xq"], xq0, 1.0 - mask0)):
+            assert rel_err(got.float().sum(0), want.float().sum(0)) < 2e-7
+            assert rel_err(got.float().sum(0), x * f[..., None]) < 2e-7
+    assert pred1[0, :, 0, 0].abs().max() == 0
+    # the last iteration's form: logits only, no activation to apply
+    l2, p2 = RF.CosineMatchUp.apply(z0, proto, H, W, 20.0, {})
+    assert torch.equal(l2, logits0) and torch.equal(p2, pred0)
+    # --- backward
+    go = rnd(55, B, K, H, W).to(DEV)
+    logits1.backward(go)
+    dpred = torch.empty(B, K, h, w, device=DEV)
+    call("rpnet_bilinear_up_bwd", ptr(go), ptr(dpred), B * K, h, w, H, W)
+    df0, dp0 = torch.empty_like(z0), torch.empty_like(proto)
+    wb = query("rpnet_cosine_match_bwd_workspace_bytes", B, K, h * w, Fc)
+    ws = torch.empty(wb // 4 + 4, device=DEV)
+    call("rpnet_cosine_match_bwd", ptr(z0), ptr(proto), ptr(dpred), ptr(df0), ptr(dp0), B, K, h * w, Fc, 20.0, 0, ptr(ws), wb)
+    assert torch.equal(z1.grad, df0)
+    assert rel_err(pg.grad, dp0) < 2e-6
+    # --- the A/B switch: the separate path through the same Function
+    RF._GLUE_FUSE = False
+    try:
+        l3, p3 = RF.CosineMatchUp.apply(z0, proto, H, W, 20.0)
+    finally:
+        RF._GLUE_FUSE = True
+    assert torch.equal(l3, logits0) and torch.equal(p3, pred0)
+
+
 def test_dice_ce_golden(RF, golden):
     g = golden("ops")
     lg = torch.from_numpy(g["dce_logits"]).to(DEV).requires_grad_(True)

@@ -26,7 +26,9 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in rpnet_abi.h but not exported"
     assert declared == set(hip.ABI_SYMBOLS), declared ^ set(hip.ABI_SYMBOLS)
     lib.rpnet_version.restype = ctypes.c_int
-    assert lib.rpnet_version() >= 100                      # no compute call without a GPU
+    from rpnet_amd import hip as _hip
+    hdr = open(os.path.join(ROOT, "include", "rpnet_abi.h")).read()
+    assert lib.rpnet_version() == _hip.ABI_VERSION == int(re.search(r"#define RPNET_ABI_VERSION (\d+)", hdr).group(1))   # no compute call without a GPU
 
 
 def test_module_surface_and_state_dict():
