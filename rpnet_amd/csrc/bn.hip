@@ -475,7 +475,11 @@ struct PoolGeom {
 };
 
 // thread = one pooled pixel x 8 channels; planes [NP][N, Ho, Wo, C] of relu(max) / s (and the fp32 pooled tensor when zp != NULL)
-template <int NP>
+// DRAIN: as bn_bwd_apply_pool_split below — every load of a half waited for with a full `s_waitcnt vmcnt(0)` before any of its
+// values is read.  Round 4 found wrong 2 x 2 window decisions in the backward form of this pass when it shared its CUs with other
+// kernels of the step; nobody has seen THIS pass fail, but it makes the same decisions from the same loads on the same streams, so
+// until the mechanism is known it runs with the same two guards (the wait, and the LDS reservation of the launch).
+template <int NP, bool DRAIN = false>
 __global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const YSrc ysrc, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, float* __restrict__ zp,
                                                                   unsigned short* __restrict__ zs, size_t total8, int C8,
@@ -506,11 +510,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const YSrc ysrc
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int cc = c8 * 8 + hh * 4;
-            const f32x4 a = load_y4(ysrc, src + hh * 4, cc);
-            const f32x4 b = load_y4(ysrc, src + C8 * 8 + hh * 4, cc);
-            const f32x4 c = load_y4(ysrc, src + rowC + hh * 4, cc);
-            const f32x4 d = load_y4(ysrc, src + rowC + C8 * 8 + hh * 4, cc);
-            const f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
+            f32x4 a = load_y4(ysrc, src + hh * 4, cc);
+            f32x4 b = load_y4(ysrc, src + C8 * 8 + hh * 4, cc);
+            f32x4 c = load_y4(ysrc, src + rowC + hh * 4, cc);
+            f32x4 d = load_y4(ysrc, src + rowC + C8 * 8 + hh * 4, cc);
+            f32x4 s4 = reinterpret_cast<const f32x4*>(sc)[hh], h4 = reinterpret_cast<const f32x4*>(sh)[hh];
+            if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(s4), "+v"(h4) : : "memory");
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -601,6 +606,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
 
 // thread = one pooled pixel x 8 channels: the four dy of its window (planes at full resolution, fp32 too when dy != NULL)
 //
+// (Round 5 on the diagnosis below: the trigger is NOT specific to the LDS-DMA weight-gradient kernel — with both guards off and
+// RPNET_BN_LDS=big the two-chain schedule WITHOUT a weight-gradient side stream still differs in 8 of 8 steps
+// (profiles/r05_pool_fault_repro.txt); the stand-alone pair of this pass and one weight-gradient launch does not reproduce it
+// (0 of 400), and a probe that reads element 1 of a 16-byte load in the instruction behind its counted wait, beside an LDS-DMA
+// streaming kernel, sees no stale value in 6.7e9 reads (tools/probe/vmcnt_probe.cpp).  What is established stays: the symptom, that the
+// two guards remove it in every schedule tried, and the tests that would show it again.)
 // DRAIN (round 4): every load of a half is waited for with `s_waitcnt vmcnt(0)` BEFORE any of its values is read (the asm
 // statement ties the loaded registers, so the compiler can make no early copy).  Without it hipcc issues the 18 loads of an
 // iteration back to back and reads them behind counted waits (vmcnt(17), vmcnt(16), ...), which is correct while loads
@@ -689,6 +700,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __re
     }
 }
 
+// LDS bytes the pooled passes reserve WITHOUT using them (RPNET_BN_POOL_ALONE: unset / 1 = 53248, 0 = none, n > 1 = n bytes), so
+// that their blocks never share a CU with a block of an LDS-DMA kernel.  Round 4 reserved 24 KB, enough against the 144 - 156 KB
+// blocks of the weight-gradient and 128-wide convolution kernels; the 64-wide convolution forms (116 - 120 KB) and the collapsed
+// up_conv weight gradient (112 KB) would still have fitted beside such a block.  52 KB excludes every LDS-DMA kernel the training
+// step launches (the smallest, 112 KB: 114688 + 53248 > 163840) and still leaves three blocks = twelve waves of the pass per CU.
+static size_t pool_alone_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("RPNET_BN_POOL_ALONE");
+        if (!e || !e[0]) return (size_t)53248;
+        const long n = atol(e);
+        return n <= 0 ? (size_t)0 : (n == 1 ? (size_t)53248 : (size_t)n);
+    }();
+    return v;
+}
+
 static int elt_grid(size_t total4) {
     size_t b = (total4 + 255) / 256;
     return (int)(b > 2048 * 4 ? 2048 * 4 : (b < 1 ? 1 : b));
@@ -773,9 +799,14 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
         const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * (HW / 4) * C;
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
+        // the guards of the pooled passes (see bn_bwd_apply_pool_split): LDS reservation of the launch, full wait in the kernel
+        const size_t alone_f = pool_alone_bytes();
+        static const bool drain_f = [] { const char* e = getenv("RPNET_BN_POOL_DRAIN"); return !(e && e[0] == '0'); }();
 #define RPNET_BN_POOL(NP_)                                                                                                  \
-    hipLaunchKernelGGL(bn_relu_pool_split_kernel<NP_>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale, shift, z, \
-                       (unsigned short*)z_split, total8, C / 8, pg, pe, gamma, beta, sqrt_n, split_scale)
+    do { if (drain_f) hipLaunchKernelGGL((bn_relu_pool_split_kernel<NP_, true>), dim3(elt_grid(total8)), dim3(256), alone_f, (hipStream_t)stream, ysrc, scale, shift, z, \
+                       (unsigned short*)z_split, total8, C / 8, pg, pe, gamma, beta, sqrt_n, split_scale);                  \
+    else hipLaunchKernelGGL((bn_relu_pool_split_kernel<NP_, false>), dim3(elt_grid(total8)), dim3(256), alone_f, (hipStream_t)stream, ysrc, scale, shift, z, \
+                       (unsigned short*)z_split, total8, C / 8, pg, pe, gamma, beta, sqrt_n, split_scale); } while (0)
         if (planes == 3) RPNET_BN_POOL(3);
         else if (planes == 2) RPNET_BN_POOL(2);
         else RPNET_BN_POOL(1);
@@ -848,9 +879,9 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
         const long Rp = R / 4;
         const BnGeom gp = bn_geom(Rp, C);
-        // RPNET_BN_POOL_ALONE (default 1): the two pooled passes reserve 24 KB of LDS they do not use, so that their blocks never
-        // share a CU with a block of the LDS-DMA GEMM kernels (147 - 156 of 160 KB) — see bn_bwd_apply_pool_split
-        static const size_t alone = [] { const char* e = getenv("RPNET_BN_POOL_ALONE"); return (e && e[0] == '0') ? (size_t)0 : (size_t)24576; }();
+        // RPNET_BN_POOL_ALONE (default on): the pooled passes reserve LDS they do not use, so that their blocks never share a CU with
+        // a block of an LDS-DMA kernel (pool_alone_bytes) — see bn_bwd_apply_pool_split
+        const size_t alone = pool_alone_bytes();
         if (bn_lds_window() == 64)
             hipLaunchKernelGGL(bn_bwd_partial_pool<64>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);

@@ -1,12 +1,15 @@
 """GPU parity, model level: rpnet_amd.RP_Net (HIP path) against the golden vectors the
 reference produced (tests/golden/*.npz) and against the CPU oracle on the same seeded
 inputs; full-size runs are checked through size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from tests.helpers import episode_tensors, in_checksum, load_cfg, rel_err, rel_l2
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-3   # BASELINE.json north_star: outputs within 1e-3 relative fp32
@@ -668,6 +671,91 @@ def test_encoder_two_chains_match_one_stream(async_wgrad, math, prepack):
             assert torch.equal(g, other[1][n]), n
         for n, b in res[0][2].items():
             assert torch.equal(b, other[2][n]), n
+
+
+@pytest.mark.parametrize("name,size,B,T,ways,math,repeats", [("configs[1]", 256, 8, 5, 1, "f16x2", 30), ("configs[4]", 512, 4, 10, 2, "f16", 10)])
+def test_default_schedule_repeats_bit_for_bit(name, size, B, T, ways, math, repeats):
+    """The canary of round 4's pooled-pass fault (profiles/r04_pool_apply_fault.txt: in roughly one step of four a pooled
+    BatchNorm-backward pass that shared its CUs with an LDS-DMA weight-gradient block put gradients on the wrong pixel of their
+    2 x 2 window — silently; only a flaky small test gave it away).  The DEFAULT schedule of the benched step — weight gradients
+    on their side stream released behind their layer's dgrad, the CRE's second branch on its own stream, (configs[4]) the
+    encoder's two calls as two chains — at the benched size, `repeats` times: every gradient and every BatchNorm buffer of
+    every repeat must have the bits of the SAME step run on one stream.  Same kernels, same order per buffer: any difference
+    is a race or a hardware-visible hazard between co-resident kernels, and any new pass / tile variant / LDS change that
+    brings one back fails here."""
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    from rpnet_amd.parallel import FlatGradBucket
+    cfg = load_cfg(T)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(77, B, size, DEV, n_shots=1, n_ways=ways)
+    RF.set_conv_math(math)
+    was = (RM._ENC_STREAMS, RM._CRE_STREAMS_TRAIN, RF._MASK_SKIP)
+    net = build(cfg, True)
+    bucket = FlatGradBucket(net)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+
+    dev = torch.device(DEV)
+    side_keys = (dev, ("reduce", dev), ("cre", dev), ("pack", dev))
+
+    def one(multi_stream):
+        net.load_state_dict(state0)          # the running statistics back to the start: every step sees the same state
+        # the SAME code path both times (weight gradients accumulated by their kernels straight into the bucket); the one-stream
+        # reference aliases every side stream to the caller's stream, so that the launches run one after the other in issue order
+        RF.set_async_wgrad(True)
+        saved = {k: RF._ASYNC["side"].pop(k, None) for k in side_keys}
+        if not multi_stream:
+            for k in side_keys:
+                RF._ASYNC["side"][k] = torch.cuda.current_stream(dev)
+        else:
+            RF._ASYNC["side"].update({k: v for k, v in saved.items() if v is not None})
+        RM._CRE_STREAMS_TRAIN = was[1] if multi_stream else False
+        RM._ENC_STREAMS = was[0] if multi_stream else 0
+        bucket.zero()
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        total_loss(out, ql, 1.0).backward()
+        bucket.allreduce()
+        torch.cuda.synchronize()
+        if not multi_stream:
+            for k in side_keys:
+                RF._ASYNC["side"].pop(k, None)
+            RF._ASYNC["side"].update({k: v for k, v in saved.items() if v is not None})
+        return bucket.flat.clone(), {n: b.clone() for n, b in net.named_buffers()}, out["output"].detach().clone()
+
+    try:
+        ref_flat, ref_buf, ref_out = one(False)
+        assert torch.isfinite(ref_flat).all() and float(ref_flat.abs().max()) > 0
+        bad = []
+        for r in range(repeats):
+            flat, buf, out = one(True)
+            if not torch.equal(flat, ref_flat):
+                nd = int((flat != ref_flat).sum())
+                where = [n for n, p in net.named_parameters() if p.grad is not None and not torch.equal(p.grad, p.grad)]   # (NaN check)
+                bad.append((r, nd, float((flat - ref_flat).abs().max()), where))
+            assert torch.equal(out, ref_out), (name, r, "logits")
+            for n in ref_buf:
+                assert torch.equal(buf[n], ref_buf[n]), (name, r, n)
+        assert not bad, f"{name}: {len(bad)} of {repeats} multi-stream steps differ from the one-stream step: {bad[:5]}"
+    finally:
+        RM._ENC_STREAMS, RM._CRE_STREAMS_TRAIN, RF._MASK_SKIP = was
+        RF.set_async_wgrad(False)
+
+
+def test_pooled_pass_guards_hold_where_the_fault_was_most_frequent():
+    """tools/canary_two_chains.py in its own process (the switches are read once per process): the configuration in which the
+    pooled BatchNorm-backward fault showed in 8 of 8 steps WITHOUT the guards — two encoder chains on two streams, the large LDS
+    form of the BatchNorm reductions (RPNET_BN_LDS=big) — with the library's guards ON (RPNET_BN_POOL_DRAIN / RPNET_BN_POOL_ALONE,
+    csrc/bn.hip): every repeat must have the bits of the first run.  (profiles/r05_pool_fault_repro.txt has the same command with
+    the guards off, the stand-alone kernel pair, and the load-return probe.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RPNET_BN_POOL_DRAIN", "RPNET_BN_POOL_ALONE")}
+    env["RPNET_BN_LDS"] = "big"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "canary_two_chains.py"), "12"], capture_output=True, text=True, env=env,
+                       cwd=ROOT, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if "repeats differ" in ln]
+    assert r.returncode == 0 and len(lines) == 2, r.stdout[-2000:] + r.stderr[-2000:]
+    for ln in lines:
+        assert ": 0 of 12 repeats differ" in ln, ln
 
 
 @pytest.mark.parametrize("async_wgrad,math", [(True, "f16x2"), (False, "f16x2"), (True, "bf16x3")])
