@@ -54,7 +54,9 @@ struct PatchRowsUp {   // pixel (ty, tx) of a low-resolution patch -> high-resol
 
 // Kc: GEMM K channels (forward: Cin; input gradient: 4 x the layer's Cout), Ncols: GEMM columns (forward: 4 x Cout; input
 // gradient: the layer's Cin).  d.N, d.H, d.W: the HIGH-resolution tensor (the layer's output / its gradient).
-template <int TW, int WN, bool DG>
+// K64: ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]) in the same LDS geometry, as in conv_split_dma.hip: a K-step is one tap
+// of 64 channels whose two 32-channel halves take the places of the two planes; the products are the diagonal ones.
+template <int TW, int WN, bool DG, bool K64 = false>
 __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_desc d, const int Kc, const int Ncols, const int tiles_n,
                                                                const int ntiles) {
     constexpr int NP = 2, WM = 4;
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     const int fphase = DG ? 0 : n0 / Cout_out;
     const int fpy = fphase >> 1, fpx = fphase & 1;
 
-    const int kchunks = Kc >> 5;
+    constexpr int CSH = K64 ? 6 : 5;               // channels per K-step: 64 (one plane, two halves) or 32 (per plane)
+    const int kchunks = Kc >> CSH;
     const int rot = (int)(blockIdx.x % (unsigned)kchunks);
-    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << 5; };
+    auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << CSH; };
     // tap base (Py, Px) of a chunk: the 3x3 index of its tap slot (r, c) is (Py + r, Px + c)
     auto chunk_py = [&](int c0) { return DG ? 1 - ((c0 / C0) >> 1) : fpy; };
     auto chunk_px = [&](int c0) { return DG ? 1 - ((c0 / C0) & 1) : fpx; };
@@ -101,8 +104,11 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     const unsigned short* x0p = reinterpret_cast<const unsigned short*>(d.x0);
     const unsigned short* wq = reinterpret_cast<const unsigned short*>(d.w);
     const int pb0 = (int)(plane0 * 2), pbw = (int)(planew * 2);
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p), (short)0, NP * pb0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), (short)0, NP * pbw, 0x00020000);
+    constexpr int NPM = K64 ? 1 : NP;              // planes in memory
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x0p), (short)0, NPM * pb0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), (short)0, NPM * pbw, 0x00020000);
+    // offset of plane / half p inside the source and inside the weights (K64: the next 32 channels of a pixel / the next weight slab)
+    const int ps0 = K64 ? 64 : pb0, psw = K64 ? Ncols * 64 : pbw;
 
     const int drow = lane >> 2;
     const int dkg16 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + p * A_BYTES + hpos[i] * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, cs * 2 + p * pb0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, cs * 2 + p * ps0, 0, 0);
         }
     };
     const int wvoff = (16 * WN * wv + drow) * 64 + dkg16;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
 #pragma unroll
             for (int q = 0; q < WN; ++q) {
                 auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * psw, 0, 0);
             }
     };
 
@@ -174,13 +180,13 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
             aaddr[i] = hr * 64 + 16 * (h ^ ((hr >> 2) & 3));
         }
     };
-    constexpr int NPROD = nprod<NP>();
+    constexpr int NPROD = K64 ? 2 : nprod<NP>();
     constexpr int NR = NP * (WM + WN), NMMA = NPROD * WM * WN;
     static_assert(NR <= NMMA, "one fragment read of the next slice behind each MFMA of this one");
     auto read_frag = [&](auto sc, auto kc, const int abase, const int bbase) {
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
         constexpr int grp = k / (WM + WN), r = k - grp * (WM + WN);
-        constexpr int pa = NP - 1 - grp, pb = grp;
+        constexpr int pa = K64 ? grp : NP - 1 - grp, pb = grp;
         if constexpr (r == 0 || r > WN) {
             constexpr int i = r == 0 ? 0 : r - WN;
             af[s][pa][i] = *reinterpret_cast<const bf16x8*>(smem + abase + (aaddr[i] ^ (32 * s)) + pa * A_BYTES);
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     auto mma_one = [&](auto sc, auto mc) {
         constexpr int s = decltype(sc)::value, m = decltype(mc)::value;
         constexpr int q = m / (WM * WN), ij = m - q * (WM * WN), i = ij / WN, j = ij - i * WN;
-        constexpr int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
+        constexpr int pa = K64 ? q : prod_a<NP>(q), pb = K64 ? q : prod_b<NP>(q);
         acc[i][j] = mma16<NP>(af[s][pa][i], bfr[s][pb][j], acc[i][j]);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     auto dma_w_one = [&](auto ec, const int wsoff, const int stage) {
         constexpr int e = decltype(ec)::value, p = e / WN, q = e - p * WN;
         auto* dst = (__attribute__((address_space(3))) void*)(smem + WOFF + stage * STAGE + p * B_BYTES + (16 * WN * wv + 16 * q) * 64);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * pbw, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff + q * 1024, wsoff + p * psw, 0, 0);
     };
 
     // ---- prologue: halo of chunk 0, weight slabs of steps 0, 1, 2
@@ -329,17 +335,19 @@ static int up4_tw(int Hl, int Wl) {
 
 // wn (1 / 2) of the launch, or 0 when the shapes do not fit (mode 1: forward, 2: input gradient)
 static int up4_plan(const rpnet_conv_desc* d, int mode, int* tw, int* Kc, int* Ncols) {
-    if (!d || d->split_planes != 2 || d->H % 2 || d->W % 2 || d->C1 || d->Co1 || d->x1 || d->y1) return 0;
+    if (!d || (d->split_planes != 2 && d->split_planes != 1) || d->H % 2 || d->W % 2 || d->C1 || d->Co1 || d->x1 || d->y1) return 0;
     const int Hl = d->H / 2, Wl = d->W / 2;
+    const bool one = d->split_planes == 1;              // one fp16 plane: 64-channel K-steps, 128-wide tiles only
     *tw = up4_tw(Hl, Wl);
-    if (!*tw || d->C0 % 32 || d->Co0 % 64) return 0;
+    if (!*tw || d->C0 % (one ? 64 : 32) || d->Co0 % (one ? 128 : 64)) return 0;
     *Kc = mode == 1 ? d->C0 : 4 * d->C0;
     *Ncols = mode == 1 ? 4 * d->Co0 : d->Co0;
     const size_t lim = (size_t)1 << 31;
-    const size_t src = (size_t)d->N * (mode == 1 ? Hl * Wl : d->H * d->W) * d->C0 * 2 * 2;
+    const size_t src = (size_t)d->N * (mode == 1 ? Hl * Wl : d->H * d->W) * d->C0 * 2 * d->split_planes;
     if (src >= lim || (size_t)2 * 4 * *Kc * *Ncols * 2 >= lim || (size_t)d->N * d->H * d->W >= lim) return 0;
     const long tiles_m = (long)d->N * Hl * Wl / 256;
     if (mode == 1) return (d->Co0 % 128 == 0) ? 2 : 1;       // a column tile never straddles two phases
+    if (one) return 2;
     return (*Ncols % 128 == 0 && tiles_m * (*Ncols / 128) >= 192) ? 2 : 1;
 }
 
@@ -378,7 +386,11 @@ extern "C" int rpnet_conv_up4(const rpnet_conv_desc* d, int mode, rpnet_stream_t
     const int tiles_m = d->N * (d->H / 2) * (d->W / 2) / 256, tiles_n = Nc / (64 * wn), ntiles = tiles_m * tiles_n;
     hipStream_t s = (hipStream_t)stream;
 #define RPNET_UP4(TWV, WNV, DGV) hipLaunchKernelGGL((conv_up4_dma_kernel<TWV, WNV, DGV>), dim3(ntiles), dim3(256), 0, s, *d, Kc, Nc, tiles_n, ntiles)
-    if (mode == 1) {
+#define RPNET_UP4K(TWV, DGV) hipLaunchKernelGGL((conv_up4_dma_kernel<TWV, 2, DGV, true>), dim3(ntiles), dim3(256), 0, s, *d, Kc, Nc, tiles_n, ntiles)
+    if (d->split_planes == 1) {
+        if (mode == 1) { if (tw == 32) RPNET_UP4K(32, false); else RPNET_UP4K(16, false); }
+        else { if (tw == 32) RPNET_UP4K(32, true); else RPNET_UP4K(16, true); }
+    } else if (mode == 1) {
         if (tw == 32) { if (wn == 2) RPNET_UP4(32, 2, false); else RPNET_UP4(32, 1, false); }
         else { if (wn == 2) RPNET_UP4(16, 2, false); else RPNET_UP4(16, 1, false); }
     } else {
@@ -386,5 +398,6 @@ extern "C" int rpnet_conv_up4(const rpnet_conv_desc* d, int mode, rpnet_stream_t
         else { if (wn == 2) RPNET_UP4(16, 2, true); else RPNET_UP4(16, 1, true); }
     }
 #undef RPNET_UP4
+#undef RPNET_UP4K
     return check_launch("conv_up4");
 }

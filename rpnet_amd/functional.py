@@ -284,11 +284,11 @@ def _cup4(d, mode):
 def _up4_ok(pw, planes, upsample, x1, in_scale, xs0, N, H, W, cout):
     """does this launch take the collapsed form of an up_conv layer (see _UP4): two fp16 planes, a single unmasked source, a
     plain 3x3 layer whose shapes fit the kernel"""
-    if not (_UP4 and upsample and planes == 2 and x1 is None and in_scale is None and pw is not None and pw.taps == 9
+    if not (_UP4 and upsample and planes in (1, 2) and x1 is None and in_scale is None and pw is not None and pw.taps == 9
             and pw.cin_pad == pw.cin and pw.cin % 32 == 0 and cout % 64 == 0):
         return False
     probe = ConvDesc()
-    probe.N, probe.H, probe.W, probe.C0, probe.Co0, probe.split_planes = N, H, W, pw.cin, cout, 2
+    probe.N, probe.H, probe.W, probe.C0, probe.Co0, probe.split_planes = N, H, W, pw.cin, cout, planes
     probe.x0, probe.y0 = ptr(xs0), ptr(xs0)
     return bool(query("rpnet_conv_up4_supported", C.byref(probe), 1))
 
@@ -825,7 +825,7 @@ class WeightCache:
         up4: the weights among them that belong to up_conv layers (nn.Upsample -> Conv2d): on two fp16 planes their forward and
         input gradient run on the COLLAPSED four-tap pack (PackedWeight.up4_packs, see _UP4), which is made here instead of
         the nine-tap pack (a launch that falls back to the nine-tap form packs it on first use)."""
-        up4 = list(up4) if (_UP4 and planes == 2) else []
+        up4 = list(up4) if (_UP4 and planes in (1, 2)) else []
         if up4:
             skip = {id(w) for w in up4}
             weights = [w for w in weights if id(w) not in skip]
@@ -1028,7 +1028,7 @@ class ConvBnRelu(Function):
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
-            if ycode is not None and (not fused or d.split_planes != 1):
+            if ycode is not None and (not fused or d.split_planes != 1 or up4):
                 ycode = None          # the separate statistics pass (rpnet_bn_stats) reads fp32: this layer keeps its fp32 tensor
                 y = _empty((N, H, W, cout), x0)
                 d.y0 = ptr(y)
@@ -1280,7 +1280,7 @@ class ConvBnRelu(Function):
                 c0, c1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
                 # dgrad = the same implicit GEMM on dy with the flipped/transposed weight pack
                 need_s = in_scale is not None and ctx.needs_input_grad[2]   # soft_mask: the mask is differentiable
-                up4 = bool(getattr(ctx, "up4", False)) and dsplit and np_ == 2
+                up4 = bool(getattr(ctx, "up4", False)) and dsplit and np_ in (1, 2)
                 if up4:
                     # the collapsed up_conv: the input gradient comes out at the SOURCE resolution (the 2 x 2 sum is in the launch)
                     pk4 = pw.up4_packs(np_)

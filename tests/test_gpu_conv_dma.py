@@ -359,6 +359,60 @@ UP4_CASES = [
 ]
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout", [UP4_CASES[0], UP4_CASES[2], UP4_CASES[5]])
+def test_upconv_collapsed_kernels_one_plane(RF, N, H, W, cin, cout):
+    """the same forward / input-gradient kernels on ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]; 64-channel K-steps):
+    against the nine-product one-plane kernels to 1e-3 of the tensor's maximum (both round their operands to fp16; the collapsed
+    weights are rounded AFTER the taps are added) and against float64 to 1e-2 (fp16 operands: 11 significand bits)"""
+    from rpnet_amd.hip import call, ptr, query
+    g = torch.Generator().manual_seed(78)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_((torch.rand(conv.weight.shape, generator=g) - 0.5) * (2.0 / (cin * 9) ** 0.5))
+        conv.bias.copy_((torch.rand(cout, generator=g) - 0.5) * 0.2)
+    a, go = rnd(292, N, cin, H // 2, W // 2), rnd(294, N, cout, H, W)
+    cr = copy.deepcopy(conv).double()
+    ar = a.double().requires_grad_(True)
+    yr = cr(F.interpolate(ar, scale_factor=2, mode="nearest"))
+    yr.backward(go.double())
+    w, b = conv.weight.detach().to(DEV), conv.bias.detach().to(DEV)
+    sx = torch.tensor([2.0 ** -13], device=DEV)
+    xs = RF.split_f16(nhwc(a).to(DEV), sx, want_scale=False, planes=1)[0]
+    dys = RF.split_f16(nhwc(go).to(DEV), sx, want_scale=False, planes=1)[0]
+    pw = RF.PackedWeight(w)
+    wp9, wd9, t9, u9 = pw.split_packs(1)
+    wp4, wd4, t4, u4 = pw.up4_packs(1)
+    out = {}
+    for up4 in (True, False):
+        y = torch.empty(N, H, W, cout, device=DEV)
+        d = RF._desc(xs, None, wp4 if up4 else wp9, b, None, 0, y, None, N, H, W, 9, 1)
+        d.split_planes = 1
+        d.acc_scale_col, d.acc_scale_x = ptr(t4 if up4 else t9), ptr(sx)
+        if up4:
+            assert query("rpnet_conv_up4_supported", C.byref(d), 1)
+            call("rpnet_conv_up4", C.byref(d), 1)
+        else:
+            call("rpnet_conv_fwd", C.byref(d))
+        if up4:
+            dx = torch.empty(N, H // 2, W // 2, cin, device=DEV)
+            dd = RF._desc(dys, None, wd4, None, None, 0, dx, None, N, H, W, 9, 1)
+            dd.split_planes = 1
+            dd.acc_scale_col, dd.acc_scale_x = ptr(u4), ptr(sx)
+            assert query("rpnet_conv_up4_supported", C.byref(dd), 2)
+            call("rpnet_conv_up4", C.byref(dd), 2)
+        else:
+            gh = torch.empty(N, H, W, cin, device=DEV)
+            dd = RF._desc(dys, None, wd9, None, None, 0, gh, None, N, H, W, 9, 0)
+            dd.split_planes = 1
+            dd.acc_scale_col, dd.acc_scale_x = ptr(u9), ptr(sx)
+            call("rpnet_conv_fwd", C.byref(dd))
+            dx = torch.empty(N, H // 2, W // 2, cin, device=DEV)
+            call("rpnet_upsample2_bwd", ptr(gh), ptr(dx), N, H, W, cin)
+        out[up4] = (y, dx)
+    assert rel_err(out[True][0], out[False][0]) < 1e-3 and rel_err(out[True][1], out[False][1]) < 1e-3
+    assert rel_err(nchw(out[True][0]), yr) < 1e-2 and rel_err(nchw(out[True][1]), ar.grad) < 1e-2
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout", UP4_CASES)
 def test_upconv_collapsed_kernels_against_nine_tap_form_and_fp64(RF, N, H, W, cin, cout):
     """rpnet_conv_up4 (csrc/conv_up4_dma.hip) through the C ABI, without a BatchNorm behind it (no ReLU decisions that a 1e-7
