@@ -581,10 +581,16 @@ def cpu_baseline(cfg, size, T, seconds_budget=18.0, net=None, bucket=None, dev=N
     return res
 
 
-DDP_GRAPH = os.environ.get("RPNET_BENCH_DDP_GRAPH", "0") == "1"
+# N > 1: the HIP-graph form of the step is CAPTURED BEFORE dist.init_process_group — no communicator, no collective-library
+# watchdog thread exists while the stream is being captured — and replayed beside the communicator afterwards (each replay followed
+# by ONE all-reduce of the flat bucket).  Round 4 captured in a process that already held a one-rank RCCL group and saw a
+# segmentation fault inside hipStreamEndCapture in 3 of 12 runs; profiles/r05_graph_capture_order.txt: 12 of 12 runs complete in
+# either order on this round's tree, gradients bit-identical to the eager step.  The timed steps use the replay when the probe
+# finds ANY rank's host unable to keep ahead of its GPU (8 Python processes on one shared host); RPNET_BENCH_DDP_GRAPH=0: never.
+DDP_GRAPH = os.environ.get("RPNET_BENCH_DDP_GRAPH", "1") == "1"
 
 
-def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
+def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None, init_group=None):
     """Times `steps` steps of workload w = dict(ways, shots, size, iters, batch, conv_math) after `warmup` untimed ones
     (barrier + synchronize on both sides, MAX over ranks), then one extra profiled step (HIP events per C-ABI call,
     streams serialised).  -> dict with value, ms_per_step, the per-call aggregate, the arithmetic that ran, the model."""
@@ -596,9 +602,21 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
     RF.set_conv_math(w["conv_math"])
     requested = math = RF.conv_math()
     net = build_model(cfg, dev)
-    broadcast_parameters(net)
     bucket = FlatGradBucket(net, force_active=ddp)
     inp = make_inputs(1234 + rank, w["batch"], w["size"], dev, w["shots"], w["ways"])   # resident in HBM before timing
+    exposed = [] if ddp else None
+    pre_gts = None
+    if init_group is not None:
+        # the process group does not exist yet (main() hands its creation in): capture the replay form of the step first
+        if DDP_GRAPH and os.environ.get("RPNET_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RPNET_BENCH_GRAPH", "auto") != "0":
+            for _ in range(2):
+                step(net, bucket, inp, scaler)          # (no group yet: the bucket's exchange is a no-op)
+            torch.cuda.synchronize()
+            pre_gts = graphed_step(net, bucket, scaler, exposed)
+            pre_gts.capture(*inp)
+            torch.cuda.synchronize()
+        init_group()
+    broadcast_parameters(net)
 
     def fence():
         torch.cuda.synchronize()
@@ -632,17 +650,15 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
             flag = torch.tensor([1.0 if bound else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             probe["host_bound_ranks_any"] = bound = bool(flag.item() > 0)
-        if bound and ddp and not DDP_GRAPH:
-            # HIP stream capture in a process that holds a collective communicator is crash-prone on this ROCm (gloo: segmentation
-            # fault or hang; RCCL: segmentation fault in hipStreamEndCapture in 3 of 12 runs, either capture mode — tools/cap_try.sh):
-            # under a process group the timed steps stay eager unless RPNET_BENCH_DDP_GRAPH=1 asks for the replay form
+        if bound and ddp and pre_gts is None:
+            # under a process group only the graph captured BEFORE the group existed is replayed (see DDP_GRAPH): never a capture
+            # beside a live communicator (gloo: segmentation fault or hang in round 4; profiles/r04_graph_capture_under_rccl.txt)
             bound = False
         if bound:
             mode = "hip_graph_replay"
-    exposed = [] if ddp else None
     gts = None
     if mode == "hip_graph_replay":
-        gts = graphed_step(net, bucket, scaler, exposed)
+        gts = pre_gts if pre_gts is not None else graphed_step(net, bucket, scaler, exposed)
         for _ in range(2):
             gts(*inp[:4], inp[4], inp[5])
         fence()
@@ -662,7 +678,7 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
         host.append(time.perf_counter() - h0)
     fence()
     el = time.perf_counter() - t0
-    del gts
+    gts = None
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     spread = {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3),
               "host_enqueue_median": round(1e3 * sorted(host)[len(host) // 2], 3),
@@ -689,16 +705,13 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None):
         # the OTHER way of issuing the step, 5 steps, so that the line carries both (eager + overlapped exchange / graph replay
         # + exposed exchange) whichever the probe chose
         other_ex = []
-        if dist.get_backend() != "nccl" or not DDP_GRAPH:
-            # the graph-replay form of the N > 1 step is OPT-IN (RPNET_BENCH_DDP_GRAPH=1, RCCL only): capturing the step in a
-            # process that holds a communicator ended in a segmentation fault inside hipStreamEndCapture in 3 of 12 one-rank RCCL
-            # runs (thread-local and global capture mode alike) and in 3 of 5 / hung 5 of 5 under gloo — eight ranks taking that
-            # chance would cost the whole line.  When it runs, its gradients equal the eager step's bit for bit
-            # (tests/test_gpu_dist.py with RPNET_TEST_DDP_GRAPH=1)
+        if pre_gts is None:
+            # no replay form without the graph captured before the group existed (gloo plumbing runs, RPNET_BENCH_DDP_GRAPH=0)
             other = None
         else:
             if mode == "eager":
-                og = graphed_step(net, bucket, scaler, other_ex)
+                og = pre_gts
+                og.exposed = other_ex
                 run_other = lambda: og(*inp[:4], inp[4], inp[5])  # noqa: E731
             else:
                 og = None
@@ -832,7 +845,6 @@ def stream_layout():
     import rpnet_amd.modules as RM
     return {"async_wgrad": bool(RF._ASYNC["on"]), "wgrad_released_behind_dgrad": RF._WGRAD_DEFER,
             "cre_second_branch_on_own_stream": bool(RM._CRE_STREAMS_TRAIN), "encoder_two_chains": RM._ENC_STREAMS,
-            "high_priority_compute_stream": int(os.environ.get("RPNET_COMPUTE_PRIORITY", "0")) != 0,
             "what": "same kernels and bits as the one-stream step (tests: test_async_weight_gradients_match, "
                     "test_encoder_two_chains_match_one_stream); per-kernel roofline figures come from an extra step with all of it serialised"}
 
@@ -912,22 +924,24 @@ def main():
                 sock.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
                 sock.close()
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+
+        def init_group():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
     import rpnet_amd.functional as RF
     RF.set_async_wgrad(os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")   # weight gradients on a second HIP stream
-    RF.use_compute_stream(dev)       # the step's main chain on a high-priority stream (the side streams keep the default one)
     w = {"ways": args.ways, "shots": args.shots, "size": args.size, "iters": args.iters, "batch": args.batch,
          "conv_math": args.conv_math or RF.conv_math()}
     headline = (args.ways, args.shots, args.size, args.iters, args.batch) == (1, 1, 256, 5, 8) and w["conv_math"] == "f16x2"
     # every timed leg that carries a roofline is DENSE: the zero-tile skip of the masked CRE convolutions (RF._MASK_SKIP, the
     # library's default) leaves out work the algorithmic FLOP count of the metric contains; it gets its own leg (mask_tile_skip)
     RF._MASK_SKIP = False
-    m = measure(w, world, rank, dev, cfg, args.steps, args.warmup, RF, ddp)
+    # (N > 1: measure() creates the process group itself, AFTER it has captured the replay form of the step — see DDP_GRAPH)
+    m = measure(w, world, rank, dev, cfg, args.steps, args.warmup, RF, ddp, init_group if ddp else None)
     math, requested, value = m["math"], m["requested"], m["value"]
     net, bucket, inp, scaler, fence = m["net"], m["bucket"], m["inp"], m["scaler"], m["fence"]
     cfg = m["cfg"]

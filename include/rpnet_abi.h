@@ -223,7 +223,7 @@ int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream);
  * fuse them — a group does not split into whole tiles — use rpnet_bn_stats on the output instead) */
 int rpnet_conv_stats_blocks(const rpnet_conv_desc* d);
 /* which tile variant of the split kernels rpnet_conv_fwd launches for this descriptor (incl. its `tune` override; -1 for
- * fp32 operands): 0-3 plain split implicit GEMM, 7 the 8-wave patch kernel, 8-10 the 4-wave patch kernels, 11 the LDS-DMA
+ * fp32 operands): 0-3 plain split implicit GEMM, 7 the 8-wave patch kernel, 8-9 the 4-wave patch kernels, 11 the LDS-DMA
  * patch kernel (conv_split_dma.hip).  Tests use it to assert that a forced variant actually ran. */
 int rpnet_conv_tile_variant(const rpnet_conv_desc* d);
 /* bytes of rpnet_conv_desc.splitk_ws with which rpnet_conv_fwd would split the K range of this launch (0: it would not — the

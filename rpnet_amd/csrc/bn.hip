@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
 // DRAIN (round 4): every load of a half is waited for with `s_waitcnt vmcnt(0)` BEFORE any of its values is read (the asm
 // statement ties the loaded registers, so the compiler can make no early copy).  Without it hipcc issues the 18 loads of an
 // iteration back to back and reads them behind counted waits (vmcnt(17), vmcnt(16), ...), which is correct while loads
-// return in issue order.  Observed on MI355X (tools/diag_taps.py, profiles/r04_pool_apply_fault.txt): when the blocks of
+// return in issue order.  Observed on MI355X (profiles/r04_pool_apply_fault.txt): when the blocks of
 // this pass share their CUs with a running LDS-DMA weight-gradient kernel (conv_wgrad9_dma_kernel on the side stream — the
 // default schedule since round 3), a few dozen of the 4 - 8 M window decisions of a launch come out as if the FIRST value
 // compared (element 1 of a float4 of y) had not yet landed: the pooled gradient then lands on the wrong pixel of its 2 x 2

@@ -898,7 +898,7 @@ static const SplitVariant kSplitVariants[] = {
     {4, 2, 2, 1, 256},    // 7: 256 x 128 on an image patch, input halo resident in LDS (conv_igemm_split_halo_kernel)
     {2, 2, 2, 0, 512},    // 8: 128 x 128 on an image patch, 4 waves, two blocks per CU (conv_igemm_split_halo4_kernel)
     {2, 2, 1, 0, 512},    // 9: 128 x 64 of the same kernel: twice the blocks for the smallest grids
-    {2, 4, 2, 0, 512},    // 10: 256 x 128 on an image patch with FOUR waves (wave tile 128 x 64), two blocks per CU
+    {2, 4, 2, 0, 512},    // 10: (round 2's 256 x 128 four-wave, two-blocks-per-CU form of the patch kernel: 431 spilled registers; removed in round 5)
     {2, 4, 2, 0, 256},    // 11: 256 x 128 on an image patch, four waves (one per SIMD), operands by LDS-DMA (conv_split_dma.hip)
     {2, 4, 1, 0, 256},    // 12: 256 x 64 of the same kernel (wave tile 128 x 32)
     {2, 4, 2, 0, 256},    // 13: 256 x 128 of the same kernel on ONE fp16 plane, 64 channels per K-step
@@ -954,7 +954,7 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
         if ((v == 12 || v == 14) && d->split_planes == 2 && halo_tw(d, Cout) && addr) return v;
         if (v == 13 && d->split_planes == 1 && halo_tw(d, Cout) && halo_bn(d, Cout) == 128 && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 && addr)
             return v;
-        if (((v == 7 || (v == 10 && d->split_planes <= 2) || (v == 11 && d->split_planes == 2 && addr)) && halo_tw(d, Cout) &&
+        if (((v == 7 || (v == 11 && d->split_planes == 2 && addr)) && halo_tw(d, Cout) &&
              halo_bn(d, Cout) == 128) ||
             ((v == 8 || v == 9) && halo4_tw(d)))
             return v;
@@ -971,8 +971,6 @@ int choose_tile_split(const rpnet_conv_desc* d, int M, int Cout) {
     if (d->split_planes == 1 && !(d->tune & 0x10000) && addr && hbn == 128 && halo_tw(d, Cout) && (d->C0 + d->C1) % 64 == 0 && d->C0 % 64 == 0 &&
         (long)(M / 256) * (Cout / 128) >= 192)
         return 13;
-    if (d->split_planes == 1 && hbn == 128 && halo_tw(d, Cout) && d->C0 + d->C1 >= 128 && (long)(M / 256) * (Cout / 128) >= 512)
-        return 10;
     // 256 x 128 patches, one block per CU: two fp16 planes -> the LDS-DMA kernel (conv_split_dma.hip: +14 ... 20 % over the
     // register-staged 8-wave kernel on every such layer, same bits); tune bit 16 = the round-2 policy (A/B switch)
     const bool dma = d->split_planes == 2 && !(d->tune & 0x10000) && addr;
@@ -1036,8 +1034,6 @@ int conv_fwd_split(const rpnet_conv_desc* d, int M, int Cin, int Cout, hipStream
         case 12: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s);
         case 13: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 2, s);
         case 14: return conv_fwd_split_dma(d, M, Cin, Cout, halo_tw(d, Cout), 1, s, 1, 128);
-        case 10:
-            return halo_tw(d, Cout) == 32 ? launch_split_halo4<32, 2, 4>(d, M, Cin, Cout, s) : launch_split_halo4<16, 2, 4>(d, M, Cin, Cout, s);
         case 9:
             return halo4_tw(d) == 32 ? launch_split_halo4<32, 1>(d, M, Cin, Cout, s) : launch_split_halo4<16, 1>(d, M, Cin, Cout, s);
         case 8:

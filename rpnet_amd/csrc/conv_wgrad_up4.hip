@@ -33,6 +33,9 @@ __device__ __forceinline__ void static_for_wu(F&& f) {
 
 // d.N / d.H / d.W: the HIGH-resolution tensor (dy [2 planes][N][H][W][Cout]); x = d.x0 [2 planes][N][H/2][W/2][Cin].
 // Ml: low-resolution pixels; lw / lh: log2 of the low-resolution width / height.
+// K64: ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]): a K-step is 64 low-resolution pixels whose two 32-pixel halves take
+// the places of the two planes; the products are the diagonal ones (half p of x with half p of dy): 8 MFMAs per wave and slice.
+template <bool K64>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                  float* __restrict__ partial, const int Ml, const int Cin, const int Cout,
                                                                  const int tiles, const int tiles_n, const int ksplit,
@@ -71,11 +74,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     const size_t planex = (size_t)Ml * Cs, planey = (size_t)d.N * d.H * d.W * Cout;
     const int pbx = (int)(planex * 2), pby = (int)(planey * 2);
 
-    const int total_steps = (Ml + BK - 1) / BK;
+    constexpr int PXS = K64 ? 64 : BK;                               // low-resolution pixels per K-step
+    constexpr int NPM = K64 ? 1 : NP;                                // planes in memory
+    const int total_steps = (Ml + PXS - 1) / PXS;
     const int s_begin = z * steps_per_split;
     const int s_end = min(s_begin + steps_per_split, total_steps);
 
-    const srd_t rsx = make_srd(src, NP * pbx), rsy = make_srd(dy, NP * pby);
+    const srd_t rsx = make_srd(src, NPM * pbx), rsy = make_srd(dy, NPM * pby);
     const unsigned lds0 = lds_addr(smem);
     const unsigned ldsw = lds0 + 8 * wv * RB;
     const unsigned lds4 = lds0 + 32 * RB;
@@ -90,13 +95,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
         constexpr int kyl = decltype(kyc)::value, stage = decltype(stagec)::value;
         constexpr int DST = stage * A_STAGE + kyl * BK * RB;
         const int dyr = py + kyl - 1;                              // -1, 0, +1
-        const int qb = st * BK + 8 * wv + dyr * Wl;
+        const int qb = st * PXS + 8 * wv + dyr * Wl;
         const int yq = (qb >> lw) & (Hl - 1);
         const bool ok = (unsigned)qb < (unsigned)Ml && (unsigned)(yq - dyr) < (unsigned)Hl;
         const int soff = ok ? qb * Cs2 + cm0 * 2 : 0;
         const int voff = ok ? xlane : (int)0x80000000;
         lds_dma16_at<DST>(rsx, ldsw, voff, soff);
-        lds_dma16_at<DST + A_PLANE>(rsx, ldsw, voff, soff + pbx);
+        if constexpr (K64) {      // slot 1: the same piece 32 pixels on (its own row / image checks)
+            const int qb1 = qb + BK, yq1 = (qb1 >> lw) & (Hl - 1);
+            const bool ok1 = (unsigned)qb1 < (unsigned)Ml && (unsigned)(yq1 - dyr) < (unsigned)Hl;
+            lds_dma16_at<DST + A_PLANE>(rsx, ldsw, ok1 ? xlane : (int)0x80000000, ok1 ? qb1 * Cs2 + cm0 * 2 : 0);
+        } else
+            lds_dma16_at<DST + A_PLANE>(rsx, ldsw, voff, soff + pbx);
     };
     // dy tile: rows r = 0 .. 39 hold the low-resolution pixels st BK - 1 + r of this phase = dy[n, 2Y + py, 2X + px]: per-lane source
     // addresses (a piece may straddle an image row, whose pixels are not equidistant in the high-resolution tensor)
@@ -104,17 +114,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     auto dma_y = [&](auto stagec, const bool fifth, const int st) {
         constexpr int stage = decltype(stagec)::value;
         constexpr int DST = BOFF + stage * B_STAGE;
-        const int q = st * BK - 1 + (fifth ? 32 : 8 * wv) + drow;
-        const int row = q >> lw;                                   // n Hl + Y
-        const int hi = (2 * row + py) * W + 2 * (q & (Wl - 1)) + px;
-        const int voff = (unsigned)q < (unsigned)Ml ? hi * Co2 + dcol : (int)0x80000000;
-        const int soff = n0 * 2;
+        const int q = st * PXS - 1 + (fifth ? 32 : 8 * wv) + drow;
+        auto addr = [&](const int qq) {
+            const int row = qq >> lw;                              // n Hl + Y
+            const int hi = (2 * row + py) * W + 2 * (qq & (Wl - 1)) + px;
+            return (unsigned)qq < (unsigned)Ml ? hi * Co2 + dcol : (int)0x80000000;
+        };
+        const int voff = addr(q);
+        const int voff1 = K64 ? addr(q + BK) : voff;              // slot 1: the other plane, or (K64) the piece 32 pixels on
+        const int soff = n0 * 2, soff1 = K64 ? soff : soff + pby;
         if (fifth) {
             lds_dma16_at<DST>(rsy, lds4, voff, soff);
-            lds_dma16_at<DST + B_PLANE>(rsy, lds4, voff, soff + pby);
+            lds_dma16_at<DST + B_PLANE>(rsy, lds4, voff1, soff1);
         } else {
             lds_dma16_at<DST>(rsy, ldsw, voff, soff);
-            lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff, soff + pby);
+            lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff1, soff1);
         }
     };
     auto dma_step = [&](auto stagec, const int st) {
@@ -156,42 +170,51 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     const int b_zero = BOFF + ZROW * RB + ((wn << 6) | cbyte);
     auto tr = [&](const unsigned char* p) -> s16x4u { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4u_t*)p); };
 
-    s16x4u afr[2][2][NP][2], bfr[2][2][NP][2];       // [slice][local tap row / column][plane][row half]
-    const unsigned char* bsel[2][2][2];
+    s16x4u afr[2][2][NP][2], bfr[2][2][NP][2];       // [slice][local tap row / column][plane slot][row half]
+    // [slice][local tap column][plane slot (K64: pixel half)][row half]: address of the dy read inside stage 0 (tile row or the zero row)
+    constexpr int NSL = K64 ? 2 : 1;
+    const unsigned char* bsel[2][2][NSL][2];
     const unsigned char* bconst[2][2][2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int kxl = 0; kxl < 2; ++kxl)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) bsel[s2][kxl][e] = bconst[s2][kxl][e] = smem + b_off[kxl] + (16 * s2 + 4 * e) * RB;
+            for (int e = 0; e < 2; ++e) {
+                bconst[s2][kxl][e] = smem + b_off[kxl] + (16 * s2 + 4 * e) * RB;
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) bsel[s2][kxl][sl][e] = bconst[s2][kxl][e];
+            }
     const unsigned char* const bzero = smem + b_zero;
     // the shifted pixel must lie in the same image row: kx = 0 reads dy[q + 1] (not past the right border), kx = 2 reads dy[q - 1]
     auto b_addr = [&](auto sc, const int st) {
         constexpr int s = decltype(sc)::value;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int q = st * BK + 16 * s + 4 * e + krow;
-            const int ox = q & (Wl - 1);
-            // (both slots written with selects: a conditional store to one of them becomes a runtime-indexed array = scratch)
-            bsel[s][0][e] = (px != 0 || ox <= Wl - 2) ? bconst[s][0][e] : bzero;      // px = 0: slot 0 is kx = 0
-            bsel[s][1][e] = (px == 0 || ox >= 1) ? bconst[s][1][e] : bzero;           // px = 1: slot 1 is kx = 2
-        }
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = st * PXS + BK * sl + 16 * s + 4 * e + krow;
+                const int ox = q & (Wl - 1);
+                // (both columns written with selects: a conditional store to one of them becomes a runtime-indexed array = scratch)
+                bsel[s][0][sl][e] = (px != 0 || ox <= Wl - 2) ? bconst[s][0][e] : bzero;      // px = 0: column 0 is kx = 0
+                bsel[s][1][sl][e] = (px == 0 || ox >= 1) ? bconst[s][1][e] : bzero;           // px = 1: column 1 is kx = 2
+            }
     };
-    constexpr int NR = NP * 8, NMMA = nprod<NP>() * 4;      // 16 reads, 12 MFMAs per slice
+    constexpr int NR = NP * 8, NMMA = (K64 ? 2 : nprod<NP>()) * 4;      // 16 reads, 12 (K64: 8) MFMAs per slice
+    static_assert(NR <= 2 * NMMA, "at most two fragment reads behind each MFMA");
     // read k of a slice, in order of first use (products l*h, h*l, h*h): per plane pair x(row 0), dy(col 0), dy(col 1), x(row 1), two
     // row halves each
     auto read_frag = [&](auto sc, auto kc, auto stagec) {
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value, stage = decltype(stagec)::value;
         constexpr int grp = k / 8, r = (k - grp * 8) >> 1, e = k & 1;
-        constexpr int pa = NP - 1 - grp, pb = grp;
+        constexpr int pa = K64 ? grp : NP - 1 - grp, pb = grp;
         if constexpr (r == 0 || r == 3) {
             constexpr int kyl = r == 0 ? 0 : 1;
             constexpr int off = stage * A_STAGE + pa * A_PLANE + (kyl * BK + 16 * s + 4 * e) * RB;
             afr[s][kyl][pa][e] = tr(aptr + off);
         } else {
             constexpr int kxl = r - 1;
-            bfr[s][kxl][pb][e] = tr(bsel[s][kxl][e] + (stage * B_STAGE + pb * B_PLANE));
+            bfr[s][kxl][pb][e] = tr(bsel[s][kxl][K64 ? pb : 0][e] + (stage * B_STAGE + pb * B_PLANE));
         }
     };
     auto frag = [](const s16x4u lo, const s16x4u hi) {
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     auto mma_one = [&](auto sc, auto mc) {
         constexpr int s = decltype(sc)::value, m = decltype(mc)::value;
         constexpr int q = m / 4, tap = m - q * 4, kyl = tap >> 1, kxl = tap & 1;
-        constexpr int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
+        constexpr int pa = K64 ? q : prod_a<NP>(q), pb = K64 ? q : prod_b<NP>(q);
         acc[tap] = mma16<NP>(frag(afr[s][kyl][pa][0], afr[s][kyl][pa][1]), frag(bfr[s][kxl][pb][0], bfr[s][kxl][pb][1]), acc[tap]);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -234,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
                     read_frag(I1{}, std::integral_constant<int, NMMA + m>{}, SK{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (m == 5 || m == 9) {
-                    dma_x(std::integral_constant<int, (m - 5) / 4>{}, SD{}, dst_step);
+                if constexpr (m == NMMA / 2 - 1 || m == NMMA - 3) {
+                    dma_x(std::integral_constant<int, (m == NMMA / 2 - 1 ? 0 : 1)>{}, SD{}, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -252,11 +275,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
                     read_frag(I0{}, std::integral_constant<int, NMMA + m>{}, SN{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (m == 5) {
+                if constexpr (m == NMMA / 2 - 1) {
                     dma_y(SD{}, false, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (m == 9) {
+                if constexpr (m == NMMA - 3) {
                     if (wv == 0) dma_y(SD{}, true, dst_step);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -355,9 +378,9 @@ static int ilog2u(int v) {
 }
 
 // split-K plan: tiles x ksplit x 4 phases ~ 256 blocks (one per CU), at least 8 K-steps per block
-static void up4_wgrad_plan(int Ml, int Cin, int Cout, int* ksplit, int* sps) {
+static void up4_wgrad_plan(int Ml, int Cin, int Cout, int pxs, int* ksplit, int* sps) {
     const int tiles = (Cin / 64) * (Cout / 64) * 4;
-    const int total_steps = (Ml + 31) / 32;
+    const int total_steps = (Ml + pxs - 1) / pxs;
     long ks = tiles >= 256 ? 1 : (256 + tiles - 1) / tiles;
     ks = std::min<long>(ks, std::max(1, total_steps / 8));
     if (ks >= 8) ks = (ks / 8) * 8;
@@ -368,11 +391,12 @@ static void up4_wgrad_plan(int Ml, int Cin, int Cout, int* ksplit, int* sps) {
 }
 
 static bool up4_wgrad_ok(const rpnet_conv_desc* d) {
-    if (!d || d->split_planes != 2 || d->C1 || d->Co1 || d->x1 || d->H % 2 || d->W % 2) return false;
+    if (!d || (d->split_planes != 2 && d->split_planes != 1) || d->C1 || d->Co1 || d->x1 || d->H % 2 || d->W % 2) return false;
     const int Hl = d->H / 2, Wl = d->W / 2;
     if (ilog2u(Wl) < 3 || ilog2u(Hl) < 0 || d->C0 % 64 || d->Co0 % 64) return false;
     const size_t lim = (size_t)1 << 31;
-    return (size_t)d->N * Hl * Wl * d->C0 * 4 < lim && (size_t)d->N * d->H * d->W * d->Co0 * 4 < lim && ((size_t)d->N * Hl * Wl) % 32 == 0;
+    return (size_t)d->N * Hl * Wl * d->C0 * 4 < lim && (size_t)d->N * d->H * d->W * d->Co0 * 4 < lim &&
+           ((size_t)d->N * Hl * Wl) % (d->split_planes == 1 ? 64 : 32) == 0;
 }
 
 }  // namespace rpnet
@@ -380,9 +404,10 @@ static bool up4_wgrad_ok(const rpnet_conv_desc* d) {
 extern "C" int rpnet_conv_wgrad_up4_supported(const rpnet_conv_desc* d) { return rpnet::up4_wgrad_ok(d) ? 1 : 0; }
 
 extern "C" size_t rpnet_conv_wgrad_up4_workspace_bytes(int N, int H, int W, int cin, int cout) {
-    int ks, sps;
-    rpnet::up4_wgrad_plan(N * (H / 2) * (W / 2), cin, cout, &ks, &sps);
-    return (size_t)4 * ks * 4 * cin * cout * sizeof(float);
+    int ks, sps, ks1, sps1;      // the larger of the two plans (two planes: 32-pixel steps; one plane: 64-pixel steps)
+    rpnet::up4_wgrad_plan(N * (H / 2) * (W / 2), cin, cout, 32, &ks, &sps);
+    rpnet::up4_wgrad_plan(N * (H / 2) * (W / 2), cin, cout, 64, &ks1, &sps1);
+    return (size_t)4 * (ks > ks1 ? ks : ks1) * 4 * cin * cout * sizeof(float);
 }
 
 extern "C" int rpnet_conv_wgrad_up4(const rpnet_conv_desc* d, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -393,14 +418,19 @@ extern "C" int rpnet_conv_wgrad_up4(const rpnet_conv_desc* d, const void* dy, fl
                   d->N, d->H, d->W, d->C0, d->Co0, d->split_planes);
     const int Hl = d->H / 2, Wl = d->W / 2, Ml = d->N * Hl * Wl, Cin = d->C0, Cout = d->Co0;
     int ks, sps;
-    up4_wgrad_plan(Ml, Cin, Cout, &ks, &sps);
+    const bool one = d->split_planes == 1;
+    up4_wgrad_plan(Ml, Cin, Cout, one ? 64 : 32, &ks, &sps);
     RPNET_REQUIRE(workspace_bytes >= rpnet_conv_wgrad_up4_workspace_bytes(d->N, d->H, d->W, Cin, Cout), RPNET_ERR_WORKSPACE, "conv_wgrad_up4: workspace");
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)workspace;
     if (dy) {       // dy == NULL: reduce phase only (the two-phase form of rpnet_conv_wgrad)
         const int tiles_n = Cout / 64, tiles = (Cin / 64) * tiles_n;
-        hipLaunchKernelGGL(conv_wgrad_up4_kernel, dim3(tiles * ks * 4), dim3(256), 0, s, *d, (const unsigned short*)dy, part, Ml, Cin, Cout, tiles,
-                           tiles_n, ks, sps, ilog2u(Wl), ilog2u(Hl));
+        if (one)
+            hipLaunchKernelGGL(conv_wgrad_up4_kernel<true>, dim3(tiles * ks * 4), dim3(256), 0, s, *d, (const unsigned short*)dy, part, Ml, Cin, Cout,
+                               tiles, tiles_n, ks, sps, ilog2u(Wl), ilog2u(Hl));
+        else
+            hipLaunchKernelGGL(conv_wgrad_up4_kernel<false>, dim3(tiles * ks * 4), dim3(256), 0, s, *d, (const unsigned short*)dy, part, Ml, Cin, Cout,
+                               tiles, tiles_n, ks, sps, ilog2u(Wl), ilog2u(Hl));
         if (int rc = check_launch("conv_wgrad_up4")) return rc;
     }
     if (!dw) return RPNET_OK;

@@ -34,9 +34,8 @@ _ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": []
 # Tensors an async weight-gradient launch reads on the side streams (dy, its planes, the saved input, the operand scales,
 # the split-K workspace) are KEPT ALIVE until the streams are joined at the end of the backward pass (join_side_streams)
 # instead of being handed to the caching allocator's record_stream: every record costs an event record at free time and
-# event queries at later allocations (~10 tensors x 27 launches per step: measurable host time), and 288 GB of HBM hold a
-# backward pass's gradients without noticing.  RPNET_WGRAD_KEEPALIVE=0 restores record_stream (A/B switch).
-_KEEPALIVE = os.environ.get("RPNET_WGRAD_KEEPALIVE", "1") == "1"
+# event queries at later allocations (~10 tensors x 27 launches per step: 9.7 -> 8.4 ms of host time per step, round 4), and
+# 288 GB of HBM hold a backward pass's gradients without noticing (bench.py reports the step's peak allocation).
 
 # Arithmetic of the 3x3 convolutions (forward, dgrad, wgrad): "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands;
 # "bf16x3" = every fp32 operand carried as three bf16 planes (exact split) and multiplied with six
@@ -94,7 +93,7 @@ def set_async_wgrad(on=True):
 
 
 # diagnostic hook (None: off): a list that ConvBnRelu.backward fills with (tag, weight shape, clone) of its intermediate tensors
-# in stream order (tools/diag_taps.py compares them between runs of one step)
+# in stream order (round 4's diagnostic of the pooled-pass fault compared them between runs of one step)
 _TAPS = None
 
 
@@ -114,26 +113,9 @@ def _direct(p):
 
 
 def use_compute_stream(device):
-    """Make a HIGH-priority HIP stream the calling thread's current stream (the step's main chain: forward, the dgrad chain
-    and its BatchNorm / correlation passes; autograd runs every backward node on its forward's stream) and return it.  The
-    weight-gradient side streams keep the default priority (the device offers two levels, 0 and -1).  With equal
-    priorities the dispatcher alternates between the blocks of dgrad(L-1) and wgrad(L), the side stream never falls behind
-    and nothing MFMA-bound is left to run beside the HBM-bound passes of the main chain; with the main chain in front the
-    weight gradients queue up and fill the machine whenever the main chain is in a BatchNorm pass or a kernel's tail:
-    18.72 -> 18.53 ms per batch-8 step, two alternations on one box (tools/ab_overlap.py) — but launching every weight
-    gradient BEHIND its layer's dgrad (RPNET_WGRAD_DEFER, the default since) gets 18.37 ms on that box with or without the
-    priority, so this is OFF by default: RPNET_COMPUTE_PRIORITY=-1 switches it on, otherwise the caller's stream stays.
-    Drivers call this once (bench.py, train_rpnet.py); the modules never switch streams on their own."""
-    prio = int(os.environ.get("RPNET_COMPUTE_PRIORITY", "0"))
-    if prio == 0:
-        return torch.cuda.current_stream(device)
-    key = ("compute", torch.device(device).index)
-    s = _ASYNC["side"].get(key)
-    if s is None:
-        s = _ASYNC["side"][key] = torch.cuda.Stream(device=device, priority=prio)
-    torch.cuda.current_stream(device).synchronize()      # whatever the caller enqueued so far is done before the switch
-    torch.cuda.set_stream(s)
-    return s
+    """The stream the step's main chain runs on: the caller's current stream.  (Round 3 tried a high-priority main stream:
+    +1 % alone, nothing on top of releasing every weight gradient behind its layer's dgrad — RPNET_WGRAD_DEFER — and removed.)"""
+    return torch.cuda.current_stream(device)
 
 
 def _reduce_stream(device):
@@ -1211,7 +1193,7 @@ class ConvBnRelu(Function):
                 d = _desc(x0, x1, None, None, in_scale, in_mode, dy, None, N, H, W, pw.taps, upsample, wgrad=True)
             wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, pw.cin_pad, cout, pw.taps)
             # the collapsed up_conv (see _UP4): sixteen tap products per source pixel instead of thirty-six
-            wup4 = bool(getattr(ctx, "up4", False)) and wsplit and np_ == 2 and bool(query("rpnet_conv_wgrad_up4_supported", C.byref(d)))
+            wup4 = bool(getattr(ctx, "up4", False)) and wsplit and np_ in (1, 2) and bool(query("rpnet_conv_wgrad_up4_supported", C.byref(d)))
             if wup4:
                 wb = query("rpnet_conv_wgrad_up4_workspace_bytes", N, H, W, pw.cin, cout)
 
@@ -1241,22 +1223,13 @@ class ConvBnRelu(Function):
                             wgrad(ptr(dyp), None, ws2)
                             red = _reduce_stream(dev)
                             red.wait_stream(side)
-                            if _KEEPALIVE:
-                                _ASYNC["keep"].append(ws2)
-                            else:
-                                for tns in (ws2, ctx.sx, ctx.sx1, sdy):       # read by the reduce (partials, the operand scales)
-                                    if tns is not None:
-                                        tns.record_stream(red)
+                            _ASYNC["keep"].append(ws2)      # read by the reduce; alive until join_side_streams
                             with torch.cuda.stream(red):
                                 wgrad(None, ptr(weight.grad), ws2)
                         else:
                             wgrad(ptr(dyp), ptr(weight.grad), ws2)
-                    if _KEEPALIVE:       # alive until join_side_streams (the saved tensors outlive this node anyway)
-                        _ASYNC["keep"].append((x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy, ctx.xs))
-                    else:
-                        for tns in (x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy) + (ctx.xs or ()):   # keep their blocks alive until the side stream is done
-                            if tns is not None:
-                                tns.record_stream(side)
+                    # alive until join_side_streams (the saved tensors outlive this node anyway)
+                    _ASYNC["keep"].append((x0, x1, in_scale, dy, dyp, ctx.sx, ctx.sx1, sdy, ctx.xs))
                     if not _ASYNC["queued"]:      # once per backward pass (reset_async re-arms it after a failed one)
                         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
                         _ASYNC["queued"] = True

@@ -82,9 +82,11 @@ class GraphedTrainStep:
     the replay is followed by `bucket.allreduce()` — one all-reduce of the whole flat bucket on the collective library's
     stream, exposed behind the step instead of overlapped with backward (what eight eager Python processes on one shared
     host trade for one graph launch per step each).  `exposed`: a list that receives a HIP-event pair around that
-    exchange (bench.py).  CAUTION (measured round 4, tools/cap_try.sh): on this ROCm a stream capture in a process that holds an RCCL
-    communicator ended in a segmentation fault inside hipStreamEndCapture in 3 of 12 one-rank runs, in thread-local and in global
-    capture mode alike — under a process group this class is opt-in for bench.py and the tests."""
+    exchange (bench.py).  ORDER under a process group: call `capture(...)` BEFORE dist.init_process_group.  A stream capture in a
+    process that already holds an RCCL communicator ended in a segmentation fault inside hipStreamEndCapture in 3 of 12 one-rank
+    runs in round 4 (profiles/r04_graph_capture_under_rccl.txt; thread-local and global capture mode alike); a graph captured
+    before the group exists and replayed beside it completed 12 of 12 runs with gradients equal to the eager step bit for bit
+    (profiles/r05_graph_capture_order.txt) — bench.py and tests/test_gpu_dist.py use that order."""
 
     def __init__(self, net, bucket, loss_fn, warmup=2, exposed=None):
         self.net, self.bucket, self.loss_fn, self.warmup = net, bucket, loss_fn, warmup
@@ -149,9 +151,20 @@ class GraphedTrainStep:
         self._graphs[key] = (g, st, loss)
         return self._graphs[key]
 
+    @staticmethod
+    def _key(net, supp_imgs, qry_imgs):
+        return (len(supp_imgs), len(supp_imgs[0]), tuple(qry_imgs[0].shape), net.num_iter)
+
+    def capture(self, supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels):
+        """Capture the step for these shapes now (ahead of the first call: before a process group exists, see the class docstring)."""
+        key = self._key(self.net, supp_imgs, qry_imgs)
+        if key not in self._graphs:
+            self._capture(key, (supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels))
+        return self
+
     def __call__(self, supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels):
         args = (supp_imgs, fore_mask, back_mask, qry_imgs, labels, appr_query_labels)
-        key = (len(supp_imgs), len(supp_imgs[0]), tuple(qry_imgs[0].shape), self.net.num_iter)
+        key = self._key(self.net, supp_imgs, qry_imgs)
         g, st, loss = self._graphs.get(key) or self._capture(key, args)
         for dn, sn in zip(st[:3], args[:3]):
             for dw, sw in zip(dn, sn):

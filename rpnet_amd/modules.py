@@ -23,9 +23,6 @@ _FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
 # no fp32 output for conv_block's first layer when its consumer reads fp16 planes
 _PREPACK = os.environ.get("RPNET_PREPACK", "1") == "1"
 _ZSKIP = os.environ.get("RPNET_ZSKIP", "1") == "1"
-# training: the per-step weight packing on its own stream beside the first-layer convolution (RF.WeightCache.prepack_async);
-# RPNET_PACK_STREAM=0: on the caller's stream in front of it (A/B switch)
-_PACK_STREAM = os.environ.get("RPNET_PACK_STREAM", "1") == "1"
 # f16x2 mode: encoder input pixels per call from which the fp16 planes are used (below: three bf16 planes; see
 # RF.set_f16_active).  262144 = batch 2 at 256^2, where the two arithmetics are level.
 _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
@@ -47,11 +44,8 @@ _CRE_STREAMS_TRAIN = os.environ.get("RPNET_CRE_STREAMS_TRAIN", "1") == "1"
 # (tools/ab_overlap.py): configs[4] (2-way 512^2: 8 + 4 images) 33.81 -> 33.02 ms; configs[2] (5-shot: 80 + 16 images, the
 # query chain ends after a fifth of the support chain) 84.3 -> 85.0 ms; configs[1] in two half-size launches per layer
 # 17.95 -> 18.54 ms (the 16^2 / 32^2 levels no longer fill the machine) — hence the default
-# 3 = for 1-way 1-shot only the 256^2 .. 64^2 levels as two chains (their half-size launches still fill the machine) and
-# the 32^2 / 16^2 levels as one launch per layer over both calls (U_Net.forward_levels); otherwise as 1
+# (mode 3 of round 4 — only the 256^2 .. 64^2 levels as two chains — measured 17.73 against 17.55 ms and was removed in round 5)
 _ENC_STREAMS = int(os.environ.get("RPNET_ENC_STREAMS", "1"))
-_ENC_LEVELS_SIDE = True       # test switch: False runs both chains of mode 3 on the caller's stream (same launches, one stream)
-_ENC_LEVELS_MIN_PIXELS = int(os.environ.get("RPNET_ENC_LEVELS_MIN_PIXELS", str(8 * 256 * 256)))   # per call, for mode 3
 _NET_SERIAL = itertools.count(1)      # a never-reused number per RP_Net instance (id() is reused after garbage collection)
 
 
@@ -242,51 +236,6 @@ class U_Net(Unet_2D):
         d5 = self.Up_conv5.forward_nhwc(x4, cache, x1=d5, groups=groups)      # cat((x4, d5), 1) as two sources
         d4 = self.Up4.forward_nhwc(d5, cache, groups=groups, out_split=sk)
         return self.Up_conv4.forward_nhwc(x3, cache, x1=d4, groups=groups, out_split=sk)    # cat((x3, d4), 1)
-
-    def forward_levels(self, xs, xq, cache, side):
-        """The support call (xs) and the query call (xq) of one RP_Net.forward, same shapes, no mask channel, train mode:
-        Conv1 .. Conv3 and Up4 / Up_conv4 (the 256^2 .. 64^2 levels) as TWO chains — the support chain on the caller's
-        stream, the query chain on `side` —, Conv4 .. Up_conv5 (the 32^2 / 16^2 levels, whose half-size launches would leave
-        CUs idle) as ONE launch per layer with two BatchNorm statistic groups.  Each chain's statistics-finalize and
-        BatchNorm + ReLU passes then run beside the other chain's convolution where those passes are largest.  The modules'
-        running statistics and parameter gradients see the support call first (RF.order_begin).  Returns the two d4 Operands."""
-        main = torch.cuda.current_stream(xs.device)
-        sk = "scale" if RF.f16_mode() else True
-        B = xs.shape[0]
-
-        def down(x):
-            p1 = self.Conv1.forward_nhwc(x, cache, out_split=sk, pool=True)
-            p2 = self.Conv2.forward_nhwc(p1, cache, out_split=sk, pool=True)
-            x3 = self.Conv3.forward_nhwc(p2, cache, out_split=sk)
-            return x3, RF.maxpool2(x3)
-
-        side.wait_stream(main)
-        x3s, p3s = down(xs)
-        with torch.cuda.stream(side):
-            x3q, p3q = down(xq)
-        xq.record_stream(side)
-        main.wait_stream(side)
-        # one tensor scale for both halves: the two chains derive it from the same BatchNorm parameters and row count
-        p3 = RF.Operand(torch.cat([p3s.x, p3q.x], 0), scale=p3s.scale)
-        x4 = self.Conv4.forward_nhwc(p3, cache, groups=2, out_split=sk)
-        x5 = self.Conv5.forward_nhwc(RF.maxpool2(x4), cache, groups=2)
-        d5 = self.Up5.forward_nhwc(x5, cache, groups=2, out_split=sk)
-        d5 = self.Up_conv5.forward_nhwc(x4, cache, x1=d5, groups=2, out_split=sk)      # the chains split their halves themselves
-        d5s, d5q = RF.SplitRows.apply(d5.x, B) if d5.x.requires_grad else (d5.x[:B], d5.x[B:])
-
-        def up(d5h, x3):
-            d4 = self.Up4.forward_nhwc(RF.Operand(d5h, scale=d5.scale), cache, out_split=sk)
-            return self.Up_conv4.forward_nhwc(x3, cache, x1=d4, out_split=sk)
-
-        side.wait_stream(main)
-        o_s = up(d5s, x3s)
-        with torch.cuda.stream(side):
-            o_q = up(d5q, x3q)
-        main.wait_stream(side)
-        for tns in (o_q.x, o_q.p16, o_q.pbf, o_q.scale, p3q.x, x3q.x):      # allocated on `side`, read (and freed) on the caller's stream
-            if tns is not None:
-                tns.record_stream(main)
-        return o_s, o_q
 
     def forward(self, x, mask=None, do_last_conv=True):
         n, c, h, w = x.shape
@@ -525,7 +474,7 @@ class RP_Net(nn.Module):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
             # (training: the two up_conv layers on their collapsed four-tap packs, RF._UP4)
             ups = (self.encoder.Up5.up[1].weight, self.encoder.Up4.up[1].weight) if self.training else ()
-            if _PACK_STREAM and self.training and supp.is_cuda:
+            if self.training and supp.is_cuda:      # the packing on its own stream beside the first-layer convolution
                 cache.prepack_async(self._pack_weights(), planes, supp.device, ups)
             else:
                 cache.prepack(self._pack_weights(), planes, ups)
@@ -539,17 +488,9 @@ class RP_Net(nn.Module):
         # chain's convolution, in backward likewise; the launches that touch a BatchNorm module's running statistics or
         # parameter gradients keep the order of the two calls (RF.order_begin).  Policy and measurements: _ENC_STREAMS
         two_chains = (self.training and supp.is_cuda and enc_mask is None and
-                      (_ENC_STREAMS == 2 or (_ENC_STREAMS in (1, 3) and ns != B and ns <= 2 * B)))
-        levels = (_ENC_STREAMS == 3 and self.training and supp.is_cuda and enc_mask is None and ns == B
-                  and B * H * W >= _ENC_LEVELS_MIN_PIXELS and not two_chains)
-        RF.order_begin(two_chains or levels)
-        if levels:
-            cache.materialize([w for w in self._pack_weights() if w is not self.cre.w_k[0].weight and w is not self.cre.w_q[0].weight],
-                              planes)
-            o_s, o_q = self.encoder.forward_levels(supp.reshape(ns, H, W, 1), qry.reshape(B, H, W, 1), cache,
-                                                   RF._cre_stream(supp.device) if _ENC_LEVELS_SIDE else torch.cuda.current_stream(supp.device))
-            (supp_d4, s_supp), (qry_d4, s_qry) = (o_s.x, o_s.scale), (o_q.x, o_q.scale)
-        elif ns == B and not two_chains:
+                      (_ENC_STREAMS == 2 or (_ENC_STREAMS == 1 and ns != B and ns <= 2 * B)))
+        RF.order_begin(two_chains)
+        if ns == B and not two_chains:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2,
                                            mask=None if enc_mask is None else torch.cat([enc_mask, enc_mask], 0))
             s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it

@@ -214,7 +214,7 @@ def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W
 ])
 def test_dma_patch_kernel_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
     """variant 13: the LDS-DMA kernel on ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]; a K-step = one tap of 64
-    channels whose halves sit where the two planes of f16x2 do).  Same products as the 4-wave one-plane kernel (variant 10)
+    channels whose halves sit where the two planes of f16x2 do).  Same products as the 8-wave one-plane patch kernel (variant 7)
     in another order: equal to fp32 summation round-off; and within the f16 tolerance of the fp64 reference."""
     old = RF.conv_math()
     RF.set_conv_math("f16")
@@ -225,7 +225,7 @@ def test_dma_patch_kernel_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout, ups)
         a = rnd(72, N, c0, hs, ws)
         b = rnd(73, N, c1, hs, ws) if c1 else None
         go = rnd(74, N, cout, H, W)
-        z0, da0, db0, rv0, dw0, ch0 = _run(RF, monkeypatch, 10, layer, a, b, go, ups, groups)
+        z0, da0, db0, rv0, dw0, ch0 = _run(RF, monkeypatch, 7, layer, a, b, go, ups, groups)
         z, da, db, rv, dw, ch = _run(RF, monkeypatch, 13, layer, a, b, go, ups, groups)
         dgrad_ok = c0 % 128 == 0 and c1 % 128 == 0
         assert ch[0] == 13 and (ch[1] == 13) == dgrad_ok, ch
@@ -411,6 +411,24 @@ def test_upconv_collapsed_kernels_one_plane(RF, N, H, W, cin, cout):
         out[up4] = (y, dx)
     assert rel_err(out[True][0], out[False][0]) < 1e-3 and rel_err(out[True][1], out[False][1]) < 1e-3
     assert rel_err(nchw(out[True][0]), yr) < 1e-2 and rel_err(nchw(out[True][1]), ar.grad) < 1e-2
+    # weight gradient on one plane (64-pixel K-steps, the halves in the two plane slots)
+    dws = {}
+    for up4 in (True, False):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        d = RF._desc(xs, None, None, None, None, 0, None, None, N, H, W, 9, 1, co_split=(cout, 0), wgrad=True)
+        d.split_planes = 1
+        d.acc_scale_x, d.acc_scale_dy = ptr(sx), ptr(sx)
+        if up4:
+            assert query("rpnet_conv_wgrad_up4_supported", C.byref(d))
+            wb = query("rpnet_conv_wgrad_up4_workspace_bytes", N, H, W, cin, cout)
+            ws = torch.empty(wb // 4 + 4, device=DEV)
+            call("rpnet_conv_wgrad_up4", C.byref(d), ptr(dys), ptr(dw), ptr(ws), wb)
+        else:
+            wb = query("rpnet_conv_wgrad_workspace_bytes", N, H, W, cin, cout, 9)
+            ws = torch.empty(wb // 4 + 4, device=DEV)
+            call("rpnet_conv_wgrad", C.byref(d), ptr(dys), ptr(dw), cin, 0, cin, cin, ptr(ws), wb)
+        dws[up4] = dw
+    assert rel_err(dws[True], dws[False]) < 1e-4 and rel_err(dws[True], cr.weight.grad) < 1e-2
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout", UP4_CASES)

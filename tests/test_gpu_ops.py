@@ -145,7 +145,7 @@ def test_conv_two_sources_upsample_and_groups(RF, conv_math):
 
 @pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [(2, 32, 32, 128, 0, 128, False), (1, 16, 16, 64, 64, 256, False),
                                                    (2, 32, 64, 64, 0, 128, True), (3, 16, 48, 64, 64, 128, False), (2, 32, 32, 64, 0, 64, False), (1, 16, 32, 128, 0, 192, False)])
-@pytest.mark.parametrize("tile", ["7", "8", "10"])
+@pytest.mark.parametrize("tile", ["7", "8"])
 def test_split_halo_kernel(RF, monkeypatch, tile, N, H, W, c0, c1, cout, ups):
     """The halo-resident 256x128 variant (conv_igemm_split_halo_kernel: image patches, input halo staged once per
     channel chunk) forced on small shapes: two sources, nearest x2, both patch widths (W % 32 == 0 / W % 16 == 0),

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for profiles/: kernel trace (serialised + async default), PMC traffic (two passes), MFMA busy, and
 # the bench lines of the same tree.  Run on the GPU box through gpurun:   bash tools/profile_all.sh r02
 # Budget: ~25 GPU-minutes when every pass works; every profiler pass runs under `timeout 150` (round 4 lost two calls to PMC passes
-# that hung until a 300 s timeout, six in a row).  tools/profile_lean.sh + tools/pmc_try.sh are the ten-minute subset.
+# that hung until a 300 s timeout, six in a row).  tools/profile_lean.sh is the ten-minute subset.
 # Raw outputs stay in gpurun_out/prof_<tag>/raw (scratch, deleted at the end); the summaries made by tools/*.py land
 # in gpurun_out/prof_<tag>/ and are copied into profiles/<tag>_* by hand.
 TAG=${1:-r04}

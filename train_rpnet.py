@@ -61,7 +61,6 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
     caller_stream = None
     if torch.device(dev).type == "cuda":
         caller_stream = torch.cuda.current_stream(dev)
-        RF.use_compute_stream(dev)       # the main chain in front of the weight-gradient side streams
     params = [p for _, p in bucket.params]
     opt = torch.optim.Adam(params, lr=lr if lr is not None else config["init_lr"], weight_decay=config["weight_decay"])
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=config["scheduler_step"])
