@@ -2,7 +2,7 @@
 default mode (weight gradients on side streams), the union of the intervals in which at least one MFMA-bound kernel
 (convolution forward / dgrad, weight gradient, local correlation) is running, per step; the rest of the step's span is
 "MFMA-idle" and is attributed to the kernels that ran then.  Steps are cut at the first-layer forward kernel
-(conv1_fwd_kernel: once per step).
+(conv1_fwd_kernel / conv1_fwd4_kernel: once per step).
 Usage: python tools/mfma_idle.py trace.db [out.txt]"""
 import collections, re, sqlite3, sys
 
@@ -13,9 +13,9 @@ cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 pick = lambda *names: next(n for n in names if n in cols)  # noqa: E731
 cs, ce = pick("start", "start_ns", "begin"), pick("end", "end_ns", "stop")
 rows = c.execute(f"select name, {cs}, {ce} from kernels order by {cs}").fetchall()
-GEMM = re.compile(r"conv_igemm|conv_wgrad9|conv_wgrad1_split|local_corr_mfma|conv_igemm_split")
+GEMM = re.compile(r"conv_igemm|conv_wgrad9|conv_wgrad1_split|local_corr_mfma|conv_igemm_split|conv_up4_dma|conv_wgrad_up4_kernel")
 short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "").replace("rpnet::", "")  # noqa: E731
-starts = [i for i, r in enumerate(rows) if "conv1_fwd_kernel" in r[0]]
+starts = [i for i, r in enumerate(rows) if "conv1_fwd_kernel" in r[0] or "conv1_fwd4_kernel" in r[0]]
 print(f"{len(rows)} kernel records, {len(starts)} steps (columns: {cols})", file=out)
 for si in range(max(0, len(starts) - 4), len(starts) - 1):       # the last full steps
     seg = rows[starts[si]:starts[si + 1]]
