@@ -53,6 +53,11 @@ constexpr int kWgrad1MaxSplits = 128;
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private
 // L2); give every XCD a contiguous run of logical tiles so neighbouring tiles (which share
 // an operand panel) hit the same L2.  Bijective for any tile count.
+// Block-uniform integers that come out of a division live in VGPRs (hipcc divides in the vector unit and does not prove the
+// quotient uniform): every address built from them becomes vector arithmetic and every scalar operand of a buffer instruction a
+// readfirstlane loop.  uni() pins such a value to an SGPR.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ int xcd_swizzle(int bid, int ntiles) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, k = bid >> 3;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

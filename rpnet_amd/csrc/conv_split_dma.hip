@@ -60,14 +60,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     const int wm = wv >> 1, wn = wv & 1;
 
     const int tile = xcd_swizzle(blockIdx.x, ntiles);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tm = uni(tile / tiles_n), tn = tile - tm * tiles_n;
     const int n0 = tn * BN;
     const int H = d.H, W = d.W, HW = H * W;
     const int ups = d.upsample;
     const int Hs = H >> ups, Ws = W >> ups;
     const int pxn = W / TW, ppi = (H / TH) * pxn;
-    const int n = tm / ppi, prem = tm - n * ppi;
-    const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
+    const int n = uni(tm / ppi), prem = tm - n * ppi;
+    const int y0 = uni(prem / pxn) * TH, x0 = uni(prem % pxn) * TW;
 
     constexpr int CSH = K64 ? 6 : 5;               // channels per K-step: 64 (one plane, two halves) or 32 (per plane)
     // split K (kshift > 0: grid.y = 2^kshift parts, conv_fwd_split_dma below): part blockIdx.y multiplies the channel chunks
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     const int kchunks = (Cin >> CSH) >> kshift;
     const int cbase = (int)blockIdx.y * kchunks;
     const int nsteps = 9 * kchunks;
-    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    const int rot = uni((int)(blockIdx.x % (unsigned)kchunks));
     auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return (cbase + c) << CSH; };
 
     const size_t plane0 = (size_t)d.N * Hs * Ws * d.C0, plane1 = (size_t)d.N * Hs * Ws * d.C1;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         constexpr int i = decltype(ic)::value;
         const bool first = c0 < d.C0;
         const int Cs = first ? d.C0 : d.C1;
-        const int soff = (first ? c0 : c0 - d.C0) * 2;
+        const int soff = uni((first ? c0 : c0 - d.C0) * 2);
         const int voff = hoff[i] * (Cs * 2) + dkg16;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     // weights: this wave moves rows 16 WN wv .. of every plane of a slab (WN pieces each)
     const int wvoff = (16 * WN * wv + drow) * 64 + dkg16;
     auto dma_w = [&](int tap, int c0, int stage) {
-        const int wsoff = ((tap * (Cin >> 5) + (c0 >> 5)) * Cout + n0) * 64;
+        const int wsoff = uni(((tap * (Cin >> 5) + (c0 >> 5)) * Cout + n0) * 64);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
         // the tail of the last chunk re-fetches valid data into buffers nobody reads again (uniform DMA counts)
         constexpr int t3 = TAP + 3 < 9 ? TAP + 3 : TAP - 6;
         const int c3 = chunk_c0((TAP + 3 < 9 || last_chunk) ? ci : ci + 1);
-        const int wsoff = ((t3 * (Cin >> 5) + (c3 >> 5)) * Cout + n0) * 64;
+        const int wsoff = uni(((t3 * (Cin >> 5) + (c3 >> 5)) * Cout + n0) * 64);
         const int wstage = (ks + 3) & 3;
         const int abase = hb * HBUF, bbase = (ks & 3) * STAGE;
         static_for<NMMA>([&](auto mc) {

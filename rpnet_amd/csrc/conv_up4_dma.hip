@@ -79,25 +79,25 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     const int wm = wv >> 1, wn = wv & 1;
 
     const int tile = xcd_swizzle(blockIdx.x, ntiles);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tm = uni(tile / tiles_n), tn = tile - tm * tiles_n;
     const int n0 = tn * BN;
     const int H = d.H, W = d.W, Hl = H >> 1, Wl = W >> 1;
     const int pxn = Wl / TW, ppi = (Hl / TH) * pxn;
-    const int n = tm / ppi, prem = tm - n * ppi;
-    const int y0 = (prem / pxn) * TH, x0 = (prem % pxn) * TW;
+    const int n = uni(tm / ppi), prem = tm - n * ppi;
+    const int y0 = uni(prem / pxn) * TH, x0 = uni(prem % pxn) * TW;
     const int C0 = d.C0;
     // forward: the phase of this block's columns
     const int Cout_out = Ncols >> 2;
-    const int fphase = DG ? 0 : n0 / Cout_out;
+    const int fphase = DG ? 0 : uni(n0 / Cout_out);
     const int fpy = fphase >> 1, fpx = fphase & 1;
 
     constexpr int CSH = K64 ? 6 : 5;               // channels per K-step: 64 (one plane, two halves) or 32 (per plane)
     const int kchunks = Kc >> CSH;
-    const int rot = (int)(blockIdx.x % (unsigned)kchunks);
+    const int rot = uni((int)(blockIdx.x % (unsigned)kchunks));
     auto chunk_c0 = [&](int ci) { int c = rot + ci; if (c >= kchunks) c -= kchunks; return c << CSH; };
     // tap base (Py, Px) of a chunk: the 3x3 index of its tap slot (r, c) is (Py + r, Px + c)
-    auto chunk_py = [&](int c0) { return DG ? 1 - ((c0 / C0) >> 1) : fpy; };
-    auto chunk_px = [&](int c0) { return DG ? 1 - ((c0 / C0) & 1) : fpx; };
+    auto chunk_py = [&](int c0) { return DG ? 1 - (uni(c0 / C0) >> 1) : fpy; };
+    auto chunk_px = [&](int c0) { return DG ? 1 - (uni(c0 / C0) & 1) : fpx; };
 
     const size_t plane0 = DG ? (size_t)d.N * H * W * C0 : (size_t)d.N * Hl * Wl * C0;
     const size_t planew = (size_t)4 * Kc * Ncols;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
         constexpr int i = decltype(ic)::value;
         int pix = hpix[i], cs = c0;
         if constexpr (DG) {
-            const int ph = c0 / C0;
+            const int ph = uni(c0 / C0);
             cs = c0 - ph * C0;
             pix += (ph >> 1) * W + (ph & 1);
         }
@@ -138,11 +138,11 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * HBUF + p * A_BYTES + hpos[i] * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, cs * 2 + p * ps0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, uni(cs * 2) + p * ps0, 0, 0);
         }
     };
     const int wvoff = (16 * WN * wv + drow) * 64 + dkg16;
-    auto w_soff = [&](int idx, int c0) { return ((idx * (Kc >> 5) + (c0 >> 5)) * Ncols + n0) * 64; };
+    auto w_soff = [&](int idx, int c0) { return uni(((idx * (Kc >> 5) + (c0 >> 5)) * Ncols + n0) * 64); };
     auto dma_w = [&](int idx, int c0, int stage) {
         const int wsoff = w_soff(idx, c0);
 #pragma unroll

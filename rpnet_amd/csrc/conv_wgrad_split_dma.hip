@@ -69,13 +69,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     int tile, z;
     if ((ksplit & 7) == 0) {       // the blocks of one pixel chunk share an XCD (and its L2)
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        z = (j / tiles) * 8 + xcd;
-        tile = j - (j / tiles) * tiles;
+        const int jt = uni(j / tiles);
+        z = jt * 8 + xcd;
+        tile = j - jt * tiles;
     } else {
-        z = blockIdx.x / tiles;
+        z = uni(blockIdx.x / tiles);
         tile = blockIdx.x - z * tiles;
     }
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tm = uni(tile / tiles_n), tn = tile - tm * tiles_n;
     const int cm0 = tm * 64, n0 = tn * 64;
 
     const int H = d.H, W = d.W, HW = H * W;

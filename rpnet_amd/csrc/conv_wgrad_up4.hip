@@ -53,19 +53,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     const int wm = wv >> 1, wn = wv & 1;
     // block -> (phase, K split, tile): the blocks of one pixel chunk and phase share an XCD where the split count allows
     const int per_phase = tiles * ksplit;
-    const int phase = blockIdx.x / per_phase;
+    const int phase = uni(blockIdx.x / per_phase);
     const int bx = blockIdx.x - phase * per_phase;
     int tile, z;
     if ((ksplit & 7) == 0) {
         const int xcd = bx & 7, j = bx >> 3;
-        z = (j / tiles) * 8 + xcd;
-        tile = j - (j / tiles) * tiles;
+        const int jt = uni(j / tiles);
+        z = jt * 8 + xcd;
+        tile = j - jt * tiles;
     } else {
-        z = bx / tiles;
+        z = uni(bx / tiles);
         tile = bx - z * tiles;
     }
     const int py = phase >> 1, px = phase & 1;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tm = uni(tile / tiles_n), tn = tile - tm * tiles_n;
     const int cm0 = tm * 64, n0 = tn * 64;
 
     const int W = d.W, Wl = W >> 1, Hl = d.H >> 1;

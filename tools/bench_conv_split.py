@@ -44,6 +44,7 @@ def conv(x, pw, co, planes, xs=None):
 torch.manual_seed(0)
 FWD_ONLY = os.environ.get("FWD_ONLY") == "1"      # only the forward speed table
 RELU = os.environ.get("RELU") == "1"              # half of the activations exact zeros, as behind a ReLU (the clock the chip holds depends on the data)
+ZERO = os.environ.get("ZERO", "")                 # "x": all-zero activations, "xw": all-zero activations and weights (no toggling in the matrix pipe: the clock the loop COULD hold)
 for (N, H, W, ci, co) in ([] if FWD_ONLY else [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]):
     x = torch.randn(N, H, W, ci, device=dev)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
@@ -65,6 +66,10 @@ for (N, H, W, ci, co) in SHAPES:
     if RELU:
         x = torch.relu(x)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    if "x" in ZERO:
+        x = x * 0 + 1e-30        # (planes of an all-zero tensor; the scale search needs a nonzero maximum)
+    if "w" in ZERO:
+        w = w * 0
     pw = PackedWeight(w)
     fl = 2.0 * N * H * W * ci * co * 9
     line = f"M={N*H*W:8d} {ci:4d}->{co:4d}"
