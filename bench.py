@@ -61,6 +61,15 @@ def algorithmic_gf_per_pair(size, T, n_shots=1, n_ways=1):
     return 3.0 * (imgs * 82.22 + cre_calls * 10.12) * s
 
 
+def upconv_collapse_saved_gf_per_pair(size, n_shots=1, n_ways=1):
+    """GF per pair the collapsed up_conv layers do NOT execute (Up5, Up4: 9.66 GF forward per image at 256^2 each, x 3 for forward +
+    input gradient + weight gradient, 5 of 9 tap products gone); 0 with RPNET_UPCONV_COLLAPSE=0."""
+    import rpnet_amd.functional as RF
+    if not RF._UP4:
+        return 0.0
+    return 3.0 * (n_ways * n_shots + 1) * 2 * 9.664 * (5.0 / 9.0) * (size / 256.0) ** 2
+
+
 def baseline_config(args, world):
     """which BASELINE.json configuration the command line is (parity-test shapes other than [1] / [3] are not headline)"""
     key = (args.ways, args.shots, args.size, args.iters)
@@ -831,6 +840,10 @@ def roofline_of(m, w, world):
             "whole_step_frac": round(value / world * gf_pair * 1e9 / (peak * 1e12), 4),
             "whole_step_tflops": round(value / world * gf_pair / 1e3, 1),
             "gflop_per_pair": round(gf_pair, 1),
+            # the same two figures on the multiply-adds the step EXECUTES (gflop_per_pair minus what the collapsed up_conv layers skip)
+            "gflop_per_pair_executed": round(gf_pair - upconv_collapse_saved_gf_per_pair(w["size"], w["shots"], w["ways"]), 1),
+            "whole_step_frac_executed": round(value / world * (gf_pair - upconv_collapse_saved_gf_per_pair(w["size"], w["shots"], w["ways"]))
+                                              * 1e9 / (peak * 1e12), 4),
             "kernel_time_share": {k: round(v[1] / kern_total, 4) for k, v in
                                   sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]},
             "sum_kernel_ms_per_step": round(1e3 * kern_total, 2),

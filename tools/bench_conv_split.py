@@ -43,9 +43,11 @@ def conv(x, pw, co, planes, xs=None):
 
 torch.manual_seed(0)
 FWD_ONLY = os.environ.get("FWD_ONLY") == "1"      # only the forward speed table
+WG_PLANES = (2,)                                  # WG_ONLY=1: only the f16x2 weight-gradient speed table
 RELU = os.environ.get("RELU") == "1"              # half of the activations exact zeros, as behind a ReLU (the clock the chip holds depends on the data)
 ZERO = os.environ.get("ZERO", "")                 # "x": all-zero activations, "xw": all-zero activations and weights (no toggling in the matrix pipe: the clock the loop COULD hold)
-for (N, H, W, ci, co) in ([] if FWD_ONLY else [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]):
+WG_ONLY = os.environ.get("WG_ONLY") == "1"
+for (N, H, W, ci, co) in ([] if (FWD_ONLY or WG_ONLY) else [(2, 32, 32, 256, 256), (1, 16, 16, 1024, 128)]):
     x = torch.randn(N, H, W, ci, device=dev)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), padding=1).permute(0, 2, 3, 1)
@@ -61,7 +63,7 @@ SHAPES = [(16, 256, 256, 64, 64), (16, 128, 128, 128, 128), (16, 64, 64, 256, 25
           (16, 16, 16, 1024, 1024), (16, 32, 32, 1024, 512), (8, 64, 64, 256, 256)]
 if os.environ.get("SHAPES"):
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
-for (N, H, W, ci, co) in SHAPES:
+for (N, H, W, ci, co) in ([] if WG_ONLY else SHAPES):
     x = torch.randn(N, H, W, ci, device=dev)
     if RELU:
         x = torch.relu(x)
@@ -122,7 +124,7 @@ def wgrad(x, dy, pw, planes):
     return dw, args, (d, ws, keep)
 
 
-for (N, H, W, ci, co) in [(2, 32, 32, 64, 128), (3, 8, 8, 128, 64), (2, 12, 20, 64, 64)]:
+for (N, H, W, ci, co) in ([] if WG_ONLY else [(2, 32, 32, 64, 128), (3, 8, 8, 128, 64), (2, 12, 20, 64, 64)]):
     x = torch.randn(N, H, W, ci, device=dev)
     dy = torch.randn(N, H, W, co, device=dev)
     w0 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
@@ -138,9 +140,13 @@ for (N, H, W, ci, co) in SHAPES:
     x = torch.randn(N, H, W, ci, device=dev)
     dy = torch.randn(N, H, W, co, device=dev)
     pw = PackedWeight(torch.zeros(co, ci, 3, 3, device=dev))
+    if "x" in ZERO:
+        x = x * 0 + 1e-30
+    if "w" in ZERO:      # (here: the other operand, the output gradient)
+        dy = dy * 0 + 1e-30
     fl = 2.0 * N * H * W * ci * co * 9
     line = f"wgrad M={N*H*W:8d} {ci:4d}->{co:4d}"
-    for planes in (0, 3, 2):
+    for planes in (WG_PLANES if os.environ.get("WG_ONLY") else (0, 3, 2)):
         _, args, _k = wgrad(x, dy, pw, planes)
         for _ in range(3):
             call("rpnet_conv_wgrad", *args)
