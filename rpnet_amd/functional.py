@@ -1484,7 +1484,75 @@ class SplitRows(Function):
         return torch.cat(parts, 0), None
 
 
+class SplitFan(Function):
+    """x [n0 + n1, ...] -> k0 aliases of x[:n0] followed by k1 aliases of x[n0:] (the support and query halves of one encoder call
+    with their consumers: the two 3x3 convolutions of the support CRE call, the 2 T of the refinement loop).  The backward sums
+    each half's incoming gradients in one pass STRAIGHT INTO its rows of the gradient of x: SplitRows' concatenation (a pass over
+    the whole tensor) and autograd's pairwise add for the support half are gone."""
+
+    @staticmethod
+    def forward(ctx, x, n0, k0, k1):
+        ctx.cfg = (n0, k0, k1)
+        ctx.meta = (tuple(x.shape), x.device, x.dtype)
+        a, b = x[:n0], x[n0:]
+        return tuple(a.view_as(a) for _ in range(k0)) + tuple(b.view_as(b) for _ in range(k1))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        n0, k0, k1 = ctx.cfg
+        shape, dev, dt = ctx.meta
+        out = torch.empty(shape, device=dev, dtype=dt)
+        for dst, gs in ((out[:n0], grads[:k0]), (out[n0:], grads[k0:])):
+            live = [g.contiguous() for g in gs if g is not None]
+            if not live:
+                dst.zero_()
+                continue
+            for i in range(0, len(live), 15):
+                chunk = ([dst] if i else []) + live[i:i + 15]
+                if len(chunk) == 1:
+                    dst.copy_(chunk[0])
+                else:
+                    arr = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+                    call("rpnet_sum_n", arr, len(chunk), ptr(dst), dst.numel())
+        return out, None, None, None
+
+
 # ------------------------------------------------------------------------ pooling
+class PoolSkip(Function):
+    """z -> (alias of z for the U-Net skip connection, nn.MaxPool2d(2, 2) of z) (net/unet.py:449-455, 460, 464: x3 and x4 feed
+    their pool AND the decoder's concatenation).  The backward routes the pooled gradient to each window's first maximum and
+    adds the gradient that arrived through the skip connection in the same pass (rpnet_maxpool2_bwd's `skip`), instead of
+    autograd's separate add over the full-resolution tensor."""
+
+    @staticmethod
+    def forward(ctx, z):
+        N, H, W, Cc = z.shape
+        out = _empty((N, H // 2, W // 2, Cc), z)
+        call("rpnet_maxpool2_fwd", ptr(z), ptr(out), N, H, W, Cc)
+        ctx.save_for_backward(z)
+        return z.view_as(z), out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dskip, dpool):
+        if dpool is None:
+            return dskip
+        (z,) = ctx.saved_tensors
+        N, H, W, Cc = z.shape
+        dz = torch.empty_like(z)
+        call("rpnet_maxpool2_bwd", ptr(z), ptr(dpool.contiguous()), None if dskip is None else ptr(dskip.contiguous()), ptr(dz),
+             N, H, W, Cc)
+        return dz
+
+
+def pool_skip(op):
+    """(the operand for the skip connection, its 2 x 2 max-pool) of an Operand whose fp32 tensor feeds both: PoolSkip"""
+    op = as_operand(op)
+    z, pooled = PoolSkip.apply(op.values())
+    return Operand(z, p16=op.p16, pbf=op.pbf, scale=op.scale), op.derive(pooled)
+
+
 class MaxPool2(Function):
     """nn.MaxPool2d(2, 2) (net/unet.py:397) on NHWC."""
 

@@ -16,9 +16,10 @@ import torch.nn as nn
 
 from . import functional as RF
 
-# one-pass gradient fan-in for the feature maps with many consumers (RF.FanOut / RF.SplitRows); RPNET_FANIN=0 leaves
-# the fan-in to autograd's pairwise adds (A/B switch)
-_FANIN = os.environ.get("RPNET_FANIN", "1") == "1"
+# one-pass gradient fan-in for the feature maps with many consumers; RPNET_FANIN=0 leaves the fan-in to autograd's pairwise
+# adds, 1 = RF.FanOut / RF.SplitRows only (round 4), 2 (default) = + both halves of the encoder output summed straight into
+# their rows (RF.SplitFan) and the skip-connection gradients added inside the max-pool backward (RF.PoolSkip) (A/B switch)
+_FANIN = int(os.environ.get("RPNET_FANIN", "2"))
 # A/B switches of two launch / traffic savings (both on by default): all operand packs of a forward in one launch, and
 # no fp32 output for conv_block's first layer when its consumer reads fp16 planes
 _PREPACK = os.environ.get("RPNET_PREPACK", "1") == "1"
@@ -230,8 +231,12 @@ class U_Net(Unet_2D):
                                          split=(128, 128, 192))
         else:
             x3 = self.Conv3.forward_nhwc(p2, cache, groups=groups, out_split=sk)
-        x4 = self.Conv4.forward_nhwc(pool(x3), cache, groups=groups, out_split=sk)
-        x5 = self.Conv5.forward_nhwc(pool(x4), cache, groups=groups)
+        # x3 and x4 feed their pool AND a skip connection: one backward pass for both gradients (RF.PoolSkip)
+        fan = _FANIN >= 2 and torch.is_grad_enabled() and x3.x.requires_grad
+        x3, p3 = RF.pool_skip(x3) if fan else (x3, pool(x3))
+        x4 = self.Conv4.forward_nhwc(p3, cache, groups=groups, out_split=sk)
+        x4, p4 = RF.pool_skip(x4) if fan else (x4, pool(x4))
+        x5 = self.Conv5.forward_nhwc(p4, cache, groups=groups)
         d5 = self.Up5.forward_nhwc(x5, cache, groups=groups, out_split=sk)
         d5 = self.Up_conv5.forward_nhwc(x4, cache, x1=d5, groups=groups)      # cat((x4, d5), 1) as two sources
         d4 = self.Up4.forward_nhwc(d5, cache, groups=groups, out_split=sk)
@@ -490,12 +495,20 @@ class RP_Net(nn.Module):
         two_chains = (self.training and supp.is_cuda and enc_mask is None and
                       (_ENC_STREAMS == 2 or (_ENC_STREAMS == 1 and ns != B and ns <= 2 * B)))
         RF.order_begin(two_chains)
+        split_fan = False
         if ns == B and not two_chains:
             d4 = self.encoder.forward_nhwc(torch.cat([supp, qry], 0).reshape(ns + B, H, W, 1), cache, groups=2,
                                            mask=None if enc_mask is None else torch.cat([enc_mask, enc_mask], 0))
             s_supp = s_qry = d4.scale      # fp16 tensor scale of the features (f16x2 / f16 training): both halves keep it
             d4 = d4.x
-            supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
+            # with the gradient fan-in of both halves (RF.SplitFan): the two 3x3 convolutions of the support CRE call, the
+            # 2 T of the refinement loop (1-way 1-shot: ns == B, one CRE call on the support features)
+            split_fan = d4.requires_grad and _FANIN >= 2 and n_ways * n_shots == 1
+            if split_fan:
+                uses = RF.SplitFan.apply(d4, ns, 2, 2 * self.num_iter)
+                supp_d4, qry_d4, fan_supp, fan_qry = uses[0], uses[2], uses[:2], uses[2:]
+            else:
+                supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
         elif two_chains:
             main, side = torch.cuda.current_stream(supp.device), RF._cre_stream(supp.device)
             qin = qry.reshape(B, H, W, 1)
@@ -528,7 +541,8 @@ class RP_Net(nn.Module):
         # ---- support relation features, per (way, shot) with that shot's own mask (:269-275)
         fore = [[m.float().contiguous() for m in way] for way in fore_mask]
         back = [[m.float().contiguous() for m in way] for way in back_mask]
-        supp_fts = [[self.cre.forward_masked(supp_d4[wa][s], RF.mask_avgpool(fore[wa][s], self.scale), cache, s_supp)
+        supp_fts = [[self.cre.forward_masked(tuple(fan_supp) if split_fan else supp_d4[wa][s],
+                                             RF.mask_avgpool(fore[wa][s], self.scale), cache, s_supp)
                      for s in range(n_shots)] for wa in range(n_ways)]
 
         # ---- prototypes: constant across iterations, computed once (:288-300)
@@ -556,7 +570,10 @@ class RP_Net(nn.Module):
         inter = pred = None
         # the query features feed 2 T convolutions: one-pass gradient fan-in instead of autograd's chain of adds
         T = self.num_iter
-        qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
+        if split_fan:
+            qry_uses = fan_qry
+        else:
+            qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
         # the loop's glue — cre.q's BatchNorm + ReLU, the cosine match, the bilinear x4, softmax / threshold / 4x4 average and the
         # operand planes of qry * mask, qry * (1 - mask) for the next iteration — is ONE launch per iteration where the shapes
         # fit (RF.CosineMatchUp / rpnet_refine_glue_fwd); a differentiable mask (soft_mask in training) keeps the separate path
