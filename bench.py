@@ -610,6 +610,7 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None, init_group=No
     scaler = cfg["align_loss_scaler"]
     RF.set_conv_math(w["conv_math"])
     requested = math = RF.conv_math()
+    torch.cuda.reset_peak_memory_stats(dev)
     net = build_model(cfg, dev)
     bucket = FlatGradBucket(net, force_active=ddp)
     inp = make_inputs(1234 + rank, w["batch"], w["size"], dev, w["shots"], w["ways"])   # resident in HBM before timing
@@ -754,10 +755,14 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None, init_group=No
     assert torch.isfinite(loss).item()
     # The profiled extra step contains the gradient all-reduce, so EVERY rank runs it (a collective
     # issued by rank 0 alone would never complete); only rank 0 reports.
+    # peak of torch's allocator over model, inputs, warm-up and the timed steps (the tensors an asynchronous weight gradient reads
+    # are kept alive until the side streams are joined at the end of backward: this is what that costs)
+    peak_gb = round(torch.cuda.max_memory_allocated(dev) / 2.0 ** 30, 2)
     RF.reset_arith()
     agg = profile_step(net, bucket, inp, scaler)
     arith = RF.arith_counts()          # which arithmetic every conv / correlation launch of that step actually ran
     return {"value": world * w["batch"] * steps / el, "el": el, "spread": spread, "agg": agg, "arith": arith, "math": math, "requested": requested,
+            "peak_gb": peak_gb,
             "net": net, "bucket": bucket, "inp": inp, "scaler": scaler, "cfg": cfg, "dist": dist_info, "fence": fence}
 
 
@@ -998,6 +1003,7 @@ def main():
                        "streams": stream_layout(),
                        "grad_allreduce_mb": round(bucket.numel * 4 / 1e6, 1)},
             "roofline": roofline_of(m, w, world),
+            "peak_allocated_gb": m["peak_gb"],
         }
         if m["dist"]:
             result["distributed"] = m["dist"]
@@ -1028,7 +1034,8 @@ def main():
             result["other_configs"][name] = {
                 "workload": workload_text(ow, 1), "value": round(om["value"], 3), "unit": "pairs/s", "steps": 5, "warmup": 3,
                 "ms_per_step": round(1e3 * om["el"] / 5, 3), "step_ms": om["spread"], "dtype": "f16" if om["math"] == "f16" else "f32",
-                "conv_math": om["math"], "launches_by_arithmetic": om["arith"], "roofline": roofline_of(om, ow, 1)}
+                "conv_math": om["math"], "launches_by_arithmetic": om["arith"], "roofline": roofline_of(om, ow, 1),
+                "peak_allocated_gb": om["peak_gb"]}
             if not args.no_cpu_baseline:
                 result["other_configs"][name]["graph_replay"] = graph_replay_leg(om["net"], om["bucket"], om["inp"], om["scaler"],
                                                                                  ow["batch"], om["fence"], 5)

@@ -204,7 +204,8 @@ typedef struct rpnet_conv_desc {
        skip_halo 1: the factor multiplies the INPUT (forward: a tile is skipped when the factor is zero on the tile and its
        one-pixel halo), 0: it multiplies the OUTPUT (input gradient with out_scale: zero on the tile itself).  skip_ws: caller's
        scratch of >= N*H*W / 128 bytes for the per-tile flags (rpnet_conv_fwd fills it with one small launch in front).  Only the
-       LDS-DMA patch kernels honour it (others compute every tile); skipped and computed tiles give the same bits (0 * w adds +0),
+       LDS-DMA patch kernels honour it (others compute every tile); skipped and computed tiles are numerically equal (0 * w adds 0;
+       the SIGN of a zero may differ: a negative accumulator times a zero factor is -0 where the skipped tile writes +0),
        unless a weight or gradient is Inf / NaN. */
     const float* skip_mask; int skip_mode; int skip_halo; unsigned char* skip_ws;
     const unsigned char* tile_skip;    /* internal (set by the launcher): flags [M tiles], 0 = skip */

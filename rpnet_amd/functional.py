@@ -779,13 +779,18 @@ class WeightCache:
         main = torch.cuda.current_stream(device)
         ps = _pack_stream(device)
         ps.wait_stream(main)
+        self._ready = None          # (the packs made below must not wait for an earlier call's event)
         with torch.cuda.stream(ps):
             self.prepack(weights, planes, up4)
             ev = torch.cuda.Event()
             ev.record(ps)
-        self._ready = (ev, set())
+        self._ready = (ev, set(), torch.cuda.is_current_stream_capturing())
 
     def get(self, weight, split=None):
+        if self._ready is not None and self._ready[2] and not torch.cuda.is_current_stream_capturing():
+            # the event was recorded inside a stream capture (GraphedTrainStep / GraphedEval): it belongs to the graph, an eager
+            # stream cannot wait for it — a replay's packs are ordered behind the replay on the stream that launched it
+            self._ready = None
         if self._ready is not None:
             sid = hip.stream()
             if sid not in self._ready[1]:

@@ -373,11 +373,11 @@ def test_masked_conv_zero_tile_skip_is_bit_identical(RF, math, training):
     loop) against the same launches dense: output, input gradient, weight gradient, BatchNorm gradients and running statistics
     BIT-identical; the launch counters show that the skip was armed; a mask that is zero nowhere skips nothing and is also equal."""
     from rpnet_amd import modules as RM
-    N, H, W, Cc = 2, 64, 64, 256
+    N, H, W, Cc = 8, 64, 64, 256          # the CRE convolutions of the headline step: M = 32768 -> 256 x 128 tiles on the LDS-DMA kernel
     g = torch.Generator().manual_seed(31)
     x = torch.randn(N, H, W, Cc, generator=g)
     blob = torch.zeros(N, H, W)
-    blob[0, 10:22, 30:41] = torch.rand(12, 11, generator=g) * 0.9 + 0.1          # 3 % of the pixels, image 1 empty
+    blob[0, 10:22, 30:41] = torch.rand(12, 11, generator=g) * 0.9 + 0.1          # 3 % of image 0's pixels, the other images empty
     go = torch.randn(N, H, W, Cc, generator=g)
     old_math, old_min, old_skip = RF.conv_math(), RM._F16_MIN_PIXELS, RF._MASK_SKIP
     RF.set_conv_math(math)
@@ -392,6 +392,7 @@ def test_masked_conv_zero_tile_skip_is_bit_identical(RF, math, training):
                     conv, bn = conv.to(DEV), bn.to(DEV).train(training)
                     xg = x.to(DEV).requires_grad_(training)
                     RF.reset_arith()
+                    RF._SKIP_STATS = flags = []
                     scale = torch.full((1,), 2.0 ** -12, device=DEV)        # |x| < 2^3: x / scale < 2^15
                     with torch.set_grad_enabled(training):
                         out = RF.conv_bn_relu_op(RF.Operand(xg, scale=scale), conv, bn, RF.WeightCache(), training, in_scale=mask.to(DEV),
@@ -406,9 +407,19 @@ def test_masked_conv_zero_tile_skip_is_bit_identical(RF, math, training):
                                 bn.running_mean.clone(), bn.running_var.clone()]
                     torch.cuda.synchronize()
                     res.append(got)
+                    if skip:
+                        # not vacuous: the kernels that honour the flags ran (their scratch, preset to 255, now holds 0 = skip /
+                        # 1 = compute for every tile); tiles WERE skipped where the factor has zeros (mode 1, x * mask, under the blob
+                        # mask: zero outside the blob) and none where it has not (the 0.5 mask; mode 2, x * (1 - mask), with a blob < 1)
+                        fl = torch.cat([f.flatten() for f in flags]).cpu()
+                        written = fl[fl != 255]
+                        assert len(flags) >= 1 and written.numel() > 0, "no launch wrote tile flags: the skip path did not run"
+                        nskip = int((written == 0).sum())
+                        assert (nskip > 0) == (mask is blob and mode == 1), (mode, nskip, int(written.numel()))
                 for a, b in zip(*res):
                     assert torch.equal(a, b), (mode, float((a - b).abs().max()))
     finally:
+        RF._SKIP_STATS = None
         RF._MASK_SKIP = old_skip
         RF.set_conv_math(old_math)
         RM._F16_MIN_PIXELS = old_min
