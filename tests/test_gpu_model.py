@@ -879,6 +879,43 @@ def test_training_driver_learns_and_checkpoints(tmp_path):
     assert torch.equal(net2.state_dict()["cre.q.0.weight"].cpu(), ck["state_dict"]["cre.q.0.weight"])
 
 
+def test_gradient_fan_in_levels_agree():
+    """The gradient fan-in forms (rpnet_amd.modules._FANIN: 0 = autograd's pairwise adds, 1 = RF.FanOut / RF.SplitRows, 2 = the
+    default: both halves of the encoder output summed straight into their rows — RF.SplitFan — and the skip-connection gradients
+    added inside the max-pool backward — RF.PoolSkip): the same step under all three.  Logits and BatchNorm buffers are equal bit
+    for bit (the forward pass is the same launches); a sum of two gradients is the same fp32 number in either order, a sum of the 2 T
+    gradients of the query features is not, and the encoder below amplifies that 1e-7 (2.6e-6 at Conv1.conv.0) — every parameter
+    gradient within 2e-5 relative L2 of level 0's, those ABOVE the
+    query-feature fan-in (nothing sums more than two terms below it) bit for bit between levels 1 and 2."""
+    import rpnet_amd.modules as RM
+    cfg = load_cfg(3)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(203, 4, 128, DEV)
+    was = RM._FANIN
+    res = []
+    try:
+        for level in (0, 1, 2):
+            RM._FANIN = level
+            net = build(cfg, True)
+            out = net(si, fg, bg, qi, appr_query_labels=appr)
+            total_loss(out, ql, 1.0).backward()
+            torch.cuda.synchronize()
+            res.append((out["output"].detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                        {n: b.clone() for n, b in net.named_buffers()}))
+    finally:
+        RM._FANIN = was
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for n, b in res[0][2].items():
+            assert torch.equal(b, other[2][n]), n
+        assert set(other[1]) == set(res[0][1])
+        for n, g in res[0][1].items():
+            e = float((g.double() - other[1][n].double()).norm() / g.double().norm().clamp_min(1e-30))
+            assert e <= 2e-5, (n, e)
+    for n, g in res[1][1].items():
+        if n.startswith("cre."):
+            assert torch.equal(g, res[2][1][n]), n
+
+
 def test_async_weight_gradients_match():
     """Opt-in async weight gradients (second HIP stream, accumulated straight into the flat bucket) give the
     same gradients as the autograd-returned ones, incl. the parameters used T+1 times (CRE)."""
