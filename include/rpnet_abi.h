@@ -165,13 +165,9 @@ typedef struct rpnet_conv_desc {
        the packed weights, rpnet_pack_conv_weight_split; *acc_scale_x = the tensor scale of the activation operand).
        rpnet_conv_wgrad multiplies dW by *acc_scale_x * *acc_scale_dy (the scales of its two operands). */
     const float* acc_scale_col; const float* acc_scale_x; const float* acc_scale_dy;
-    /* optional (rpnet_conv_fwd used as the INPUT-GRADIENT launch of a layer whose single source x0 is the output of a
-       train-mode BatchNorm + ReLU with no other consumer — single destination, no out_scale / accumulate, whole tiles per
-       statistic group: rpnet_conv_stats_blocks(d) with d->groups = bnb_groups must be > 0): the reduction pass of THAT
-       BatchNorm's backward fused into this epilogue.  bnb_y: its saved pre-BatchNorm tensor [N*H*W][Cout]; bnb_stats:
-       [4][bnb_groups][Cout] = scale, shift, mean, invstd (the four outputs of rpnet_bn_stats, contiguous); outputs
-       bnb_partial [bnb_groups * rows][Cout][2] (sum dz m, sum dz m xhat) and bnb_pmax [same rows][Cout] (max |dz m|; may
-       be NULL) for rpnet_bn_bwd(given_partial, given_pmax, given_rows = rows) */
+    /* RESERVED, must be NULL / 0.  (Rounds 1 - 4 could run the reduction pass of the SOURCE layer's BatchNorm backward in this
+       launch's epilogue; measured slower than the separate pass every round — the strided reads of y and the fp64 sums cost the
+       matrix-bound kernel more than the pass saves — and removed in round 5; the fields stay so that the layout does not move.) */
     const float* bnb_y; const float* bnb_stats; double* bnb_partial; float* bnb_pmax; int bnb_groups;
     const float* acc_scale_x1;         /* optional (fp16 planes, two sources, rpnet_conv_fwd with taps == 1 and rpnet_conv_wgrad with
                                           taps == 1 only): the tensor scale of source x1 when it differs from source x0's
@@ -209,13 +205,8 @@ typedef struct rpnet_conv_desc {
        unless a weight or gradient is Inf / NaN. */
     const float* skip_mask; int skip_mode; int skip_halo; unsigned char* skip_ws;
     const unsigned char* tile_skip;    /* internal (set by the launcher): flags [M tiles], 0 = skip */
-    /* Optional (round 4, the one-plane fp16 arithmetic of BASELINE configs[4]): the pre-BatchNorm output y0 is written as 2-byte
-       codes instead of fp32 — y0 then points to Co0-channel fp16 rows, code = fp16((y - a[c]) * b[c]) with a = y_enc[c],
-       b = y_enc[y_enc_stride + c] per output channel (the caller derives them from the layer's RUNNING statistics before the
-       launch: a = running_mean, b = a power of two near 2^-4 / sqrt(running_var + eps), so that codes are O(1) whatever the
-       batch and fp16 cannot overflow below ~1e6 standard deviations; saturating).  BatchNorm is invariant under a per-channel
-       affine map of its input, so rpnet_bn_relu / rpnet_bn_bwd decode with (a, 1 / b) (their y_dec argument) and nothing else
-       changes; the fused statistics (stats_partial) still come from the fp32 accumulators.  Single destination, no eval affine. */
+    /* RESERVED, must be NULL / 0.  (Round 4 could write the pre-BatchNorm output as 2-byte codes here — measured neutral in time and
+       worse in error on BASELINE configs[4], removed in round 5; the fields stay so that the layout does not move.) */
     const float* y_enc; int y_enc_stride;
 } rpnet_conv_desc;
 
@@ -352,8 +343,7 @@ int rpnet_bn_eval_affine(const float* gamma, const float* beta, const float* run
  * [N, H/2, W/2, C], the full-resolution z is never written; rpnet_bn_bwd with the same pool_w takes dz of that pooled
  * shape, finds each window's first maximum (row, column scan order, as rpnet_maxpool2_bwd) again from y and writes dy at
  * full resolution (dy_split required, no given_partial). */
-/* y_dec != NULL (round 4): `y` holds the 2-byte codes a convolution wrote with rpnet_conv_desc.y_enc = (a, b); y_dec = (a, 1 / b):
- * a at [0 .. C), 1 / b at [y_dec_stride .. y_dec_stride + C) */
+/* y_dec / y_dec_stride: RESERVED, must be NULL / 0 (the decode side of rpnet_conv_desc.y_enc, removed in round 5) */
 int rpnet_bn_relu(const float* y, const float* scale, const float* shift, float* z, void* z_split, int planes,
                   const float* gamma, const float* beta, float* split_scale, int N, int HW, int C, int groups,
                   int pool_w, const float* y_dec, int y_dec_stride, rpnet_stream_t stream);
@@ -364,8 +354,8 @@ int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma, const floa
                  const float* mean, const float* invstd, float* dy, void* dy_split, int planes, float* split_scale,
                  float* dgamma, float* dbeta, int N, int HW, int C, int groups, int accumulate,
                  const double* given_partial, const float* given_pmax, int given_rows /* NULL, NULL, 0: the reduction pass
-                 runs here; else it already ran in the epilogue that produced dz (rpnet_conv_desc.bnb_*) */,
-                 int pool_w, void* workspace, size_t workspace_bytes, const float* y_dec /* as rpnet_bn_relu */, int y_dec_stride,
+                 runs here; else the caller made the sums itself (the first layer: rpnet_conv1_bn_bwd_partial) */,
+                 int pool_w, void* workspace, size_t workspace_bytes, const float* y_dec /* reserved */, int y_dec_stride,
                  rpnet_stream_t stream);
 
 /* conv + bias + ReLU without BatchNorm (vgg.Encoder, net/vgg.py:39-58) — backward pieces:

@@ -16,24 +16,13 @@ struct BnGeom {
     int rows_blk;  // rows per block
 };
 
-// The pre-BatchNorm tensor as the passes read it: fp32, or (round 4, the one-plane fp16 arithmetic) 2-byte codes
-// (y - a[c]) * b[c] written by the convolution's epilogue (rpnet_conv_desc.y_enc) and decoded here with dec = (a, 1 / b):
-// a [0 .. C), 1 / b [stride .. stride + C).  `off` = element offset of 4 consecutive channels starting at channel c.
+// The pre-BatchNorm tensor as the passes read it (fp32).  `off` = element offset of 4 consecutive channels starting at channel c.
+// (Round 4 could also hold it as 2-byte codes decoded here — measured neutral in time and worse in error, removed in round 5;
+// the y_dec arguments of rpnet_bn_relu / rpnet_bn_bwd are reserved and must be NULL.)
 struct YSrc {
-    const float* y;      // fp32 tensor, or the fp16 codes (dec != nullptr)
-    const float* dec;
-    int stride;
+    const float* y;
 };
-__device__ __forceinline__ f32x4 load_y4(const YSrc s, const size_t off, const int c) {
-    if (s.dec) {
-        using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
-        const h16x4 hv = *reinterpret_cast<const h16x4*>(reinterpret_cast<const _Float16*>(s.y) + off);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(s.dec + c), ib = *reinterpret_cast<const f32x4*>(s.dec + s.stride + c);
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (float)hv[k] * ib[k] + a[k];
-        return v;
-    }
+__device__ __forceinline__ f32x4 load_y4(const YSrc s, const size_t off, const int) {
     return *reinterpret_cast<const f32x4*>(s.y + off);
 }
 
@@ -789,8 +778,8 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
                              int pool_w, const float* y_dec, int y_dec_stride, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(y && scale && shift && (z || z_split), RPNET_ERR_ARG, "bn_relu: null pointer");
-    RPNET_REQUIRE(!y_dec || y_dec_stride >= C, RPNET_ERR_ARG, "bn_relu: y_dec_stride=%d < C=%d", y_dec_stride, C);
-    const YSrc ysrc{y, y_dec, y_dec_stride};      // y_dec != NULL: y holds fp16 codes (rpnet_conv_desc.y_enc)
+    RPNET_REQUIRE(!y_dec && !y_dec_stride, RPNET_ERR_ARG, "bn_relu: y_dec / y_dec_stride are reserved (must be NULL / 0)");
+    const YSrc ysrc{y};
     if (int rc = bn_check("bn_relu", N, HW, C, groups)) return rc;
     if (pool_w > 0) {      // + MaxPool2d(2, 2): z / z_split are [N, H/2, W/2, C]
         RPNET_REQUIRE(z_split && planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_ARG, "bn_relu: the pooled form writes split planes (planes=%d C=%d)", planes, C);
@@ -853,8 +842,8 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
                             size_t workspace_bytes, const float* y_dec, int y_dec_stride, rpnet_stream_t stream) {
     using namespace rpnet;
     (void)gamma;
-    RPNET_REQUIRE(!y_dec || y_dec_stride >= C, RPNET_ERR_ARG, "bn_bwd: y_dec_stride=%d < C=%d", y_dec_stride, C);
-    const YSrc ysrc{y, y_dec, y_dec_stride};      // y_dec != NULL: y holds fp16 codes (rpnet_conv_desc.y_enc)
+    RPNET_REQUIRE(!y_dec && !y_dec_stride, RPNET_ERR_ARG, "bn_bwd: y_dec / y_dec_stride are reserved (must be NULL / 0)");
+    const YSrc ysrc{y};
     RPNET_REQUIRE(dz && scale && shift && mean && invstd && dgamma && dbeta && workspace, RPNET_ERR_ARG, "bn_bwd: null pointer");
     // y may be NULL only where nothing reads it: the reduction already ran elsewhere (given_partial) and no dy is asked for
     RPNET_REQUIRE(y || (given_partial && !dy && !dy_split), RPNET_ERR_ARG, "bn_bwd: y is NULL but a pass that reads it was asked for");
@@ -905,7 +894,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         return check_launch("bn_bwd_pool");
     }
     if (given_partial) {
-        // the reduction pass already happened in the epilogue of the launch that produced dz (rpnet_conv_desc.bnb_*):
+        // the caller made the sums itself (the first layer without its pre-BatchNorm tensor: rpnet_conv1_bn_bwd_partial):
         // [groups * given_rows][C][2] sums (and [..][C] maxima for fp16 planes)
         RPNET_REQUIRE(given_rows > 0 && (!f16 || given_pmax), RPNET_ERR_ARG, "bn_bwd: given partial sums need their row count (and maxima for fp16 planes)");
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, given_partial, given_rows, R, C, groups, coef, dgamma, dbeta,

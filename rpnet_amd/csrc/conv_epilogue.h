@@ -156,29 +156,11 @@ __device__ __forceinline__ float conv_epilogue_store(const rpnet_conv_desc& d, f
                 }
             }
         }
-        if (d.y_enc) {
-            // the pre-BatchNorm tensor as fp16 codes (rpnet_conv_desc.y_enc): (v - a[c]) * b[c], saturating, 8-byte stores
-            _Float16* dst16 = reinterpret_cast<_Float16*>(dstb);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c4 = (q * 64 + lane) % (WN * 8);
-                const f32x4 ea = *reinterpret_cast<const f32x4*>(d.y_enc + cd0 + c4 * 4);
-                const f32x4 eb = *reinterpret_cast<const f32x4*>(d.y_enc + d.y_enc_stride + cd0 + c4 * 4);
-                if (RowMap::kAlwaysValid || orow[q] >= 0) {
-                    using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
-                    h16x4 hv;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) hv[k] = (_Float16)fminf(fmaxf((v4[q][k] - ea[k]) * eb[k], -65504.f), 65504.f);
-                    *reinterpret_cast<h16x4*>(dst16 + (size_t)orow[q] * Cd + cd0 + c4 * 4) = hv;
-                }
-            }
-        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c4 = (q * 64 + lane) % (WN * 8);
             if (RowMap::kAlwaysValid || orow[q] >= 0)
                 *reinterpret_cast<f32x4*>(dstb + (size_t)orow[q] * Cd + cd0 + c4 * 4) = v4[q];
-        }
         }
         __builtin_amdgcn_wave_barrier();
         if (ROWOPS && d.y_split) {
@@ -287,66 +269,6 @@ __device__ __forceinline__ void conv_epilogue(const rpnet_conv_desc& d, f32x16 (
     else if (!aff) amax = conv_epilogue_store<WM, WN, RowMap, false, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
     else if (!rowops) conv_epilogue_store<WM, WN, RowMap, true, false>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
     else amax = conv_epilogue_store<WM, WN, RowMap, true, true>(d, acc, rows, M, Cout, per_group, n0, wm, wn, li, h, slab, cso);
-    if (d.bnb_y) {
-        // This launch is the input gradient dz of a layer whose source is the output of a train-mode BatchNorm + ReLU with
-        // no other consumer: the reduction pass of THAT BatchNorm's backward (sum dz m, sum dz m xhat, max |dz m| per
-        // channel; m = its ReLU mask, xhat its normalised pre-activation, both recomputed from its saved y) happens here,
-        // on the tile that is still in registers, instead of in a separate pass over dz and y (rpnet_bn_bwd given_partial).
-        // One row per block tile, as the forward statistics; tiles never straddle a statistic group (host-checked).
-        // (single destination, no row factor / accumulate / eval affine: dz = acc * scale + bias)
-        constexpr int BNC = 64 * WN;
-        double* red = reinterpret_cast<double*>(lds);                       // [WGM][BNC][2]
-        float* redm = reinterpret_cast<float*>(red + WGM * BNC * 2);       // [WGM][BNC]
-        __syncthreads();                                   // every wave is done with its slab
-        const int G = d.bnb_groups, gper = (d.N / G) * HW;
-        const int g = rows(0) / gper;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + wn * WN * 32 + j * 32 + li;
-            const float bv = d.bias ? d.bias[col] : 0.f;
-            const float as = d.acc_scale_col ? d.acc_scale_col[col] * xs : xs;
-            const float sc = d.bnb_stats[(0 * G + g) * Cout + col], sh = d.bnb_stats[(1 * G + g) * Cout + col];
-            const float mu = d.bnb_stats[(2 * G + g) * Cout + col], is = d.bnb_stats[(3 * G + g) * Cout + col];
-            double s1 = 0.0, s2 = 0.0;
-            float mx = 0.f;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rows(wm * WM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    if (row >= 0) {
-                        const float yv = d.bnb_y[(size_t)row * Cout + col];
-                        const float dm = (yv * sc + sh > 0.f) ? acc[i][j][r] * as + bv : 0.f;
-                        s1 += dm;
-                        s2 += (double)dm * ((yv - mu) * is);
-                        mx = fmaxf(mx, fabsf(dm));
-                    }
-                }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (h == 0) {
-                const int cl = wn * WN * 32 + j * 32 + li;
-                red[((size_t)wm * BNC + cl) * 2] = s1;
-                red[((size_t)wm * BNC + cl) * 2 + 1] = s2;
-                redm[wm * BNC + cl] = mx;
-            }
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < BNC; e += WGM * 128) {
-            double a1 = 0.0, a2 = 0.0;
-            float m = 0.f;
-#pragma unroll
-            for (int r = 0; r < WGM; ++r) {
-                a1 += red[((size_t)r * BNC + e) * 2];
-                a2 += red[((size_t)r * BNC + e) * 2 + 1];
-                m = fmaxf(m, redm[r * BNC + e]);
-            }
-            d.bnb_partial[((size_t)tm * Cout + n0 + e) * 2] = a1;
-            d.bnb_partial[((size_t)tm * Cout + n0 + e) * 2 + 1] = a2;
-            if (d.bnb_pmax) d.bnb_pmax[(size_t)tm * Cout + n0 + e] = m;
-        }
-    }
     if (d.out_absmax) {      // max |output| of the launch: one order-independent atomic per wave (values >= 0: uint order = float order)
         // and only where it would raise the stored value (it only grows: a stale read costs a redundant atomic, never a
         // maximum) — same-address atomics serialise in L2 at ~11 ns each, 16 K waves of a 256^2-level launch = 0.17 ms

@@ -276,9 +276,8 @@ extern "C" int rpnet_conv_fwd(const rpnet_conv_desc* d, rpnet_stream_t stream) {
                   "conv_fwd: y_split needs a single destination and 1 to 3 planes");
     RPNET_REQUIRE(!d->y_split || d->split_out_planes == 3 || d->y_split_scale, RPNET_ERR_ARG,
                   "conv_fwd: fp16 output planes (split_out_planes 1 / 2) need y_split_scale");
-    RPNET_REQUIRE(!d->y_enc || (d->Co1 == 0 && !d->accumulate && !d->ep_scale && !d->ep_relu && !d->out_scale_mode && !d->y_split &&
-                                !d->splitk_ws && !d->out_absmax && d->y_enc_stride >= Cout),
-                  RPNET_ERR_ARG, "conv_fwd: fp16 codes of the output (y_enc) go with a single plain destination only");
+    RPNET_REQUIRE(!d->y_enc && !d->y_enc_stride, RPNET_ERR_ARG, "conv_fwd: y_enc / y_enc_stride are reserved (must be NULL / 0)");
+    RPNET_REQUIRE(!d->bnb_y && !d->bnb_stats && !d->bnb_partial && !d->bnb_pmax, RPNET_ERR_ARG, "conv_fwd: the bnb_* fields are reserved (must be NULL)");
     RPNET_REQUIRE((long)d->N * d->H * d->W < (1L << 31), RPNET_ERR_SHAPE, "conv_fwd: too many pixels");
     RPNET_REQUIRE((size_t)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * 4 < (1UL << 31) &&
                       (size_t)d->taps * Cin * Cout * 4 < (1UL << 31),

@@ -450,9 +450,9 @@ class Operand:
              f16x2 / f16 mode runs on three bf16 planes, and the launch counters (arith_counts) show it.
     A tensor derived from x whose values are a subset of x's (max-pool, a batch slice, an alias) keeps the bound:
     `derive`."""
-    __slots__ = ("x", "p16", "pbf", "scale", "planes_only", "bn_ref", "deferred", "masked")
+    __slots__ = ("x", "p16", "pbf", "scale", "planes_only", "deferred", "masked")
 
-    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False, bn_ref=None, deferred=None, masked=None):
+    def __init__(self, x, p16=None, pbf=None, scale=None, planes_only=False, deferred=None, masked=None):
         self.x, self.p16, self.pbf, self.scale = x, p16, pbf, scale
         # deferred (train-mode cre.q, conv_bn_relu_op(defer_act=True)): (y, batch scale, batch shift) — x is still UNWRITTEN, the
         # consumer (CosineMatchUp's fused launch) applies BatchNorm + ReLU and fills it
@@ -460,10 +460,6 @@ class Operand:
         # masked: (mask tensor, mode, planes) — the operand planes of x * mask (mode 1) / x * (1 - mask) (mode 2) already exist
         # (written by the previous iteration's fused glue launch); a convolution gathering x with that very mask takes them
         self.masked = masked
-        # bn_ref (only on a planes_only operand, i.e. a BatchNorm output with exactly one consumer): the producer's saved
-        # pre-BatchNorm tensor and statistics, so that the consumer's input-gradient launch can run the reduction pass of
-        # the producer's BatchNorm backward in its epilogue (BnRef)
-        self.bn_ref = bn_ref
         # planes_only: x is a shape-only placeholder for autograd (a zero-storage expanded tensor) — its fp32 values were
         # never written because the single consumer reads p16 (conv_bn_relu_op(z_unused=True)); reading x is an error
         self.planes_only = planes_only
@@ -483,22 +479,6 @@ class Operand:
         return Operand(x, scale=self.scale)
 
 
-class BnRef:
-    """Link between a train-mode conv + BatchNorm + ReLU layer and the ONE convolution that consumes its output: the
-    consumer's backward (which runs first) leaves the BatchNorm-backward partial sums it computed in its dgrad epilogue
-    here (`fused` = (partial, pmax, rows, data_ptr of the dz tensor they belong to)), the producer's backward picks them
-    up instead of running its own reduction pass."""
-    __slots__ = ("y", "stats", "groups", "fused")
-
-    def __init__(self, y, stats, groups):
-        self.y, self.stats, self.groups, self.fused = y, stats, groups, None
-
-
-# the BatchNorm-backward reduction in the consumer's dgrad epilogue: OFF by default — measured on one box, two runs each:
-# 364.3 / 364.2 pairs/s with it against 367.0 / 366.5 without (the 64 strided reads of y per lane and the fp64 sums in
-# the epilogue of the matrix-bound kernel cost more than the pass over dz and y of the seven eligible layers saves: conv
-# launches 317 instead of 331 TF).  RPNET_BNBWD_FUSE=1 switches it on; tests/test_gpu_model.py keeps it correct.
-_BNBWD_FUSE = os.environ.get("RPNET_BNBWD_FUSE", "0") == "1"
 # async weight gradients go out behind a dgrad (ConvBnRelu.backward): 1 = their own layer's, d = the one d - 1 layers further
 # down the chain (a deeper backlog of MFMA-bound work beside the chain's HBM-bound passes); 0 = in front of their own
 _WGRAD_DEFER = int(os.environ.get("RPNET_WGRAD_DEFER", "1"))
@@ -523,42 +503,6 @@ _UP4 = os.environ.get("RPNET_UPCONV_COLLAPSE", "1") == "1"
 # dense launch.  The support mask covers 2 - 15 % of the pixels, so most tiles of w_k go.  bench.py keeps the HEADLINE dense
 # (the roofline accounting is algorithmic) and reports this as its own leg.  RPNET_MASK_SKIP=0: off
 _MASK_SKIP = os.environ.get("RPNET_MASK_SKIP", "1") == "1"
-
-
-# The one-plane fp16 arithmetic (BASELINE configs[4]) stores the pre-BatchNorm tensor of a conv + BatchNorm + ReLU layer as 2-byte
-# codes (rpnet_conv_desc.y_enc): code = fp16((y - a[c]) * b[c]) with a = the layer's running mean and b = a power of two near
-# 2^-4 / sqrt(running variance + eps), both taken BEFORE the forward pass — so the codes are O(1) whatever the batch (fp16 cannot
-# overflow below ~1e6 standard deviations, and saturates there), with no data-dependent scale and nothing to redo.  BatchNorm does
-# not care about a per-channel affine map of its input: the passes decode with (a, 1 / b) and everything else — the statistics
-# from the fp32 accumulators, the ReLU mask, the gradients — is as before.  What it buys: the tensor is written once and read
-# three times (BatchNorm + ReLU, both passes of the backward) at 2 instead of 4 bytes.
-# MEASURED AND OFF (round 4): configs[4] 34.11 / 34.32 ms per step with the codes against 34.21 / 34.22 without (one box, two
-# alternations: the passes it shortens already run beside the other chain's convolutions), and the decoded tensor flips
-# enough ReLU / window decisions to move a layer's input gradient by 9e-3 (relative L2) against the fp32 tensor.  RPNET_Y16=1
-# switches it on.
-_Y16 = os.environ.get("RPNET_Y16", "0") == "1"
-_YCODE = {}            # running_mean.data_ptr() -> (enc [2, S], dec [2, S], offset, S); rebuilt by y_codes_begin per forward
-
-
-def y_codes_begin(bns):
-    """RP_Net.forward (training, "f16" arithmetic): the codes of every BatchNorm module of `bns` from its running statistics as
-    they are NOW, a handful of small launches for the whole model; y_codes_end() drops them."""
-    _YCODE.clear()
-    bns = [b for b in bns if getattr(b, "running_mean", None) is not None and b.running_mean.is_cuda]
-    if not (_Y16 and bns):
-        return
-    rm = torch.cat([b.running_mean.detach().float() for b in bns])
-    rv = torch.cat([b.running_var.detach().float() for b in bns])
-    b2 = torch.exp2(torch.round(torch.log2(0.0625 * torch.rsqrt(rv + BN_EPS))))
-    enc, dec = torch.stack([rm, b2]), torch.stack([rm, 1.0 / b2])
-    off, S = 0, rm.numel()
-    for b in bns:
-        _YCODE[b.running_mean.data_ptr()] = (enc, dec, off, S)
-        off += b.running_mean.numel()
-
-
-def y_codes_end():
-    _YCODE.clear()
 
 
 _SKIP_STATS = None     # diagnostic (bench.py): a list that receives every launch's flag buffer (preset to 255 = "no tile here")
@@ -973,11 +917,7 @@ class ConvBnRelu(Function):
         recomp = bool(first and _CONV1_RECOMP and f16_mode() and cout % 8 == 0 and 256 % (cout // 8) == 0 and out_split is True
                       and produced.get("z_unused") and not produced.get("pool_req") and _CONV1_BN_FUSE
                       and query("rpnet_conv1_stats_blocks", N, H, W, cout, groups) > 0)
-        # fp16 codes of y (see _YCODE): the one-plane arithmetic, a module whose codes RP_Net.forward prepared, fused statistics
-        ycode = _YCODE.get(running_mean.data_ptr()) if (not first and running_mean is not None and _MATH["f16_planes"] == 1
-                                                         and f16_mode() and cout % 64 == 0) else None
-        y = None if recomp else (torch.empty((N, H, W, cout), device=x0.device, dtype=torch.float16) if ycode is not None
-                                 else _empty((N, H, W, cout), x0))
+        y = None if recomp else _empty((N, H, W, cout), x0)
         stats = _empty((4, groups, cout), x0)  # scale, shift, mean, invstd
         fused, xs, sx, sx1 = 0, None, None, None
         if first:      # batch statistics out of the same launch (one partial row per block and group)
@@ -1015,13 +955,6 @@ class ConvBnRelu(Function):
             if fused:  # batch statistics come out of the conv epilogue: y is not re-read
                 part = torch.empty(groups * fused * cout * 2, device=x0.device, dtype=torch.float64)
                 d.stats_partial = ptr(part)
-            if ycode is not None and (not fused or d.split_planes != 1 or up4):
-                ycode = None          # the separate statistics pass (rpnet_bn_stats) reads fp32: this layer keeps its fp32 tensor
-                y = _empty((N, H, W, cout), x0)
-                d.y0 = ptr(y)
-            if ycode is not None:
-                d.y_enc, d.y_enc_stride = ycode[0].data_ptr() + 4 * ycode[2], ycode[3]
-                ARITH[("pre_bn_tensor", "fp16 codes")] += 1
             if up4:
                 _cup4(d, 1)
             else:
@@ -1061,9 +994,7 @@ class ConvBnRelu(Function):
             # max-pool reads it)
             z = torch.empty(1, device=x0.device, dtype=torch.float32).expand(N, Hz, Wz, cout)
             produced["planes_only"] = True
-            if not pool and out_split is True and not recomp and ycode is None:
-                produced["bn_ref"] = BnRef(y, stats, groups)
-        defer = (bool(produced.get("defer_act")) and not pool and not np_out and not want16 and not recomp and ycode is None
+        defer = (bool(produced.get("defer_act")) and not pool and not np_out and not want16 and not recomp
                  and groups == 1 and not produced.get("planes_only"))
         if defer:
             # BatchNorm + ReLU are applied by the consumer's fused launch (CosineMatchUp, rpnet_refine_glue_fwd), which fills z
@@ -1076,10 +1007,9 @@ class ConvBnRelu(Function):
             ARITH[("bn_relu", "first layer made again from the image")] += 1
         else:
             # the tensor scale comes out of the same launch: with the fp16 planes, or alone (np_out == 0, "scale")
-            ydec = (ycode[1].data_ptr() + 4 * ycode[2], ycode[3]) if ycode is not None else (None, 0)
             call("rpnet_bn_relu", ptr(y), ptr(stats[0]), ptr(stats[1]), None if produced.get("planes_only") else ptr(z), ptr(zs),
                  np_out, ptr(gamma), ptr(beta),
-                 ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0, ydec[0], ydec[1])
+                 ptr(sz) if want16 else None, N, H * W, cout, groups, W if pool else 0, None, 0)
         if pool:
             ARITH[("bn_relu", "with the 2x2 max-pool")] += 1
         if want16 and np_out:
@@ -1091,12 +1021,9 @@ class ConvBnRelu(Function):
         _tap("fwd:y,stats", weight, y, stats)
         ctx.save_for_backward(x0, x1, in_scale, weight, gamma, y, stats)
         ctx.yshape = (N, H, W, cout)
-        ctx.ycode = None if (recomp or ycode is None) else (ycode[1], ycode[2], ycode[3])      # the decode pair outlives _YCODE
         ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
         ctx.up4 = (not first) and up4
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
-        ctx.bn_ref = produced.get("bn_ref")                                 # this layer as a producer
-        ctx.src_bn = op0.bn_ref if (op0.planes_only and _BNBWD_FUSE) else None   # this layer as the single consumer
         return z
 
     @staticmethod
@@ -1154,22 +1081,13 @@ class ConvBnRelu(Function):
             raise RuntimeError("rpnet_amd: the pooled BatchNorm backward needs dy as split planes and the pooled gradient")
         direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
-        # the reduction pass may already have run in the epilogue of the launch that produced dz (the single consumer's
-        # input gradient: BnRef) — taken only if dz is that very tensor
-        gp = gm_ = None
-        grows = 0
-        fz = ctx.bn_ref.fused if ctx.bn_ref is not None else None
-        if fz is not None and fz[3] == dz.data_ptr():
-            gp, gm_, grows = fz[0], fz[1], fz[2]
-        if ctx.bn_ref is not None:
-            ctx.bn_ref.fused = None
-        ARITH[("bn_bwd", "reduction in the consumer's dgrad epilogue" if gp is not None else "own reduction pass")] += 1
+        ARITH[("bn_bwd", "own reduction pass")] += 1
         if direct:
             _order_wait(gamma.data_ptr())  # gamma.grad / beta.grad: after the other chain's accumulation into them
         call("rpnet_bn_bwd", ptr(dz), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]),
              ptr(dy), ptr(dys), np_ if dys is not None else 0, ptr(sdy), ptr(gamma.grad if direct else dgamma),
-             ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, ptr(gp), ptr(gm_), grows,
-             W if ctx.pool else 0, ptr(ws), wsb, *((ctx.ycode[0].data_ptr() + 4 * ctx.ycode[1], ctx.ycode[2]) if ctx.ycode else (None, 0)))
+             ptr(beta.grad if direct else dbeta), N, H * W, cout, groups, 1 if direct else 0, None, None, 0,
+             W if ctx.pool else 0, ptr(ws), wsb, None, 0)
         if direct:
             _order_done(gamma.data_ptr())
         _tap("bn_bwd:dz,dy,dys,sdy,ws", weight, dz, dy, dys, sdy, ws)
@@ -1281,18 +1199,6 @@ class ConvBnRelu(Function):
                         dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
                         if pw.taps == 9 and x1 is None and not upsample and not need_s:
                             _set_skip(dd, in_scale, in_mode, 0, N, H, W)
-                    sb = ctx.src_bn
-                    if sb is not None and x1 is None and in_scale is None and not upsample and sb.y.shape == g0.shape:
-                        dd.groups = sb.groups
-                        rows = query("rpnet_conv_stats_blocks", C.byref(dd))
-                        if rows > 0:      # whole tiles per statistic group: the producer's BatchNorm-backward sums from this epilogue
-                            bp = torch.empty(sb.groups * rows * c0 * 2, device=y.device, dtype=torch.float64)
-                            bm = torch.empty(sb.groups * rows * c0, device=y.device, dtype=torch.float32)
-                            dd.bnb_y, dd.bnb_stats, dd.bnb_partial, dd.bnb_pmax = ptr(sb.y), ptr(sb.stats), ptr(bp), ptr(bm)
-                            dd.bnb_groups = sb.groups
-                            sb.fused = (bp, bm, rows, g0.data_ptr())
-                        else:
-                            dd.groups = 1
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
@@ -1347,7 +1253,7 @@ def conv_bn_relu_op(x0, conv, bn, cache, training, x1=None, in_scale=None, in_mo
                          bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None, pw, training, groups,
                          1 if upsample else 0, in_mode, out_split, (op0, op1), produced)
     out = Operand(z, produced.get("p16"), produced.get("pbf"), produced.get("scale"), bool(produced.get("planes_only")),
-                  produced.get("bn_ref"), produced.get("deferred"))
+                  produced.get("deferred"))
     if pool and not produced.get("pooled"):
         out = maxpool2(out)
     return out

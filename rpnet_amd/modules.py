@@ -36,13 +36,13 @@ _CRE_STREAMS = os.environ.get("RPNET_CRE_STREAMS", "1") != "0"
 _CRE_STREAMS_MAX_PIXELS = int(os.environ.get("RPNET_CRE_STREAMS_MAX_PIXELS", "16384"))
 # train-mode CRE: w_q (convolution, BatchNorm + ReLU and, through autograd, their backward) on its own HIP stream beside
 # w_k: each branch's HBM-bound BatchNorm passes run beside the other branch's convolution — 18.11 -> 17.87 ms per batch-8
-# step, configs[4] 33.65 -> 33.34 ms (two alternations on one box, tools/ab_overlap.py); same kernels, same bits.
+# step, configs[4] 33.65 -> 33.34 ms (two alternations on one box, round 3); same kernels, same bits.
 # RPNET_CRE_STREAMS_TRAIN=0: both branches on the caller's stream (A/B switch)
 _CRE_STREAMS_TRAIN = os.environ.get("RPNET_CRE_STREAMS_TRAIN", "1") == "1"
 # train-mode encoder: the support and the query call as two chains on two streams: 0 = never, 1 (default) = when they are
 # separate calls anyway (multi-shot / multi-way) AND of comparable length (support images <= 2 x query images), 2 = always,
 # also for 1-way 1-shot (two half-size launches per layer instead of one).  Measured, two alternations on one box
-# (tools/ab_overlap.py): configs[4] (2-way 512^2: 8 + 4 images) 33.81 -> 33.02 ms; configs[2] (5-shot: 80 + 16 images, the
+# (round 3): configs[4] (2-way 512^2: 8 + 4 images) 33.81 -> 33.02 ms; configs[2] (5-shot: 80 + 16 images, the
 # query chain ends after a fifth of the support chain) 84.3 -> 85.0 ms; configs[1] in two half-size launches per layer
 # 17.95 -> 18.54 ms (the 16^2 / 32^2 levels no longer fill the machine) — hence the default
 # (mode 3 of round 4 — only the 256^2 .. 64^2 levels as two chains — measured 17.73 against 17.55 ms and was removed in round 5)
@@ -470,11 +470,6 @@ class RP_Net(nn.Module):
                 pred_key = (self._serial, RF.conv_math(), ns, B, H, W, self.num_iter, n_ways, n_shots, self.forced_masks is not None)
                 RF.pred_begin(supp.device, pred_key, allow=not getattr(self, "_pred_redo", False))
         planes = RF.pack_planes()
-        # the one-plane fp16 arithmetic in training: the pre-BatchNorm tensors as 2-byte codes (RF._YCODE)
-        if self.training and supp.is_cuda and RF.f16_mode() and planes == 1:
-            RF.y_codes_begin(self._bn_modules())
-        else:
-            RF.y_codes_end()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
             # (training: the two up_conv layers on their collapsed four-tap packs, RF._UP4)
@@ -632,13 +627,6 @@ class RP_Net(nn.Module):
             finally:
                 self._pred_redo = False
         return {"output": output, "align_loss": align_loss, "refinement": refinement}
-
-    def _bn_modules(self):
-        bl = getattr(self, "_bn_list", None)
-        if bl is None:
-            bl = self._bn_list = [m for m in list(self.encoder.modules()) + [self.cre.w_k[1], self.cre.w_q[1], self.cre.q[1]]
-                                  if isinstance(m, nn.BatchNorm2d)]
-        return bl
 
     def _pack_weights(self):
         ws = getattr(self, "_pack_list", None)

@@ -329,34 +329,6 @@ def test_eval_call_full_size_all_paths_agree():
             assert rel_err(out["refinement"][i], g[i]) <= 1e-6, i
 
 
-def test_bn_bwd_reduction_in_dgrad_epilogue(monkeypatch):
-    """rpnet_conv_desc.bnb_*: the first layer of each of the seven conv_blocks has ONE consumer, whose input-gradient
-    launch can run the reduction pass of that layer's BatchNorm backward in its epilogue (off by default: measured
-    slower, rpnet_amd/functional.py).  Switched on, the step must give the same gradients as the separate pass."""
-    from rpnet_amd import functional as RF
-    from rpnet_amd import modules as RM
-    RM._F16_MIN_PIXELS = 0
-    cfg = load_cfg(2)
-    (si, fg, bg, qi, ql, appr), _ = episode_tensors(321, 4, 128, DEV)
-    grads = {}
-    for fuse in (False, True):
-        monkeypatch.setattr(RF, "_BNBWD_FUSE", fuse)
-        net = build(cfg, True)
-        RF.reset_arith()
-        out = net(si, fg, bg, qi, appr_query_labels=appr)
-        total_loss(out, ql, 1.0).backward()
-        counts = dict(RF.arith_counts()["bn_bwd"])
-        # (Conv1.conv.0 on fp16 planes keeps no pre-BatchNorm tensor: its reduction pass makes it again from the image and is
-        # neither of the two forms below — one eligible layer less for the fused form)
-        first = counts.pop("first layer made again from the image", 0)
-        assert first in (0, 1)
-        assert counts == ({"reduction in the consumer's dgrad epilogue": 7 - first, "own reduction pass": 18} if fuse else
-                          {"own reduction pass": 25 - first}), counts
-        grads[fuse] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
-    for n, gr in grads[False].items():
-        assert rel_l2(grads[True][n], gr) < 1e-5 or float(gr.abs().max()) < 1e-6, n
-
-
 @pytest.mark.parametrize("math", ["f16x2", "bf16x3", "f16"])
 def test_bn_relu_maxpool_in_one_pass(monkeypatch, math):
     """rpnet_bn_relu(pool_w) / rpnet_bn_bwd(pool_w): x1 and x2 of the encoder feed nothing but their MaxPool2d(2, 2)
