@@ -715,8 +715,12 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None, init_group=No
         # the OTHER way of issuing the step, 5 steps, so that the line carries both (eager + overlapped exchange / graph replay
         # + exposed exchange) whichever the probe chose
         other_ex = []
-        if pre_gts is None:
-            # no replay form without the graph captured before the group existed (gloo plumbing runs, RPNET_BENCH_DDP_GRAPH=0)
+        # On a real multi-GPU job the extra leg is opt-in (RPNET_BENCH_DDP_OTHER=1): graph replay beside RCCL communicators has only
+        # been exercised with ONE rank here (no multi-GPU lease in any round), and a crash in an informational leg would take the
+        # headline line with it.  The replay form stays captured: it is the fallback the probe above switches to when any rank's
+        # host cannot keep ahead of its GPU.
+        if pre_gts is None or (world > 1 and os.environ.get("RPNET_BENCH_DDP_OTHER", "0") != "1" and mode == "eager"):
+            # (also: no replay form without the graph captured before the group existed — gloo plumbing runs, RPNET_BENCH_DDP_GRAPH=0)
             other = None
         else:
             if mode == "eager":
