@@ -459,6 +459,8 @@ int conv_wgrad9_split(const rpnet_conv_desc* d, const void* dy, float* part9, in
 bool conv_wgrad9_dma_one_plane_ok(const rpnet_conv_desc* d, int M, int sps9);
 int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9,
                           hipStream_t s);
+bool conv_wgrad9_ring_ok(const rpnet_conv_desc* d, int M, int sps9);
+int conv_wgrad9_ring(const rpnet_conv_desc* d, const void* dy, float* part9, int M, int Cin, int Cout, int ks9, int sps9, hipStream_t s);
 void wgrad1_split_plan(int M, int Cin, int Cout, int* ksplit, int* steps_per_split);
 int conv_wgrad1_split(const rpnet_conv_desc* d, const void* dy, float* part, int M, int Cin, int Cout, int ks, int sps, hipStream_t s);
 
@@ -510,9 +512,15 @@ extern "C" int rpnet_conv_wgrad(const rpnet_conv_desc* d, const float* dy, float
                 // the register-staged 12-wave kernel of round 2 (A/B switch), 4 = its 4-wave layout
                 // (one fp16 plane: the same kernel with the two halves of a 64-pixel step in the two plane slots, where the
                 // image rows are at least that long — conv_wgrad9_dma_one_plane_ok)
-                const bool dma = (d->split_planes == 2 || conv_wgrad9_dma_one_plane_ok(d, M, sps9)) && d->tune != 8 && d->tune != 4;
-                if (int rc = dma ? conv_wgrad9_split_dma(d, dy, part9, M, Cin, Cout, ks9, sps9, s)
-                                 : conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s))
+                // round 6: where the images are power-of-two and at least a K-step wide, the same kernel with its K-steps walked
+                // down the image columns (conv_wgrad_ring.hip: every x strip fetched once; equal to rounding, not bit for bit);
+                // tune 16 keeps the row-major kernel (A/B switch)
+                const int tv = d->tune & 255;
+                const bool dma = (d->split_planes == 2 || conv_wgrad9_dma_one_plane_ok(d, M, sps9)) && tv != 8 && tv != 4;
+                const bool ring = dma && tv != 16 && conv_wgrad9_ring_ok(d, M, sps9);
+                if (int rc = ring ? conv_wgrad9_ring(d, dy, part9, M, Cin, Cout, ks9, sps9, s)
+                             : dma ? conv_wgrad9_split_dma(d, dy, part9, M, Cin, Cout, ks9, sps9, s)
+                                   : conv_wgrad9_split(d, dy, part9, M, Cin, Cout, ks9, sps9, s))
                     return rc;
             }
             if (!dw) return RPNET_OK;       // GEMM phase only: the partial sums stay in the workspace

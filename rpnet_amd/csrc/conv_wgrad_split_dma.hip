@@ -42,7 +42,9 @@ __device__ __forceinline__ void static_for_w(F&& f) {
 // K64: ONE fp16 plane (the f16 arithmetic of BASELINE configs[4]) in the same LDS geometry, as in conv_split_dma.hip: a
 // K-step is 64 pixels of one image row, whose two 32-pixel halves take the places of the two planes; the products are the
 // diagonal ones (half p of x with half p of dy): 18 MFMAs per wave and slice for the same 24 fragment reads.
-template <int NP, bool POW2, bool FAST, bool K64 = false>
+// ABL (tools/wgrad_anatomy.sh; results are then meaningless): 1 = only the centre x strip is fetched (the DMA count of a strip
+// ring), 2 = no DMA at all, 3 = no fragment reads, 4 = neither (MFMAs, barriers and waits only)
+template <int NP, bool POW2, bool FAST, bool K64 = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                   float* __restrict__ partial, const int M, const int Cin,
                                                                   const int Cout, const int tiles, const int tiles_n,
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     auto dma_x = [&](auto kyc, auto stagec, const int st) {
         constexpr int kyi = decltype(kyc)::value, stage = decltype(stagec)::value;
         constexpr int DST = stage * A_STAGE + kyi * BK * RB;
+        if constexpr (ABL == 2 || ABL == 4 || (ABL == 1 && kyi != 1)) return;
         int voff, soff;
         if constexpr (FAST) {
             const int qb0 = st * PXS + 8 * wv;                        // centre-row pixel of the piece; source = qb0 + (ky - 1) W
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     auto dma_y = [&](auto stagec, const bool fifth, const int st) {
         constexpr int stage = decltype(stagec)::value;
         constexpr int DST = BOFF + stage * B_STAGE;
+        if constexpr (ABL == 2 || ABL == 4) return;
         const int rowb = st * PXS - 1 + (fifth ? 32 : 8 * wv);      // first pixel of the piece (uniform): -1 for step 0, piece 0
         const bool neg = rowb < 0;
         const int soff = (neg ? 0 : rowb) * (Cout * 2) + n0 * 2;
@@ -171,6 +175,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     };
     // wave 0 issues (3 + 2) NP DMAs per step, the others (3 + 1) NP: "everything but the last step's" as a wait count
     auto wait_all_but_one_step = [&]() {
+        if constexpr (ABL == 2 || ABL == 4) return;
+        if constexpr (ABL == 1) {
+            if (wv == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            return;
+        }
         if (wv == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
@@ -213,6 +223,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     // krow + 4..).  Read k of a slice in order of first use (products l*h, h*l, h*h: the l plane of x and the h plane of dy
     // first): per plane pair x(ky 0), dy(kx 0..2), x(ky 1), x(ky 2) — two reads each.
     s16x4 afr[2][3][NP][2], bfr[2][3][NP][2];
+    if constexpr (ABL >= 3) {       // (the fragments are never read: give them defined, varying contents)
+#pragma unroll
+        for (int i = 0; i < 2 * 3 * NP * 2; ++i) {
+            (&afr[0][0][0][0])[i] = s16x4{(short)(lane + i), (short)(15360 + i), (short)lane, (short)i};
+            (&bfr[0][0][0][0])[i] = s16x4{(short)(lane * 3 + i), (short)(15361 + i), (short)(lane + 7), (short)(i * 5)};
+        }
+    }
     // [slice][kx][row half]: address of the dy read inside plane 0 of stage 0 (tile row or the zero row)
     const unsigned char* bsel[2][3][2];
     const unsigned char* bconst[2][3][2];
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value, stage = decltype(stagec)::value;
         constexpr int grp = k / 12, r = (k - grp * 12) >> 1, e = k & 1;      // plane pair, fragment of the pair, row half
         constexpr int pa = K64 ? grp : NP - 1 - grp, pb = grp;
+        if constexpr (ABL >= 3) return;
         if constexpr (r == 0 || r >= 4) {
             constexpr int ky = r == 0 ? 0 : r - 3;
             constexpr int off = (stage & 1) * A_STAGE + pa * A_PLANE + (ky * BK + 16 * s + 4 * e) * RB;
@@ -394,6 +412,15 @@ int conv_wgrad9_split_dma(const rpnet_conv_desc* d, const void* dy, float* part9
 #define RPNET_W9D(NPL, P2, FA)                                                                                                 \
     hipLaunchKernelGGL((conv_wgrad9_dma_kernel<NPL, P2, FA>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, \
                        tiles9, tiles_n9, ks9, sps9, P2 ? lw : 0, P2 ? lh : 0)
+    const int abl = (d->tune >> 8) & 7;
+    if (d->split_planes == 2 && fast && abl) {
+#define RPNET_W9A(A)                                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad9_dma_kernel<2, true, true, false, A>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, \
+                       Cout, tiles9, tiles_n9, ks9, sps9, lw, lh)
+        if (abl == 1) RPNET_W9A(1); else if (abl == 2) RPNET_W9A(2); else if (abl == 3) RPNET_W9A(3); else RPNET_W9A(4);
+#undef RPNET_W9A
+        return check_launch("conv_wgrad9_split_dma (ablation)");
+    }
     if (d->split_planes == 2) { if (fast) RPNET_W9D(2, true, true); else if (p2) RPNET_W9D(2, true, false); else RPNET_W9D(2, false, false); }
     else if (conv_wgrad9_dma_one_plane_ok(d, M, sps9)) {
         hipLaunchKernelGGL((conv_wgrad9_dma_kernel<2, true, true, true>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout,

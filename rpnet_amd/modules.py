@@ -364,8 +364,12 @@ class ContextCorrelationEncoder(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fm2 = w_q()
-            if two_train:        # read by the side stream (the caching allocator must not hand their blocks out before it is done)
-                for tns in (fq, mask, fts_scale):
+            if two_train or pre is not None:
+                # read by the side stream (the caching allocator must not hand their blocks out before it is done).  The operand
+                # planes `pre` come from the glue launch on the MAIN stream; w_q reads pre[1] on the side stream in forward and,
+                # through the saved operand of its weight gradient, in backward — with nothing else keeping it alive once the
+                # backward node has returned (round-5 advisor finding)
+                for tns in (fq, mask, fts_scale) + (tuple(pre) if pre is not None else ()):
                     if tns is not None:
                         tns.record_stream(side)
             fm1 = w_k()
@@ -574,13 +578,14 @@ class RP_Net(nn.Module):
         # fit (RF.CosineMatchUp / rpnet_refine_glue_fwd); a differentiable mask (soft_mask in training) keeps the separate path
         K = 1 + n_ways
         soft_grad = soft and torch.is_grad_enabled()
-        fuse = qry_d4.is_cuda and RF.glue_supported(K, h, w, H, W, 64) and not soft_grad
+        cq = self.cre.q[0].out_channels           # width of the relation features the glue matches against the prototypes
+        fuse = qry_d4.is_cuda and RF.glue_supported(K, h, w, H, W, cq) and not soft_grad
         # planes of the masked query features the two 3x3 convolutions of the NEXT call read: fp16 (the feature scale is known)
         # or three bf16; 0 = they gather fp32 values with the mask factor themselves
         xplanes = 0
         if fuse and RF.pack_planes() and qry_d4.shape[-1] % 64 == 0:
             xplanes = RF.pack_planes() if (RF.f16_mode() and s_qry is not None) else RF._MATH["planes"]
-            if not RF.glue_supported(K, h, w, H, W, 64, qry_d4.shape[-1], xplanes):
+            if not RF.glue_supported(K, h, w, H, W, cq, qry_d4.shape[-1], xplanes):
                 xplanes = 0
         pre = None
         for i in range(T):

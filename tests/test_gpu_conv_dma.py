@@ -165,18 +165,25 @@ def test_dma_patch_kernel_repeatable(RF, monkeypatch):
 
 
 @pytest.mark.parametrize("N,H,W,c0,c1,cout,ups", [
-    (2, 32, 32, 128, 0, 128, False),     # power-of-two image, 4 tiles, split-K over 64 K-steps
-    (1, 16, 64, 128, 128, 256, False),   # two sources (a tile lies in one of them)
+    (2, 32, 32, 128, 0, 128, False),     # power-of-two image, 4 tiles, split-K over 64 K-steps; one 32-pixel block per row
+    (1, 16, 64, 128, 128, 256, False),   # two sources (a tile lies in one of them); two blocks per row
     (2, 32, 64, 64, 0, 128, True),       # nearest x2: the x strips come from the half-resolution source
     (3, 16, 48, 128, 128, 128, False),   # W not a power of two (division path), odd image count
     (2, 8, 8, 64, 0, 64, False),         # M = 128: four K-steps in all — prologue and tail of the ring only
     (4, 4, 4, 128, 0, 64, False),        # image rows of 4 pixels (the deepest level of a 64 x 64 episode): a DMA piece spans two rows
     (2, 4, 8, 64, 0, 64, False),         # H != W, rows of exactly one piece
     (5, 24, 40, 64, 0, 192, False),      # M = 4800 = 150 K-steps, image rows wider than a K-step and not a multiple of it
+    (2, 64, 64, 64, 0, 64, False),       # one tile -> 32 splits of 8 steps: every split range begins and ends INSIDE an image column
+    (1, 16, 128, 64, 0, 128, False),     # four blocks per row (interior blocks have both neighbours), 16-row columns
+    (3, 8, 32, 64, 64, 64, False),       # odd image count, columns of 8 rows: more column changes than ring slots in a range
+    (2, 2, 32, 64, 0, 64, False),        # two-row images: every step has a zero strip above or below
+    (1, 1, 64, 64, 0, 64, False),        # one-row image: both neighbours zero in every step; two steps in all
 ])
 def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W, c0, c1, cout, ups):
-    """conv_wgrad9_dma_kernel (conv_wgrad_split_dma.hip) against the register-staged 12-wave kernel of round 2 (tune 8): same
-    tiles, split-K plan and order of accumulation -> bit-identical dW; and against the fp64 reference"""
+    """conv_wgrad9_dma_kernel (conv_wgrad_split_dma.hip, tune 16) against the register-staged 12-wave kernel of round 2 (tune 8):
+    same tiles, split-K plan and order of accumulation -> bit-identical dW.  The default of round 6 — the same kernel with its
+    K-steps walked down the image columns (conv_wgrad_ring.hip; power-of-two images at least 32 pixels wide, no up-sampling) —
+    sums a split's pixels in another order: equal to fp32 summation round-off.  All against the fp64 reference."""
     old = RF.conv_math()
     RF.set_conv_math("f16x2")
     try:
@@ -197,11 +204,26 @@ def test_dma_weight_gradient_bit_identical_and_accurate(RF, monkeypatch, N, H, W
         ref.backward(go.double())
         monkeypatch.setitem(RF.TUNE, "wgrad", 8)
         dw_old = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
+        monkeypatch.setitem(RF.TUNE, "wgrad", 16)
+        dw_row = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
         monkeypatch.setitem(RF.TUNE, "wgrad", 0)
         dw_new = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
         assert RF.arith_counts()["wgrad3x3"].get("f16x2", 0) >= 1
-        assert torch.equal(dw_old, dw_new)
+        assert torch.equal(dw_old, dw_row)
+        # (rows of exactly one K-step, W == 32, or one-row images: the column-major order IS the row-major order — the ring kernel
+        # then has to reproduce the row-major kernel's bits, which checks its strip ring, zero strips and waits against a known answer)
+        ring = (not ups) and W >= 32 and (W & (W - 1)) == 0 and (H & (H - 1)) == 0
+        if ring and (W == 32 or H == 1):
+            assert torch.equal(dw_row, dw_new)
+        elif ring:
+            assert not torch.equal(dw_row, dw_new)          # another kernel ran (another summation order)
+            assert rel_err(dw_new, dw_row) < 2e-6
+            again = _run(RF, monkeypatch, -1, layer, a, b, go, ups, groups)[4]
+            assert torch.equal(again, dw_new)               # (the ring's counted waits: a stale strip would show up here)
+        else:
+            assert torch.equal(dw_row, dw_new)
         assert rel_err(dw_new, c_ref.weight.grad) < 1e-3
+        assert rel_err(dw_new, c_ref.weight.grad) < 1.05 * rel_err(dw_row, c_ref.weight.grad) + 1e-6
     finally:
         RF.set_conv_math(old)
 
@@ -276,11 +298,13 @@ def test_dma_weight_gradient_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout):
         ref.backward(go.double())
         monkeypatch.setitem(RF.TUNE, "wgrad", 8)
         dw_old = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
-        monkeypatch.setitem(RF.TUNE, "wgrad", 0)
+        monkeypatch.setitem(RF.TUNE, "wgrad", 16)           # round 5's row-major K order
+        dw_row = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
+        monkeypatch.setitem(RF.TUNE, "wgrad", 0)            # round 6: K-steps down the image columns (conv_wgrad_ring.hip)
         dw_new = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
         assert RF.arith_counts()["wgrad3x3"].get("f16", 0) >= 1
-        assert not torch.equal(dw_old, dw_new)          # another kernel ran (another summation order)
-        assert rel_err(dw_new, dw_old) < 2e-6
+        assert not torch.equal(dw_old, dw_new) and not torch.equal(dw_row, dw_new)      # another kernel ran (another summation order)
+        assert rel_err(dw_new, dw_old) < 2e-6 and rel_err(dw_row, dw_old) < 2e-6
         # (one fp16 plane of dy behind a BatchNorm backward: per-element roundings of 2^-11 of the TENSOR maximum — the
         # error against fp64 is that of the arithmetic, the same for both kernels)
         e_new, e_old = rel_err(dw_new, c_ref.weight.grad), rel_err(dw_old, c_ref.weight.grad)

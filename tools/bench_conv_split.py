@@ -114,7 +114,9 @@ def wgrad(x, dy, pw, planes):
         d.split_planes = planes
         if planes == 2:
             d.acc_scale_x, d.acc_scale_dy = sx.data_ptr(), sdy.data_ptr()
-        args = (C.byref(d), ptr(dys), ptr(dw), ci, 0, ci, ci, ptr(ws), wb)
+        d.tune = (int(os.environ.get("WG_ABL", "0")) << 8) | int(os.environ.get("WG_TUNE", "0"))   # WG_TUNE=16: round 5's row-major K order      # ablation forms of conv_wgrad9_dma_kernel (tools/wgrad_anatomy.sh)
+        # WG_GEMM_ONLY=1: the split-K GEMM launch alone (dw == NULL: the two-phase form without its reduce)
+        args = (C.byref(d), ptr(dys), None if os.environ.get("WG_GEMM_ONLY") == "1" else ptr(dw), ci, 0, ci, ci, ptr(ws), wb)
         keep = (xs, dys, sx, sdy)
     else:
         d = _desc(x, None, pw.wp, None, None, 0, dy, None, N, H, W, 9, 0)

@@ -17,6 +17,20 @@ import rpnet_amd.modules as RM  # noqa: E402
 from rpnet_amd.parallel import FlatGradBucket  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+# CANARY_KEEPALIVE=1 (round 6): every tensor the host code allocates through torch's factory functions during a step stays referenced until
+# the step's device work has been synchronised — the caching allocator then cannot hand a block that one stream still reads to an
+# allocation of another stream.  Same kernels, same streams, same timing: if the fault goes away with this switch it is a host-side
+# lifetime race (the round-5 advisor's hypothesis); if it stays, it is not one of these tensors.
+_KEEP = []
+if os.environ.get("CANARY_KEEPALIVE") == "1":
+    def _wrap(fn):
+        def f(*a, **k):
+            out = fn(*a, **k)
+            _KEEP.append(out)
+            return out
+        return f
+    for _n in ("empty", "zeros", "ones", "full", "empty_like", "zeros_like", "ones_like", "stack", "cat", "tensor"):
+        setattr(torch, _n, _wrap(getattr(torch, _n)))
 RM._F16_MIN_PIXELS = 0
 RM._ENC_STREAMS = 1
 if os.environ.get("CANARY_TILE"):        # force a tile variant of rpnet_conv_fwd (13 = variant 12: the 64-wide LDS-DMA form, 116 - 120 KB of LDS)
@@ -36,7 +50,10 @@ def run(asyncw):
     if bucket is not None:
         bucket.allreduce()
     torch.cuda.synchronize()
-    return out["output"].detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    res = out["output"].detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    torch.cuda.synchronize()
+    _KEEP.clear()
+    return res
 
 
 print("env:", {k: v for k, v in os.environ.items() if k.startswith("RPNET_")})

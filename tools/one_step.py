@@ -30,8 +30,8 @@ torch.cuda.set_device(0)
 cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
 cfg["n_iter_refinement"] = a.iters
 RF.set_conv_math(a.conv_math)
-if a.serial:
-    RF.set_async_wgrad(False)
+# bench.py's default schedule: weight gradients on their side stream (RPNET_ASYNC_WGRAD=0 / --serial: through autograd on the main one)
+RF.set_async_wgrad(not a.serial and os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")
 net = bench.build_model(cfg, dev)
 bucket = FlatGradBucket(net)
 inp = bench.make_inputs(1234, a.batch, a.size, dev, a.shots, a.ways)
