@@ -105,14 +105,14 @@ def make_inputs(seed, B, size, dev, n_shots=1, n_ways=1):
 def step(net, bucket, inp, scaler, exposed=None):
     """exposed (N > 1): list that receives a (start, end) HIP-event pair around the part of the gradient exchange that is
     NOT hidden under backward — from the end of backward on the compute stream to the moment the averaged bucket is ready"""
-    from rpnet_amd.functional import dice_ce_sum
+    import rpnet_amd.functional as RF
     si, fg, bg, qi, ql, appr = inp
     bucket.zero()
     out = net(si, fg, bg, qi, appr_query_labels=appr)
-    # dice_ce of the final output and of every refinement iteration's output, summed (one multi-tensor launch pair)
-    loss = dice_ce_sum([out["output"], *out["refinement"].values()], ql)
-    loss = loss + scaler * out["align_loss"]
-    loss.backward()
+    # dice_ce of the final output and of every refinement iteration's output, summed, + scaler * align_loss: one launch pair
+    # (RF.objective: the values of `dice_ce_sum(...) + scaler * out["align_loss"]`, bit for bit)
+    loss = RF.objective([out["output"], *out["refinement"].values()], ql, out["align_loss"], scaler)
+    RF.backward(loss)
     if exposed is not None:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -773,11 +773,11 @@ def measure(w, world, rank, dev, cfg, steps, warmup, RF, ddp=None, init_group=No
 def graphed_step(net, bucket, scaler, exposed=None):
     """the bench step (same objective as `step`) as a rpnet_amd.graph.GraphedTrainStep (N > 1: the replay is followed by one
     all-reduce of the whole bucket, bracketed by a HIP-event pair appended to `exposed`)"""
-    from rpnet_amd.functional import dice_ce_sum
+    import rpnet_amd.functional as RF
     from rpnet_amd.graph import GraphedTrainStep
 
     def loss_fn(out, ql):
-        return dice_ce_sum([out["output"], *out["refinement"].values()], ql) + scaler * out["align_loss"]
+        return RF.objective([out["output"], *out["refinement"].values()], ql, out["align_loss"], scaler)
     return GraphedTrainStep(net, bucket, loss_fn, exposed=exposed)
 
 

@@ -51,7 +51,7 @@ enum rpnet_status {
  * rpnet_upconv_collapse_weights added; nothing existing changed).  A caller MUST zero-initialise rpnet_conv_desc (fields added
  * later are optional features that are off at zero) and SHOULD compare rpnet_version() with the RPNET_ABI_VERSION it was built
  * against. */
-#define RPNET_ABI_VERSION 105
+#define RPNET_ABI_VERSION 106
 int rpnet_version(void);
 const char* rpnet_last_error_string(void);
 
@@ -513,11 +513,24 @@ int rpnet_dice_ce_multi_fwd(const float* const* logits, int n, const int64_t* la
                             int K, int H, int W, void* workspace, size_t workspace_bytes, rpnet_stream_t stream);
 int rpnet_dice_ce_multi_bwd(const float* const* logits, float* const* dlogits, int n, const int64_t* labels,
                             const float* stats, const float* gscale, int B, int K, int H, int W, rpnet_stream_t stream);
+/* The whole training objective in the same two launches (round 6): total = sum_i weights[i] * dice_ce(logits[i], labels) +
+ * extra_scale * extra[0] — `weights` a HOST array of n multiplicities (the final output IS the last refinement iteration's output,
+ * net/rp_net.py:314-337: it is summed once with weight 2 instead of twice), `extra` a device scalar or NULL (the align loss,
+ * net/rp_net.py:394-440, with its yaml scaler `align_loss_scaler`).  loss: n + 1 floats as rpnet_dice_ce_multi_fwd (loss[n] = total;
+ * the products and the sum are formed as the tensor expression `sum + scaler * align` forms them: bit-identical).
+ * backward: dlogits[i] = gscale[0] * weights[i] * d dice_ce_i / d logits[i]; dextra[0] (optional) = gscale[0] * extra_scale. */
+int rpnet_objective_fwd(const float* const* logits, const float* weights, int n, const int64_t* labels, const float* extra,
+                        float extra_scale, float* loss, float* stats, int B, int K, int H, int W, void* workspace,
+                        size_t workspace_bytes, rpnet_stream_t stream);
+int rpnet_objective_bwd(const float* const* logits, float* const* dlogits, const float* weights, int n, const int64_t* labels,
+                        const float* stats, const float* gscale, float* dextra, float extra_scale, int B, int K, int H, int W,
+                        rpnet_stream_t stream);
 
 /* alignLoss pieces: arg-max class masks of the low-res prediction with their pixel
- * counts (net/rp_net.py:412-417) — masks [B][K][hw] (0/1), counts [B][K]; and the support
- * label map 1 = fore, 0 = back, 255 = ignore (net/rp_net.py:433-436). */
-int rpnet_argmax_masks(const float* pred, float* masks, float* counts, int B, int K, int hw, rpnet_stream_t stream);
+ * counts (net/rp_net.py:412-417) — masks [B][K][hw] (0/1), counts [B][K], keep [K][B] (optional; 1 where the count is positive:
+ * the per-episode skip of a way whose predicted mask is empty, net/rp_net.py:414,421, as the sample weight of rpnet_dice_ce_fwd);
+ * and the support label map 1 = fore, 0 = back, 255 = ignore (net/rp_net.py:433-436). */
+int rpnet_argmax_masks(const float* pred, float* masks, float* counts, float* keep, int B, int K, int hw, rpnet_stream_t stream);
 int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, size_t n, rpnet_stream_t stream);
 
 /* ------------------------------------------------- registration pre-step

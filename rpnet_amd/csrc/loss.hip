@@ -11,6 +11,7 @@ constexpr int kMaxCls = 4;
 constexpr int kMaxLogitSets = 16;   // logit tensors per multi-tensor launch (rpnet_dice_ce_multi_*)
 struct LogitSet { const float* p[kMaxLogitSets]; };
 struct GradSet { float* p[kMaxLogitSets]; };
+struct WeightSet { float w[kMaxLogitSets]; };      // multiplicity of each logit tensor in the objective (rpnet_objective_*)
 
 // partial[z][b][blk][2K+2] doubles: inter_k, card_k, ce_sum, count (z = blockIdx.z: which logit tensor of the set)
 __global__ __launch_bounds__(256) void dice_ce_partial(const LogitSet set, const int64_t* __restrict__ labels,
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void dice_ce_partial(const LogitSet set, const
 __global__ __launch_bounds__(1024) void dice_ce_final(const double* __restrict__ partial, float* __restrict__ stats,
                                                       float* __restrict__ loss, int B, int K, int nblk, int with_dice,
                                                       int per_sample, const float* __restrict__ sample_weight, int n,
-                                                      float* __restrict__ total) {
+                                                      float* __restrict__ total, const WeightSet wts,
+                                                      const float* __restrict__ extra, float extra_scale) {
     extern __shared__ double sums[];  // [B][S]
     const int S = 2 * K + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -90,24 +92,31 @@ __global__ __launch_bounds__(1024) void dice_ce_final(const double* __restrict__
                 l += 1.0 - d / (double)K;
             }
             loss[z] = (float)l;
-            all += (double)(float)l;       // the sum of the fp32 losses, as a chain of fp32 tensors' values would be added in fp64
+            all += (double)wts.w[z] * (double)(float)l;       // the sum of the fp32 losses, as a chain of fp32 tensors' values would be added in fp64
         }
         __syncthreads();                   // `sums` is rewritten by the next tensor
     }
-    if (threadIdx.x == 0 && total) total[0] = (float)all;
+    if (threadIdx.x == 0 && total) {
+        float tt = (float)all;
+        if (extra) tt = tt + extra_scale * extra[0];       // fp32 multiply, fp32 add: what `dice_sum + scaler * align_loss` does on tensors
+        total[0] = tt;
+    }
 }
 
 __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const LogitSet set, const int64_t* __restrict__ labels,
                                                            const float* __restrict__ stats_all, const float* __restrict__ gscale,
                                                            const GradSet gset, int B, int K, int HW, int with_dice,
                                                            int ignore_index, int per_sample,
-                                                           const float* __restrict__ sample_weight, int accumulate) {
+                                                           const float* __restrict__ sample_weight, int accumulate,
+                                                           const WeightSet wts, float* __restrict__ dextra, float extra_scale) {
     const int b = blockIdx.y;
     const int S = 2 * K + 2;
     const float* logits = set.p[blockIdx.z];
     float* dlogits = gset.p[blockIdx.z];
     const float* stats = stats_all + (size_t)blockIdx.z * (B + 1) * S;
-    const float gs = gscale ? gscale[0] : 1.f;
+    const float g0 = gscale ? gscale[0] : 1.f;
+    const float gs = g0 * wts.w[blockIdx.z];
+    if (dextra && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) dextra[0] = g0 * extra_scale;
     float ce_coef;
     if (per_sample) {
         const float wgt = sample_weight ? sample_weight[b] : 1.f;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const LogitSet set, co
 
 // alignLoss pieces (net/rp_net.py:412-417,433-436)
 __global__ __launch_bounds__(256) void argmax_masks_kernel(const float* __restrict__ pred, float* __restrict__ masks,
-                                                            float* __restrict__ counts, int K, int hw) {
+                                                            float* __restrict__ counts, float* __restrict__ keep, int K, int hw) {
     __shared__ double sm4[4];
     const int b = blockIdx.x;
     const float* p = pred + (size_t)b * K * hw;
@@ -168,7 +177,10 @@ __global__ __launch_bounds__(256) void argmax_masks_kernel(const float* __restri
     }
     for (int k = 0; k < K; ++k) {
         const double c = block_sum256(cnt[k], sm4);
-        if (threadIdx.x == 0) counts[b * K + k] = (float)c;
+        if (threadIdx.x == 0) {
+            counts[b * K + k] = (float)c;
+            if (keep) keep[(size_t)k * gridDim.x + b] = c > 0.0 ? 1.f : 0.f;       // [K][B]: a class's row is contiguous
+        }
     }
 }
 
@@ -179,6 +191,12 @@ __global__ void align_labels_kernel(const float* __restrict__ fore, const float*
         if (back[i] == 1.f) v = 0;
         lab[i] = v;
     }
+}
+
+static WeightSet ones_set() {
+    WeightSet w{};
+    for (int i = 0; i < kMaxLogitSets; ++i) w.w[i] = 1.f;
+    return w;
 }
 
 }  // namespace rpnet
@@ -200,7 +218,7 @@ extern "C" int rpnet_dice_ce_fwd(const float* logits, const int64_t* labels, flo
     set.p[0] = logits;
     hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B), dim3(256), 0, s, set, labels, (double*)workspace, K, H * W, ignore_index);
     hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, with_dice,
-                       per_sample, sample_weight, 1, (float*)nullptr);
+                       per_sample, sample_weight, 1, (float*)nullptr, ones_set(), (const float*)nullptr, 0.f);
     return check_launch("dice_ce_fwd");
 }
 
@@ -219,8 +237,30 @@ extern "C" int rpnet_dice_ce_multi_fwd(const float* const* logits, int n, const 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B, n), dim3(256), 0, s, set, labels, (double*)workspace, K, H * W, -1);
     hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, 1,
-                       0, (const float*)nullptr, n, loss + n);
+                       0, (const float*)nullptr, n, loss + n, ones_set(), (const float*)nullptr, 0.f);
     return check_launch("dice_ce_multi_fwd");
+}
+
+extern "C" int rpnet_objective_fwd(const float* const* logits, const float* weights, int n, const int64_t* labels, const float* extra,
+                                   float extra_scale, float* loss, float* stats, int B, int K, int H, int W, void* workspace,
+                                   size_t workspace_bytes, rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(logits && weights && labels && loss && stats && workspace, RPNET_ERR_ARG, "objective_fwd: null pointer");
+    RPNET_REQUIRE(n >= 1 && n <= kMaxLogitSets, RPNET_ERR_ARG, "objective_fwd: %d logit tensors (1..%d per call)", n, kMaxLogitSets);
+    RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "objective_fwd: K=%d", K);
+    RPNET_REQUIRE(workspace_bytes >= (size_t)n * rpnet_loss_workspace_bytes(B, K, H, W), RPNET_ERR_WORKSPACE, "objective_fwd: workspace");
+    LogitSet set{};
+    WeightSet wts{};
+    for (int i = 0; i < n; ++i) {
+        RPNET_REQUIRE(logits[i], RPNET_ERR_ARG, "objective_fwd: null logit tensor %d", i);
+        set.p[i] = logits[i];
+        wts.w[i] = weights[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dice_ce_partial, dim3(kLossBlocks, B, n), dim3(256), 0, s, set, labels, (double*)workspace, K, H * W, -1);
+    hipLaunchKernelGGL(dice_ce_final, dim3(1), dim3(1024), (size_t)B * (2 * K + 2) * sizeof(double), s, (const double*)workspace, stats, loss, B, K, kLossBlocks, 1,
+                       0, (const float*)nullptr, n, loss + n, wts, extra, extra_scale);
+    return check_launch("objective_fwd");
 }
 
 extern "C" int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gscale,
@@ -235,7 +275,7 @@ extern "C" int rpnet_dice_ce_bwd(const float* logits, const int64_t* labels, con
     set.p[0] = logits;
     gset.p[0] = dlogits;
     hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, set, labels, stats, gscale, gset,
-                       B, K, H * W, with_dice, ignore_index, per_sample, sample_weight, accumulate);
+                       B, K, H * W, with_dice, ignore_index, per_sample, sample_weight, accumulate, ones_set(), (float*)nullptr, 0.f);
     return check_launch("dice_ce_bwd");
 }
 
@@ -254,15 +294,37 @@ extern "C" int rpnet_dice_ce_multi_bwd(const float* const* logits, float* const*
     }
     int nb = cdiv(H * W, 256); if (nb > 256) nb = 256;
     hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B, n), dim3(256), 0, (hipStream_t)stream, set, labels, stats, gscale, gset,
-                       B, K, H * W, 1, -1, 0, (const float*)nullptr, 0);
+                       B, K, H * W, 1, -1, 0, (const float*)nullptr, 0, ones_set(), (float*)nullptr, 0.f);
     return check_launch("dice_ce_multi_bwd");
 }
 
-extern "C" int rpnet_argmax_masks(const float* pred, float* masks, float* counts, int B, int K, int hw, rpnet_stream_t stream) {
+extern "C" int rpnet_objective_bwd(const float* const* logits, float* const* dlogits, const float* weights, int n, const int64_t* labels,
+                                   const float* stats, const float* gscale, float* dextra, float extra_scale, int B, int K, int H, int W,
+                                   rpnet_stream_t stream) {
+    using namespace rpnet;
+    RPNET_REQUIRE(logits && dlogits && weights && labels && stats, RPNET_ERR_ARG, "objective_bwd: null pointer");
+    RPNET_REQUIRE(n >= 1 && n <= kMaxLogitSets, RPNET_ERR_ARG, "objective_bwd: %d logit tensors (1..%d per call)", n, kMaxLogitSets);
+    RPNET_REQUIRE(K >= 2 && K <= kMaxCls, RPNET_ERR_SHAPE, "objective_bwd: K=%d", K);
+    LogitSet set{};
+    GradSet gset{};
+    WeightSet wts{};
+    for (int i = 0; i < n; ++i) {
+        RPNET_REQUIRE(logits[i] && dlogits[i], RPNET_ERR_ARG, "objective_bwd: null tensor %d", i);
+        set.p[i] = logits[i];
+        gset.p[i] = dlogits[i];
+        wts.w[i] = weights[i];
+    }
+    int nb = cdiv(H * W, 256); if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(nb, B, n), dim3(256), 0, (hipStream_t)stream, set, labels, stats, gscale, gset,
+                       B, K, H * W, 1, -1, 0, (const float*)nullptr, 0, wts, dextra, extra_scale);
+    return check_launch("objective_bwd");
+}
+
+extern "C" int rpnet_argmax_masks(const float* pred, float* masks, float* counts, float* keep, int B, int K, int hw, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(pred && masks && counts, RPNET_ERR_ARG, "argmax_masks: null pointer");
     RPNET_REQUIRE(K >= 1 && K <= kMaxCls, RPNET_ERR_SHAPE, "argmax_masks: K=%d", K);
-    hipLaunchKernelGGL(argmax_masks_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, masks, counts, K, hw);
+    hipLaunchKernelGGL(argmax_masks_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, masks, counts, keep, K, hw);
     return check_launch("argmax_masks");
 }
 

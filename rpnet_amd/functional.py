@@ -108,8 +108,27 @@ def _tap(tag, weight, *tensors):
 
 
 def _direct(p):
-    return (_ASYNC["on"] and p is not None and p.grad is not None and p.grad.is_contiguous()
-            and not getattr(p, "_rpnet_autograd_grad", False))
+    if not (_ASYNC["on"] and p is not None and p.grad is not None and p.grad.is_contiguous()):
+        return False
+    tag = getattr(p, "_rpnet_autograd_grad", False)
+    if tag is False or tag is None:
+        return True
+    # tagged by a gradient bucket (rpnet_amd.parallel.FlatGradBucket): this parameter's AccumulateGrad hook launches a segment's
+    # all-reduce — only while there is an exchange to launch (a process group of more than one rank, hooks not suspended by a graph
+    # capture); otherwise the gradient goes straight into the bucket like every other (no AccumulateGrad add, no hook)
+    wants = getattr(tag, "wants_hooks", None)
+    return not (wants() if wants is not None else True)
+
+
+def _accumulate_direct(p, g):
+    """bucket mode: add a parameter gradient that a kernel could only WRITE (the first layer's direct weight gradient) into p.grad on the
+    producing stream — ordered against the other chain's accumulation into the same parameter — and hand autograd nothing; otherwise g"""
+    if not _direct(p):
+        return g
+    _order_wait(p.data_ptr())
+    p.grad.add_(g)
+    _order_done(p.data_ptr())
+    return None
 
 
 def use_compute_stream(device):
@@ -613,8 +632,9 @@ def _f16_sources(op0, op1, in_scale, in_mode, two_scales=False):
 class PackedWeight:
     """Packed copies of one nn.Conv2d weight (see rpnet_pack_conv_weight)."""
 
-    def __init__(self, weight, split=None):
+    def __init__(self, weight, split=None, pool=None):
         cout, cin, kh, kw = weight.shape
+        self._pool = pool         # WeightCache's store of PADDED pack buffers (their padding rows are written once, not per step)
         self.taps = kh * kw
         if split is None:
             self.off0, self.split, self.off1, self.cin_pad = 0, cin, cin, cin
@@ -687,8 +707,17 @@ class PackedWeight:
         if self.wps is None:
             self.wps = {}
         n = self.taps * self.cin_pad * self.cout
-        mk = torch.zeros if self.cin_pad != self.cin else torch.empty
+        padded = self.cin_pad != self.cin
         w = self._weight
+        # a padded pack (the 1x1 convolution over cat([corr, fm1]): 377 -> 384 rows) keeps its buffers across steps: the pack kernel
+        # writes the real rows only, the zero rows / unit scales of the padding are set once (three fill launches per step otherwise).
+        # Safe because a layer's packs are written and read in stream order step after step (prepack waits for the caller's stream)
+        key = (w.data_ptr(), tuple(w.shape), planes, self.cin_pad, self.off0, self.split, self.off1, str(w.device))
+        if padded and self._pool is not None and key in self._pool:
+            pk = self._pool[key]
+            self.wps[planes] = pk
+            return pk
+        mk = torch.zeros if padded else torch.empty
         dt = torch.bfloat16 if planes == 3 else torch.float16
         wps, wds = mk((planes, n), device=w.device, dtype=dt), mk((planes, n), device=w.device, dtype=dt)
         if planes == 3:
@@ -696,8 +725,10 @@ class PackedWeight:
         else:
             t = torch.empty(self.cout, device=w.device, dtype=torch.float32)
             # the kernel writes the scale of every real gathered row; only padding rows (none on the 3x3 layers) need a preset
-            u = (torch.ones if self.cin_pad != self.cin else torch.empty)(self.cin_pad, device=w.device, dtype=torch.float32)
+            u = (torch.ones if padded else torch.empty)(self.cin_pad, device=w.device, dtype=torch.float32)
             pk = (wps, wds, t, u)
+        if padded and self._pool is not None:
+            self._pool[key] = pk
         self.wps[planes] = pk
         return pk
 
@@ -709,6 +740,7 @@ class WeightCache:
     def __init__(self):
         self._d = {}
         self._ready = None          # (event, streams that already wait for it): the packs of prepack_async
+        self._padded = {}           # buffers of PADDED split packs, kept across clear() (PackedWeight.alloc_split)
 
     def clear(self):
         self._d.clear()
@@ -745,7 +777,7 @@ class WeightCache:
         key = (weight.data_ptr(), weight._version, None if split is None else tuple(split))
         pw = self._d.get(key)
         if pw is None:
-            pw = PackedWeight(weight.detach(), split)
+            pw = PackedWeight(weight.detach(), split, self._padded)
             self._d[key] = pw
         return pw
 
@@ -1062,6 +1094,7 @@ class ConvBnRelu(Function):
             coef = ws.data_ptr() + query("rpnet_bn_bwd_coef_offset", cout, groups)
             call("rpnet_conv1_wgrad_bn", ptr(x0), ptr(dz), None, ptr(stats), coef, ptr(dw), N, H, W, cout, groups, ptr(ws2), wb,
                  ptr(weight), ptr(bias))
+            dw = _accumulate_direct(weight, dw)
             db = None if _direct(bias) else torch.zeros_like(gamma)
             return None, None, None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         # which forms of dy the two consumers (wgrad, dgrad) want: split-bf16 planes and / or fp32
@@ -1102,6 +1135,7 @@ class ConvBnRelu(Function):
                      ptr(ws2), wb, None, None)
             else:
                 call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
+            dw = _accumulate_direct(weight, dw)
         else:
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)
@@ -1826,12 +1860,91 @@ def dice_ce_sum(logits, true):
     return total
 
 
-def argmax_masks(pred):
-    """pred [B,K,h,w] -> (masks [B,K,h*w] one-hot of argmax, counts [B,K]) (net/rp_net.py:412-415)."""
+class Objective(Function):
+    """The training objective in two launches forward, one backward (rpnet_objective_fwd / _bwd):
+    sum_i w_i dice_ce(logits_i, labels) + extra_scale * extra — w_i the multiplicity of tensor i in the caller's list (the final output IS
+    the last refinement iteration's output, net/rp_net.py:314-337), extra the align loss (net/rp_net.py:394-440) with the yaml's
+    align_loss_scaler.  Replaces DiceCESum + two scalar tensor operations + the autograd add of the duplicate's two gradients (and their
+    backward nodes): same values, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, labels, extra, extra_scale, weights, *logits):
+        B, K, H, W = logits[0].shape
+        logits = tuple(t.contiguous() for t in logits)
+        labels = labels.contiguous()
+        n = len(logits)
+        loss = _empty((n + 1,), logits[0])
+        stats = _empty((n * (B + 1) * (2 * K + 2),), logits[0])
+        wb = n * query("rpnet_loss_workspace_bytes", B, K, H, W)
+        ws = _ws(wb, logits[0])
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in logits])
+        warr = (C.c_float * n)(*[float(w) for w in weights])
+        call("rpnet_objective_fwd", arr, warr, n, ptr(labels), ptr(extra), float(extra_scale), ptr(loss), ptr(stats), B, K, H, W,
+             ptr(ws), wb)
+        ctx.save_for_backward(labels, stats, *logits)
+        ctx.cfg = (tuple(float(w) for w in weights), float(extra_scale), extra is not None and extra.requires_grad)
+        ctx.per_tensor = loss[:n]
+        return loss[n]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        labels, stats, *logits = ctx.saved_tensors
+        weights, extra_scale, want_extra = ctx.cfg
+        B, K, H, W = logits[0].shape
+        n = len(logits)
+        dl = torch.empty((n, B, K, H, W), device=logits[0].device, dtype=torch.float32)
+        dextra = _empty((), logits[0]) if want_extra else None
+        la = (C.c_void_p * n)(*[t.data_ptr() for t in logits])
+        da = (C.c_void_p * n)(*[dl[i].data_ptr() for i in range(n)])
+        warr = (C.c_float * n)(*weights)
+        call("rpnet_objective_bwd", la, da, warr, n, ptr(labels), ptr(stats), ptr(g.contiguous()), ptr(dextra), extra_scale, B, K, H, W)
+        return (None, dextra, None, None) + tuple(dl.unbind(0))
+
+
+def objective(logits, true, extra=None, extra_scale=1.0):
+    """sum_i dice_ce(logits_i, true) + extra_scale * extra (extra: a scalar tensor, or None / a Python number for "no such term") —
+    what train_rpnet.py and bench.py minimise; a tensor listed twice is evaluated once with weight 2"""
+    uniq, weights = [], []
+    for t in logits:
+        for j, u in enumerate(uniq):
+            if u is t:
+                weights[j] += 1.0
+                break
+        else:
+            uniq.append(t)
+            weights.append(1.0)
+    ex = extra if torch.is_tensor(extra) else None
+    if not _DICE_MULTI or len(uniq) > 16 or not uniq[0].is_cuda:
+        total = dice_ce_sum(logits, true)
+        return total if ex is None else total + extra_scale * ex
+    if ex is not None:
+        ex = ex.reshape(())
+        if ex.dtype != torch.float32:
+            ex = ex.float()
+    return Objective.apply(true, ex, float(extra_scale), tuple(weights), *uniq)
+
+
+_SEEDS = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached gradient seed (autograd otherwise fills a fresh ones_like(loss) every step: one launch)"""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    seed = _SEEDS.get(key)
+    if seed is None:
+        seed = _SEEDS[key] = torch.ones(loss.shape, device=loss.device, dtype=loss.dtype)
+    loss.backward(gradient=seed)
+
+
+def argmax_masks(pred, want_keep=False):
+    """pred [B,K,h,w] -> (masks [B,K,h*w] one-hot of argmax, counts [B,K][, keep [K,B] = 1 where counts > 0: the reference's
+    per-episode skip of a way whose predicted mask is empty]) (net/rp_net.py:412-415,421)."""
     B, K, h, w = pred.shape
     masks, counts = _empty((B, K, h * w), pred), _empty((B, K), pred)
-    call("rpnet_argmax_masks", ptr(pred), ptr(masks), ptr(counts), B, K, h * w)
-    return masks, counts
+    keep = _empty((K, B), pred) if want_keep else None
+    call("rpnet_argmax_masks", ptr(pred), ptr(masks), ptr(counts), ptr(keep), B, K, h * w)
+    return (masks, counts, keep) if want_keep else (masks, counts)
 
 
 def align_labels(fore, back):

@@ -105,8 +105,8 @@ class GraphedTrainStep:
             self.bucket.zero()
             out = self.net(si, fg, bg, qi, appr_query_labels=appr)
             loss = self.loss_fn(out, ql)
-            loss.backward()
             from . import functional as RF
+            RF.backward(loss)                # (cached gradient seed: no fill launch in the captured step)
             RF.join_side_streams()           # the weight gradients of the side streams land before the graph ends
         finally:
             self.bucket.hooks_enabled = was

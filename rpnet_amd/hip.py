@@ -117,11 +117,13 @@ _SIGS = {
     "rpnet_dice_ce_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]),
     "rpnet_dice_ce_multi_fwd": (ci, [C.POINTER(vp), ci, vp, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
     "rpnet_dice_ce_multi_bwd": (ci, [C.POINTER(vp), C.POINTER(vp), ci, vp, vp, vp, ci, ci, ci, ci, vp]),
-    "rpnet_argmax_masks": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "rpnet_objective_fwd": (ci, [C.POINTER(vp), C.POINTER(cf), ci, vp, vp, cf, vp, vp, ci, ci, ci, ci, vp, cs, vp]),
+    "rpnet_objective_bwd": (ci, [C.POINTER(vp), C.POINTER(vp), C.POINTER(cf), ci, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp]),
+    "rpnet_argmax_masks": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
     "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
-ABI_VERSION = 105      # RPNET_ABI_VERSION of include/rpnet_abi.h
+ABI_VERSION = 106      # RPNET_ABI_VERSION of include/rpnet_abi.h
 
 
 def lib_path():

@@ -460,7 +460,8 @@ class RP_Net(nn.Module):
             cache.clear()  # packed weights live for one forward only (never reused across optimizer steps)
 
         # ---- features: support and query through the encoder, separate BN statistics (:245-258)
-        supp = torch.cat([torch.cat(way, 0) for way in supp_imgs], 0).float()
+        # (one way, one shot: the support tensor itself — torch.cat of a single tensor is a copy launch each)
+        supp = (supp_imgs[0][0] if n_ways * n_shots == 1 else torch.cat([torch.cat(way, 0) for way in supp_imgs], 0)).float()
         qry = qry_imgs[0].float()
         ns = supp.shape[0]
         # eval mode: with predicted scales (RF.pred_*: the previous call's maxima) the fp16 planes cost no extra pass, so they
@@ -577,6 +578,8 @@ class RP_Net(nn.Module):
         # operand planes of qry * mask, qry * (1 - mask) for the next iteration — is ONE launch per iteration where the shapes
         # fit (RF.CosineMatchUp / rpnet_refine_glue_fwd); a differentiable mask (soft_mask in training) keeps the separate path
         K = 1 + n_ways
+        # the prototypes feed the T matches of the loop: one-pass gradient fan-in as for the query features
+        proto_uses = RF.FanOut.apply(protos, T) if (T > 1 and protos.requires_grad and _FANIN) else (protos,) * T
         soft_grad = soft and torch.is_grad_enabled()
         cq = self.cre.q[0].out_channels           # width of the relation features the glue matches against the prototypes
         fuse = qry_d4.is_cuda and RF.glue_supported(K, h, w, H, W, cq) and not soft_grad
@@ -599,13 +602,13 @@ class RP_Net(nn.Module):
                 ex = {"deferred": io.deferred, "mask": not last, "soft": bool(soft)}
                 if not last and xplanes and not forced_next:
                     ex.update(x=qry_d4, x_scale=s_qry if xplanes <= 2 else None, planes=xplanes)
-                logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0, ex)
+                logits, pred = RF.CosineMatchUp.apply(inter, proto_uses[i], H, W, 20.0, ex)
                 if not last:
                     qry_mask = ex["mask_out"]
                     pre = (ex["xk"], ex["xq"]) if ex.get("xk") is not None else None
             else:
                 inter = self.cre.forward_masked((qry_uses[2 * i], qry_uses[2 * i + 1]), qry_mask, cache, s_qry)
-                logits, pred = RF.CosineMatchUp.apply(inter, protos, H, W, 20.0)
+                logits, pred = RF.CosineMatchUp.apply(inter, proto_uses[i], H, W, 20.0)
             if taps is not None:
                 taps[f"inter_{i}"] = _to_nchw(inter.detach())
             refinement[i] = logits
@@ -648,16 +651,18 @@ class RP_Net(nn.Module):
         qry_fts [B,h,w,C]; pred [B,1+Wa,h,w]; supp_fts[wa][s] [B,h,w,C]; masks[wa][s] [B,H,W]."""
         n_ways, n_shots = len(fore_mask), len(fore_mask[0])
         H, W = fore_mask[0][0].shape[-2:]
-        masks, counts = RF.argmax_masks(pred)                                # :412-415
+        masks, counts, keep_all = RF.argmax_masks(pred, want_keep=True)      # :412-415; keep [K,B]: skip_ways (:414,421), per episode
         qp = RF.MaskedPool.apply(qry_fts, masks, counts)                     # :416-417  [B,1+Wa,C]
         loss = 0
         for wa in range(n_ways):
-            keep = (counts[:, wa + 1] > 0).float()                           # skip_ways (:414,421), per episode
+            keep = keep_all[wa + 1]
             protos = qp if n_ways == 1 else torch.stack([qp[:, 0], qp[:, wa + 1]], 1).contiguous()
             for s in range(n_shots):
                 logits, _ = RF.CosineMatchUp.apply(supp_fts[wa][s], protos, H, W, 20.0)   # :425-431
                 lab = RF.align_labels(fore_mask[wa][s], back_mask[wa][s])                 # :433-436
-                loss = loss + RF.DiceCE.apply(logits, lab, False, 255, True, keep) / n_shots / n_ways
+                term = RF.DiceCE.apply(logits, lab, False, 255, True, keep)
+                # (one way, one shot: x / 1 / 1 and 0 + x are x — three scalar launches forward, two backward)
+                loss = term if n_ways * n_shots == 1 else loss + term / n_shots / n_ways
         return loss
 
     # reference-named helpers kept for API parity (NCHW tensors, single episode)

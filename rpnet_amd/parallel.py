@@ -71,10 +71,14 @@ class FlatGradBucket:
                     last = p
                 o += p.numel()
             if last is not None and hasattr(last, "register_post_accumulate_grad_hook"):
-                last._rpnet_autograd_grad = True          # keep this one on AccumulateGrad so that the hook fires
+                last._rpnet_autograd_grad = self          # keep this one on AccumulateGrad so that the hook fires (while wants_hooks())
                 self._hooks.append(last.register_post_accumulate_grad_hook(self._launcher(i)))
         self._hook = self._hooks[-1] if self._hooks else None
         self._tail_work = None
+
+    def wants_hooks(self):
+        """True while a tagged parameter's gradient has to pass AccumulateGrad for its hook to launch an exchange (functional._direct)"""
+        return self._active() and self.hooks_enabled
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_active)

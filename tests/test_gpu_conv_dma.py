@@ -303,7 +303,11 @@ def test_dma_weight_gradient_one_plane(RF, monkeypatch, N, H, W, c0, c1, cout):
         monkeypatch.setitem(RF.TUNE, "wgrad", 0)            # round 6: K-steps down the image columns (conv_wgrad_ring.hip)
         dw_new = _run(RF, monkeypatch, -1, layer, a, b, go, False, groups)[4]
         assert RF.arith_counts()["wgrad3x3"].get("f16", 0) >= 1
-        assert not torch.equal(dw_old, dw_new) and not torch.equal(dw_row, dw_new)      # another kernel ran (another summation order)
+        assert not torch.equal(dw_old, dw_new)               # another kernel ran (another summation order)
+        if W == 64 or H == 1:   # one 64-pixel step per image row: column-major IS row-major — the ring kernel must reproduce the bits
+            assert torch.equal(dw_row, dw_new)
+        else:
+            assert not torch.equal(dw_row, dw_new)
         assert rel_err(dw_new, dw_old) < 2e-6 and rel_err(dw_row, dw_old) < 2e-6
         # (one fp16 plane of dy behind a BatchNorm backward: per-element roundings of 2^-11 of the TENSOR maximum — the
         # error against fp64 is that of the arithmetic, the same for both kernels)

@@ -698,6 +698,39 @@ def test_dice_ce_sum_matches_separate_calls(RF, n, B, K, H, W):
         assert torch.equal(x.grad, y.grad)
 
 
+@pytest.mark.parametrize("n,B,K,H,W,dup,with_extra", [(6, 3, 2, 24, 20, True, True), (3, 2, 3, 16, 16, False, True), (5, 1, 2, 8, 8, True, False)])
+def test_objective_is_the_tensor_expression_bit_for_bit(RF, n, B, K, H, W, dup, with_extra):
+    """rpnet_objective_fwd / _bwd (RF.objective: what train_rpnet.py / bench.py minimise) against the tensor expression it replaces,
+    dice_ce_sum(terms) + scaler * align: the value, every logit gradient (a tensor listed twice gets the sum of its two gradients) and
+    the gradient of the extra term — bit for bit, also behind a seed other than 1."""
+    lab = torch.from_numpy(np.random.default_rng(6).integers(0, K, (B, H, W))).to(DEV)
+    lgs = [rnd(60 + i, B, K, H, W).to(DEV) for i in range(n)]
+    scaler = 0.37
+
+    def run(fused):
+        a = [t.clone().requires_grad_(True) for t in lgs]
+        ex = torch.tensor(1.2345, device=DEV, requires_grad=True) if with_extra else 0
+        terms = ([a[-1]] + a) if dup else a            # (the final output IS the last refinement output)
+        tot = RF.objective(terms, lab, ex, scaler) if fused else RF.dice_ce_sum(terms, lab) + scaler * ex
+        (tot * 0.75).backward()
+        return tot.detach(), [t.grad for t in a], (ex.grad if with_extra else None)
+
+    t0, g0, e0 = run(False)
+    t1, g1, e1 = run(True)
+    assert torch.equal(t0, t1)
+    for x, y in zip(g0, g1):
+        assert torch.equal(x, y)
+    if with_extra:
+        assert torch.equal(e0, e1)
+    # the cached seed of RF.backward is the seed autograd would have made
+    a = [t.clone().requires_grad_(True) for t in lgs]
+    RF.backward(RF.objective(a, lab, None, 1.0))
+    b = [t.clone().requires_grad_(True) for t in lgs]
+    RF.objective(b, lab, None, 1.0).backward()
+    for x, y in zip(a, b):
+        assert torch.equal(x.grad, y.grad)
+
+
 def test_align_loss(golden):
     """alignLoss against the reference's value and gradients (tests/golden/ops.npz) incl. the skip-way case."""
     from rpnet_amd.modules import RP_Net

@@ -23,21 +23,22 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from net.model import model_factory  # noqa: E402
-from rpnet_amd.functional import dice_ce, dice_ce_sum  # noqa: E402
+import rpnet_amd.functional as RF  # noqa: E402
+from rpnet_amd.functional import dice_ce  # noqa: E402
 from rpnet_amd.parallel import FlatGradBucket, broadcast_parameters  # noqa: E402
 from rpnet_amd.utils.synth import make_episode  # noqa: E402
 from utils.util import load_yaml  # noqa: E402
 
 
 def objective(out, labels, scaler):
-    # dice_ce of the final output and of every refinement iteration's output, summed (on the GPU: one multi-tensor launch pair)
+    # dice_ce of the final output and of every refinement iteration's output, summed, + scaler * align_loss (on the GPU: ONE launch pair,
+    # rpnet_amd.functional.objective -> rpnet_objective_fwd; the reference ships no training loop: this is what its paper describes)
     terms = [out["output"], *out["refinement"].values()]
     if terms[0].is_cuda:
-        loss = dice_ce_sum(terms, labels)
-    else:
-        loss = dice_ce(terms[0], labels)
-        for v in terms[1:]:
-            loss = loss + dice_ce(v, labels)
+        return RF.objective(terms, labels, out["align_loss"], scaler)
+    loss = dice_ce(terms[0], labels)
+    for v in terms[1:]:
+        loss = loss + dice_ce(v, labels)
     return loss + scaler * out["align_loss"]
 
 
@@ -86,7 +87,7 @@ def train(config, steps, batch, size, dev, lr=None, log_every=10, out_dir=None, 
         bucket.zero()                       # gradients live in the flat bucket: one memset instead of zero_grad
         out = net(si, fg, bg, qi, appr_query_labels=appr)
         loss = objective(out, ql, scaler)
-        loss.backward()
+        RF.backward(loss)                   # (cached gradient seed)
         bucket.allreduce()
         opt.step()
         history.append(loss.detach())       # no host sync per step
