@@ -62,12 +62,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
     const int lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wv >> 1, wn = wv & 1;
+    // block -> (tile, pixel chunk z) so that the blocks of ONE pixel chunk — which read the same x strips (tiles of one cin row) and dy
+    // tiles (one cout column) — sit on as few XCDs (private L2s; the dispatcher places block b on XCD b % 8) as possible:
+    // ksplit a multiple of 8: one XCD per chunk (8 chunks at a time); ksplit = 1, 2 or 4 with enough tiles: 8 / ksplit XCDs per chunk,
+    // each with a contiguous share of the tiles (round 5 spread such a chunk over all 8: its operands were fetched up to 8 times,
+    // 180 MB per launch at 512 channels against 134 MB once)
     int tile, z;
-    if ((ksplit & 7) == 0) {       // the blocks of one pixel chunk share an XCD (and its L2)
+    const int xg = ksplit < 8 ? 8 / max(ksplit, 1) : 0;          // XCDs per chunk
+    if ((ksplit & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int jt = uni(j / tiles);
         z = jt * 8 + xcd;
         tile = j - jt * tiles;
+    } else if (xg * ksplit == 8 && tiles % xg == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;     // j = 0 .. tiles / xg - 1
+        z = uni(xcd / xg);
+        tile = (xcd - z * xg) * (tiles / xg) + j;
     } else {
         z = uni(blockIdx.x / tiles);
         tile = blockIdx.x - z * tiles;

@@ -104,7 +104,7 @@ def test_two_rank_rp_net_bucket_on_one_gpu():
     assert float(want.abs().max()) > 0
 
 
-def _nccl_world1_worker(port, q, ways, size, B, T_):
+def _nccl_world1_worker(port, q, ways, size, B, T_, reps=5, greps=3, bench_objective=False):
     """ONE rank, backend nccl (= RCCL) on cuda:0, the bucket's exchange forced on: the real step — async weight gradients on
     the side streams, the CRE's second branch (and for 2-way the encoder's second chain) on their own stream, the
     three-segment exchange launched from post-accumulate hooks in autograd's thread — meets RCCL's stream semantics (the
@@ -124,6 +124,8 @@ def _nccl_world1_worker(port, q, ways, size, B, T_):
     (si, fg, bg, qi, ql, appr), _ = episode_tensors(910, B, size, "cuda:0", n_ways=ways)
 
     def loss_fn(out, lab):
+        if bench_objective:          # bench.py's / train_rpnet.py's form of the same objective (one launch pair)
+            return RF.objective([out["output"], *out["refinement"].values()], lab, out["align_loss"], cfg["align_loss_scaler"])
         loss = dice_ce(out["output"], lab)
         for v in out["refinement"].values():
             loss = loss + dice_ce(v, lab)
@@ -151,7 +153,7 @@ def _nccl_world1_worker(port, q, ways, size, B, T_):
     _, want = one(False)
     _, again = one(False)
     res = {"deterministic": bool(torch.equal(want, again)), "nonzero": float(want.abs().max()) > 0, "equal": [], "launched": []}
-    for _ in range(5):
+    for _ in range(reps):
         launched, got = one(True)
         res["launched"].append(launched)
         res["equal"].append(bool(torch.equal(got, want)))
@@ -161,7 +163,7 @@ def _nccl_world1_worker(port, q, ways, size, B, T_):
     q.put(dict(res, graph_equal=None))           # the eager result first: a crash below must not take it along
     bucket.force_active = True
     res["graph_equal"] = []
-    for _ in range(3):                           # replay + one all-reduce of the whole bucket behind it
+    for _ in range(greps):                       # replay + one all-reduce of the whole bucket behind it
         gts(si, fg, bg, qi, ql, appr)
         torch.cuda.synchronize()
         res["graph_equal"].append(bool(torch.equal(bucket.flat, want)))
@@ -185,6 +187,28 @@ def test_rccl_world1_bucket_equals_plain_step(ways, size, B, T_):
     p.join(120)
     assert p.exitcode == 0
     assert res["graph_equal"] and all(res["graph_equal"]), res
+    assert res["ranks_seen"] == 1.0
+
+
+def test_rccl_world1_canary_at_the_benched_size():
+    """The canary the round-5 review asked for: BASELINE configs[1] at FULL size (batch 8, 256 x 256, T = 5, bench.py's objective) under a
+    forced one-rank RCCL group — the three bucket segments launched from the hooks while the LDS-DMA kernels of the backward pass (and
+    the guarded pooled BatchNorm passes) run, RCCL's own kernels sharing the CUs with them — 30 times, every bucket bit-identical to
+    the non-distributed step's; then the pre-captured HIP-graph replay + ONE all-reduce, 30 times.  The one silent-corruption fault
+    this code base has had (profiles/r05_pool_fault_repro.txt) was a co-residence fault; this is the schedule an 8-GPU job runs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(41500 + os.getpid() % 2000, q, 1, 256, 8, 5, 30, 30, True))
+    p.start()
+    res = q.get(timeout=1200)
+    assert res["deterministic"] and res["nonzero"], res
+    assert len(res["equal"]) == 30 and all(l == [1, 2] for l in res["launched"]), res
+    assert all(res["equal"]), res
+    res = q.get(timeout=1200)
+    p.join(120)
+    assert p.exitcode == 0
+    assert len(res["graph_equal"]) == 30 and all(res["graph_equal"]), res
     assert res["ranks_seen"] == 1.0
 
 
