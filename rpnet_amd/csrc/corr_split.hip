@@ -13,6 +13,8 @@
 // the window) — a GEMM over K = NQ halo positions.  G's 32-column slabs are built in LDS from the fp32 gradient
 // tile and split on the fly; fo's halo is [q][channel], i.e. K is the ROW index, so its fragments come from
 // ds_read_b64_tr_b16 as in conv_wgrad_split.hip.  A block computes 64 pixels x 128 channels.
+#include <stdlib.h>
+
 #include "common.h"
 #include "split_bf16.h"
 
@@ -185,11 +187,12 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
                                                                       float* __restrict__ df, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
                                                                       const float inv_sqrt_c, const float* __restrict__ s_fo,
-                                                                      const float* __restrict__ add) {
+                                                                      const float* __restrict__ add, const int xcd_order) {
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NCH = (NQ + 31) / 32, GS = (KK + 3) & ~3;
     constexpr int BN = 128 * NJ, RSB = BN * 2 + 64;                     // fo row: 128 channels + pad (conflict-free transposing reads)
     constexpr int A_BYTES = 64 * 64, B_BYTES = 32 * RSB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[64 * GS * 4 + NP * (A_BYTES + B_BYTES)];
+    constexpr int LOOP_LDS = 64 * GS * 4 + NP * (A_BYTES + B_BYTES), OUT_LDS = 64 * (BN + 4) * 4;     // K loop / output tile (epilogue)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LOOP_LDS > OUT_LDS ? LOOP_LDS : OUT_LDS];
     float* gs = reinterpret_cast<float*>(smem);                     // [64][GS] window gradients of the tile
     unsigned char* const asm_ = smem + 64 * GS * 4;
     unsigned char* const bsm = asm_ + NP * A_BYTES;
@@ -198,8 +201,18 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
     const int lane = t & 63, wv = t >> 6;
     const int li = lane & 31, hh = lane >> 5;
     const int tiles_x = (w + 7) / 8;
-    const int b = blockIdx.z, n0 = blockIdx.y * BN;
-    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
+    int b = blockIdx.z, tl = blockIdx.x;
+    const int n0 = blockIdx.y * BN;
+    const int abl = xcd_order >> 4;          // diagnostic (tools/bench_corr_bwd.py, RPNET_CORR_BWD_XCD = 16 * bits + order): 1 = no G build,
+                                               // 2 = no fo staging, 4 = no MFMAs, 8 = no epilogue stores; results are then meaningless
+    if ((xcd_order & 1) && gridDim.y == 1) {
+        // XCD-aware order (common.h): an XCD works on a contiguous run of tiles, so that the halo rows neighbouring tiles share
+        // are fetched into ONE private L2 instead of up to five
+        const int lin = xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+        b = lin / gridDim.x;
+        tl = lin - b * gridDim.x;
+    }
+    const int ty0 = (tl / tiles_x) * 8, tx0 = (tl % tiles_x) * 8;
     const size_t plane = (size_t)B * h * w * C, img = (size_t)b * h * w * C;
     __amdgpu_buffer_rsrc_t rf[NP];
 #pragma unroll
@@ -225,10 +238,35 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
     fetch_fo(0);
 
     const float* gb = g + (size_t)b * h * w * cstride;
-    for (int e = t; e < 64 * GS; e += 256) {
-        const int p = e / GS, o = e - p * GS;
-        const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
-        gs[e] = (o < KK && y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] * inv_sqrt_c : 0.f;
+    if ((cstride & 3) == 0 && (GS & 3) == 0) {
+        // 16-byte loads, all of a thread's in flight at once (round 6: the scalar loop below was a chain of 31 dependent
+        // 4-byte load -> LDS store rounds per thread: a fifth of the launch)
+        constexpr int G4 = GS / 4, NV = (64 * G4 + 255) / 256;
+        f32x4 gv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e4 = t + 256 * k, p = e4 / G4, o4 = e4 - p * G4;
+            const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
+            gv[k] = (e4 < 64 * G4 && y < h && x < w) ? *reinterpret_cast<const f32x4*>(gb + ((size_t)y * w + x) * cstride + 4 * o4)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e4 = t + 256 * k, p = e4 / G4, o4 = e4 - p * G4;
+            if (e4 < 64 * G4) {
+                f32x4 v = gv[k] * inv_sqrt_c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * o4 + q >= KK) v[q] = 0.f;
+                *reinterpret_cast<f32x4*>(gs + p * GS + 4 * o4) = v;
+            }
+        }
+    } else {
+        for (int e = t; e < 64 * GS; e += 256) {
+            const int p = e / GS, o = e - p * GS;
+            const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
+            gs[e] = (o < KK && y < h && x < w) ? gb[((size_t)y * w + x) * cstride + o] * inv_sqrt_c : 0.f;
+        }
     }
     // NP <= 2: the window gradients have no a-priori bound, but the tile is right here: a block-local power-of-two scale
     // from its own maximum (exact), the fo planes carry their producer's tensor scale; the result takes both back
@@ -264,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
     for (int ch = 0; ch < NCH; ++ch) {
         const int q0 = ch * 32;
         __syncthreads();      // previous slab consumed (and gs complete on the first pass)
-        {   // G[p][q0 + 8 akg .. +7]
+        if (!(abl & 1)) {   // G[p][q0 + 8 akg .. +7]
             float v[8];
             const int qs = q0 + akg * 8;
             int qy = qs / HT, qx = qs - qy * HT;              // rows beyond NQ fall outside the window by themselves (c >= K)
@@ -281,11 +319,13 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(asm_ + p * A_BYTES + adst) = o[p];
         }
+        if (!(abl & 2)) {
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(bsm + p * B_BYTES + (brow + RPP * j) * RSB + bpc) = rfo[p][j];
         if (ch + 1 < NCH) fetch_fo(q0 + 32);
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -304,6 +344,13 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
                 }
             }
             constexpr int NPROD = nprod<NP>();
+            if (abl & 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) acc[i][jn][0] += (float)af[0][i][0] + (float)bfr[0][jn][0] + (float)af[NP - 1][i][1] + (float)bfr[NP - 1][jn][1];
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < NPROD; ++q) {
                 const int pa = prod_a<NP>(q), pb = prod_b<NP>(q);
@@ -317,21 +364,44 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_bwd_kernel(const float
     float* dfb = df + (size_t)b * h * w * C;
     const float* addb = add ? add + (size_t)b * h * w * C : nullptr;    // a second gradient of the same tensor, summed here
     const int col = n0 + wv * 32 + li;
+    if (abl & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][jn][r];
+        if (sacc == 1.2345f) dfb[0] = sacc;
+        return;
+    }
+    // the 64 x BN tile through LDS so that a thread stores (and, for `add`, loads) 16 bytes of one pixel's channels: 16 stores per
+    // thread instead of 64 four-byte ones (the epilogue was a fifth of the launch; conv_epilogue.h made the same change in round 2)
+    constexpr int TS = BN + 4;                                          // padded row (floats)
+    float* ot = reinterpret_cast<float*>(smem);
+    __syncthreads();                                                    // the last slab's fragments are read
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
-            if (y < h && x < w) {
 #pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    const size_t o = ((size_t)y * w + x) * C + col + jn * 128;
-                    const float v = NP <= 2 ? acc[i][jn][r] * out_scale : acc[i][jn][r];
-                    dfb[o] = addb ? v + addb[o] : v;
-                }
-            }
+            for (int jn = 0; jn < NJ; ++jn) ot[pl * TS + wv * 32 + li + jn * 128] = NP <= 2 ? acc[i][jn][r] * out_scale : acc[i][jn][r];
         }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                                          // 16-byte pieces per pixel
+#pragma unroll
+    for (int k = 0; k < 64 * C4 / 256; ++k) {
+        const int idx = t + 256 * k, pl = idx / C4, c4 = idx - pl * C4;
+        const int y = ty0 + (pl >> 3), x = tx0 + (pl & 7);
+        if (y < h && x < w) {
+            const size_t o = ((size_t)y * w + x) * C + n0 + 4 * c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ot + pl * TS + 4 * c4);
+            if (addb) v += *reinterpret_cast<const f32x4*>(addb + o);
+            *reinterpret_cast<f32x4*>(dfb + o) = v;
+        }
+    }
+    (void)col;
 }
 
 int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, int cstride, int r, hipStream_t s);   // corr.hip
@@ -383,15 +453,16 @@ extern "C" int rpnet_local_corr_split_bwd(const void* f1s, const void* f2s, cons
     const unsigned short* b2 = (const unsigned short*)f2s;
     // two planes or one: a block covers 256 channels when C allows (the G slab is built once for all of them)
     const bool wide = planes <= 2 && C % 256 == 0;
+    static const int xcd_order = getenv("RPNET_CORR_BWD_XCD") ? atoi(getenv("RPNET_CORR_BWD_XCD")) : 0;
     const dim3 grid(tiles, wide ? C / 256 : C / 128, B);
 #define RPNET_CORR_BWD(NP_, SIGN_, NJ_, ...) hipLaunchKernelGGL((local_corr_mfma_bwd_kernel<5, NP_, SIGN_, NJ_>), grid, dim3(256), 0, s, __VA_ARGS__)
 #define RPNET_CORR_BWD_PASS(SIGN_, G_, FO_, DF_, SFO_, ADD_)                                                       \
     do {                                                                                                            \
-        if (planes == 3) RPNET_CORR_BWD(3, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, (const float*)nullptr, ADD_); \
-        else if (planes == 2 && wide) RPNET_CORR_BWD(2, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);     \
-        else if (planes == 2) RPNET_CORR_BWD(2, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);             \
-        else if (wide) RPNET_CORR_BWD(1, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);                    \
-        else RPNET_CORR_BWD(1, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_);                              \
+        if (planes == 3) RPNET_CORR_BWD(3, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, (const float*)nullptr, ADD_, xcd_order); \
+        else if (planes == 2 && wide) RPNET_CORR_BWD(2, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_, xcd_order);     \
+        else if (planes == 2) RPNET_CORR_BWD(2, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_, xcd_order);             \
+        else if (wide) RPNET_CORR_BWD(1, SIGN_, 2, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_, xcd_order);                    \
+        else RPNET_CORR_BWD(1, SIGN_, 1, G_, FO_, DF_, B, h, w, C, cstride, isc, SFO_, ADD_, xcd_order);                              \
     } while (0)
     RPNET_CORR_BWD_PASS(1, dcorr, b2, df1, scale2, df1_add);
     if (int rc = launch_corr_transpose(dcorr, dct, B, h, w, cstride, r, s)) return rc;

@@ -47,7 +47,7 @@ _ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": []
 # "f16" = ONE fp16 plane of operand / scale (plain fp16 operands, fp32 accumulation, fp32 BatchNorm statistics): the
 # reduced-precision arithmetic of BASELINE configs[4]; NOT fp32-equivalent (tolerances: DESIGN.md §6).
 _MODES = {"f32": (0, False, 0), "bf16x3": (3, False, 0), "f16x2": (3, True, 2), "f16": (3, True, 1)}
-_CORR16 = os.environ.get("RPNET_CORR_F16", "1") == "1"   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
+_CORR16 = True   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
 _MATH = {}
 
 
@@ -62,6 +62,32 @@ set_conv_math(os.environ.get("RPNET_CONV_MATH", "f16x2"))
 
 def conv_math():
     return _MATH["mode"]
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def scope(conv_math=None, async_wgrad=None, mask_skip=None):
+    """Activate a model's own options (rpnet_amd.schedule.Schedule) for the duration of ONE forward call; None = keep the
+    process-wide default.  Restores the defaults afterwards (also on an exception): nothing leaks into the next model's call.
+    The backward pass does not need the scope: every autograd node captured the options it needs when it was created."""
+    global _MASK_SKIP
+    saved = (_MATH["mode"], _MATH.get("f16_on", True), _ASYNC["on"], _MASK_SKIP)
+    try:
+        if conv_math is not None and conv_math != saved[0]:
+            set_conv_math(conv_math)
+        if async_wgrad is not None:
+            _ASYNC["on"] = bool(async_wgrad)
+        if mask_skip is not None:
+            _MASK_SKIP = bool(mask_skip)
+        yield
+    finally:
+        if _MATH["mode"] != saved[0]:
+            set_conv_math(saved[0])
+        _MATH["f16_on"] = saved[1]
+        _ASYNC["on"] = saved[2]
+        _MASK_SKIP = saved[3]
 
 
 def f16_mode():
@@ -107,8 +133,9 @@ def _tap(tag, weight, *tensors):
                 _TAPS.append((f"{tag}{i}", tuple(weight.shape), t.detach() if _TAPS_PIN else t.detach().clone()))
 
 
-def _direct(p):
-    if not (_ASYNC["on"] and p is not None and p.grad is not None and p.grad.is_contiguous()):
+def _direct(p, on=None):
+    """on: the weight-gradient option the autograd node captured at forward time (None: the process-wide switch)"""
+    if not ((_ASYNC["on"] if on is None else on) and p is not None and p.grad is not None and p.grad.is_contiguous()):
         return False
     tag = getattr(p, "_rpnet_autograd_grad", False)
     if tag is False or tag is None:
@@ -120,10 +147,10 @@ def _direct(p):
     return not (wants() if wants is not None else True)
 
 
-def _accumulate_direct(p, g):
+def _accumulate_direct(p, g, on=None):
     """bucket mode: add a parameter gradient that a kernel could only WRITE (the first layer's direct weight gradient) into p.grad on the
     producing stream — ordered against the other chain's accumulation into the same parameter — and hand autograd nothing; otherwise g"""
-    if not _direct(p):
+    if not _direct(p, on):
         return g
     _order_wait(p.data_ptr())
     p.grad.add_(g)
@@ -133,7 +160,7 @@ def _accumulate_direct(p, g):
 
 def use_compute_stream(device):
     """The stream the step's main chain runs on: the caller's current stream.  (Round 3 tried a high-priority main stream:
-    +1 % alone, nothing on top of releasing every weight gradient behind its layer's dgrad — RPNET_WGRAD_DEFER — and removed.)"""
+    +1 % alone, nothing on top of releasing every weight gradient behind its layer's dgrad — _WGRAD_DEFER — and removed.)"""
     return torch.cuda.current_stream(device)
 
 
@@ -332,7 +359,7 @@ def _absmax_slot(device):
 # while out_absmax still measures the truth.  pred_end() compares: a maximum above its predicted bound (fp16 would have
 # overflowed or lost its top bit) makes the caller redo the call on measured scales — counted in pred_stats().
 PRED_SAFETY = float(os.environ.get("RPNET_EVAL_PRED_SAFETY", "4"))
-_EVAL_PREDICT = os.environ.get("RPNET_EVAL_PREDICT", "1") == "1"
+_EVAL_PREDICT = True
 _PRED = {}
 
 
@@ -500,36 +527,37 @@ class Operand:
 
 # async weight gradients go out behind a dgrad (ConvBnRelu.backward): 1 = their own layer's, d = the one d - 1 layers further
 # down the chain (a deeper backlog of MFMA-bound work beside the chain's HBM-bound passes); 0 = in front of their own
-_WGRAD_DEFER = int(os.environ.get("RPNET_WGRAD_DEFER", "1"))
+_WGRAD_DEFER = 1
 # A/B switch: split K for the eval-mode 3x3 convolutions whose grid covers half of the CUs or fewer
-_EVAL_SPLITK = os.environ.get("RPNET_EVAL_SPLITK", "1") == "1"
+_EVAL_SPLITK = True
 # A/B switch: BatchNorm + ReLU + MaxPool2d(2, 2) of the encoder levels whose output feeds only its pool in one pass
-_POOL_FUSE = os.environ.get("RPNET_POOL_FUSE", "1") == "1"
+_POOL_FUSE = True
 # A/B switch: the BatchNorm-backward apply pass of Conv1.conv.0 inside its direct weight gradient (rpnet_conv1_wgrad_bn)
-_CONV1_BN_FUSE = os.environ.get("RPNET_CONV1_BN_FUSE", "1") == "1"
+_CONV1_BN_FUSE = True
 # Conv1.conv.0 (Cin = 1) in training on fp16 planes: its pre-BatchNorm tensor is never written — the statistics launch only
 # sums it, BatchNorm + ReLU and the backward's reduction pass / weight gradient make it again from the image (nine
-# multiply-adds per value against eight bytes written and re-read; csrc/conv_first.hip).  RPNET_CONV1_RECOMPUTE=0: A/B switch
-_CONV1_RECOMP = os.environ.get("RPNET_CONV1_RECOMPUTE", "1") == "1"
+# multiply-adds per value against eight bytes written and re-read; csrc/conv_first.hip).  _CONV1_RECOMP = False: A/B switch (module constant; tests / tools set it)
+_CONV1_RECOMP = True
 # up_conv (nn.Upsample(scale_factor=2) -> Conv2d 3x3, net/modules.py:61-75: Up5, Up4) on its COLLAPSED weights: a 3x3 convolution over a
 # nearest-x2 up-sampled image reads a 2 x 2 block of source pixels per output pixel, so with the weights of coinciding taps added
 # up front the layer needs 4 / 9 of its multiply-adds — forward, input gradient and weight gradient (csrc/conv_up4_dma.hip,
 # rpnet_conv_up4; the two layers are 17 % of the step's FLOPs as the reference writes them).  Differs from the nine-product
-# form by the rounding of the weight sums (2^-24 relative).  RPNET_UPCONV_COLLAPSE=0: the nine-product form (A/B switch).
-_UP4 = os.environ.get("RPNET_UPCONV_COLLAPSE", "1") == "1"
+# form by the rounding of the weight sums (2^-24 relative).  _UP4 = False: the nine-product form (A/B switch: module constant, tests / tools set it).
+_UP4 = True
 # w_k(x * mask) / w_q(x * (1 - mask)) (net/rp_net.py:275,283): output tiles whose masked input is zero on the tile and its halo
 # (forward) or whose factor is zero on the tile (input gradient) skip their K loop (rpnet_conv_desc.skip_*) — same bits as the
 # dense launch.  The support mask covers 2 - 15 % of the pixels, so most tiles of w_k go.  bench.py keeps the HEADLINE dense
-# (the roofline accounting is algorithmic) and reports this as its own leg.  RPNET_MASK_SKIP=0: off
+# (the roofline accounting is algorithmic) and reports this as its own leg.  RPNET_MASK_SKIP=0 / Schedule.mask_skip = False: off
 _MASK_SKIP = os.environ.get("RPNET_MASK_SKIP", "1") == "1"
 
 
 _SKIP_STATS = None     # diagnostic (bench.py): a list that receives every launch's flag buffer (preset to 255 = "no tile here")
 
 
-def _set_skip(d, mask, mode, halo, N, H, W):
-    """lend a launch the mask and the flag scratch of the tile skip (only the LDS-DMA patch kernels use them)"""
-    if _MASK_SKIP and mask is not None and mode in (1, 2):
+def _set_skip(d, mask, mode, halo, N, H, W, on=None):
+    """lend a launch the mask and the flag scratch of the tile skip (only the LDS-DMA patch kernels use them); on: the option the
+    autograd node captured at forward time (None: the process-wide switch)"""
+    if (_MASK_SKIP if on is None else on) and mask is not None and mode in (1, 2):
         if _SKIP_STATS is not None:
             d._skip_ws = torch.full((max(N * H * W // 128, 16),), 255, device=mask.device, dtype=torch.uint8)
             _SKIP_STATS.append(d._skip_ws)
@@ -568,8 +596,8 @@ def _split_operand(op, planes, scale=None, mode=0):
 
 
 # the 1x1 convolution over cat([corr, fm1]) on split planes too (gathering weight pack, per-source fp16 scales, single-tap
-# split weight gradient); RPNET_CONV1X1_SPLIT=0 keeps it on the fp32-MFMA kernels (A/B switch)
-_CONV1X1_SPLIT = os.environ.get("RPNET_CONV1X1_SPLIT", "1") == "1"
+# split weight gradient); _CONV1X1_SPLIT = False keeps it on the fp32-MFMA kernels (A/B switch)
+_CONV1X1_SPLIT = True
 
 
 def _use_split(pw, x0, x1):
@@ -1056,6 +1084,7 @@ class ConvBnRelu(Function):
         ctx.pw, ctx.cfg, ctx.eval_mode, ctx.pool = pw, (groups, upsample, in_mode, first), False, pool
         ctx.up4 = (not first) and up4
         ctx.bias, ctx.beta, ctx.xs, ctx.sx, ctx.sx1 = bias, beta, xs, sx, sx1
+        ctx.opts = (_ASYNC["on"], _MASK_SKIP)       # the model's options when the node was made (rpnet_amd.schedule): backward reads these
         return z
 
     @staticmethod
@@ -1065,6 +1094,7 @@ class ConvBnRelu(Function):
             raise NotImplementedError("rpnet_amd: backward through eval-mode BatchNorm is not implemented "
                                       "(the reference only evaluates under torch.no_grad, test_rpnet.py:163)")
         x0, x1, in_scale, weight, gamma, y, stats = ctx.saved_tensors
+        async_on, skip_on = getattr(ctx, "opts", (None, None))
         pw = ctx.pw
         groups, upsample, in_mode, first = ctx.cfg
         dz = dz.contiguous()
@@ -1075,7 +1105,7 @@ class ConvBnRelu(Function):
         beta, bias = ctx.beta, ctx.bias
         if y is None:
             # the first layer without its pre-BatchNorm tensor: reduction pass and weight gradient make y again from the image
-            direct = _direct(gamma) and _direct(beta)
+            direct = _direct(gamma, async_on) and _direct(beta, async_on)
             dgamma, dbeta = (None, None) if direct else (_empty((cout,), dz), _empty((cout,), dz))
             rows = query("rpnet_conv1_bn_bwd_rows", N, H, W, cout, groups)
             part = torch.empty(groups * rows * cout * 2, device=dz.device, dtype=torch.float64)
@@ -1094,8 +1124,8 @@ class ConvBnRelu(Function):
             coef = ws.data_ptr() + query("rpnet_bn_bwd_coef_offset", cout, groups)
             call("rpnet_conv1_wgrad_bn", ptr(x0), ptr(dz), None, ptr(stats), coef, ptr(dw), N, H, W, cout, groups, ptr(ws2), wb,
                  ptr(weight), ptr(bias))
-            dw = _accumulate_direct(weight, dw)
-            db = None if _direct(bias) else torch.zeros_like(gamma)
+            dw = _accumulate_direct(weight, dw, async_on)
+            db = None if _direct(bias, async_on) else torch.zeros_like(gamma)
             return None, None, None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         # which forms of dy the two consumers (wgrad, dgrad) want: split-bf16 planes and / or fp32
         np_ = ctx.xs[0].shape[0] if ctx.xs is not None else 0
@@ -1112,7 +1142,7 @@ class ConvBnRelu(Function):
             dy = None
         if ctx.pool and (dys is None or dz.shape[1] * 2 != H):
             raise RuntimeError("rpnet_amd: the pooled BatchNorm backward needs dy as split planes and the pooled gradient")
-        direct = _direct(gamma) and _direct(beta)     # straight into the gradient bucket, no AccumulateGrad add
+        direct = _direct(gamma, async_on) and _direct(beta, async_on)     # straight into the gradient bucket, no AccumulateGrad add
         dgamma, dbeta = (None, None) if direct else (_empty((cout,), y), _empty((cout,), y))
         ARITH[("bn_bwd", "own reduction pass")] += 1
         if direct:
@@ -1135,7 +1165,7 @@ class ConvBnRelu(Function):
                      ptr(ws2), wb, None, None)
             else:
                 call("rpnet_conv1_wgrad", ptr(x0), ptr(dy), ptr(dw), N, H, W, cout, ptr(ws2), wb)
-            dw = _accumulate_direct(weight, dw)
+            dw = _accumulate_direct(weight, dw, async_on)
         else:
             # same gather descriptor as the forward (sources, up-sampling, x*mask factor); dy is the other operand
             if wsplit:       # both wgrad operands as split planes (the x*mask factor is already in xs)
@@ -1163,7 +1193,7 @@ class ConvBnRelu(Function):
                 else:
                     _cconv("rpnet_conv_wgrad", d, dy_ptr, dw_ptr, pw.cin, pw.off0, pw.split, pw.off1, ptr(ws_t), wb)
             deferred = None
-            if _direct(weight):
+            if _direct(weight, async_on):
                 # the stream this backward node runs on (the one that produced dy and will run this layer's dgrad), taken NOW:
                 # a deferred launch may be released by a later node that runs on another stream (the CRE's second branch, the
                 # encoder's second chain), and must still wait for THIS one
@@ -1191,7 +1221,7 @@ class ConvBnRelu(Function):
                         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
                         _ASYNC["queued"] = True
                     _ASYNC["pending"].add(dev)
-                # RPNET_WGRAD_DEFER >= 1 (default 1): the launch goes out right BEHIND this layer's dgrad and waits for it, so that it
+                # _WGRAD_DEFER >= 1 (default 1): the launch goes out right BEHIND this layer's dgrad and waits for it, so that it
                 # starts when the main chain enters the BatchNorm-backward passes of the layer below — every HBM-bound pass
                 # of the chain then has an MFMA-bound partner on the machine.  Launched in front of the dgrad (=0) the two
                 # GEMMs share the CUs, end together, and the passes behind them run alone.
@@ -1232,7 +1262,7 @@ class ConvBnRelu(Function):
                     if np_ <= 2:
                         dd.acc_scale_col, dd.acc_scale_x = ptr(pk[3]), ptr(sdy)
                         if pw.taps == 9 and x1 is None and not upsample and not need_s:
-                            _set_skip(dd, in_scale, in_mode, 0, N, H, W)
+                            _set_skip(dd, in_scale, in_mode, 0, N, H, W, skip_on)
                 else:
                     dd = _desc(dy, None, pw.wd, None, None, 0, g0, g1, N, H, W, pw.taps, 0,
                                out_scale=None if need_s else in_scale, out_mode=in_mode)
@@ -1258,7 +1288,7 @@ class ConvBnRelu(Function):
             if deferred:                  # no input gradient wanted: no dgrad to wait for
                 _release_wgrads(_WGRAD_DEFER - 1)
         # conv bias in front of a train-mode BatchNorm: the gradient is analytically zero
-        db = None if _direct(bias) else torch.zeros_like(gamma)
+        db = None if _direct(bias, async_on) else torch.zeros_like(gamma)
         return dx0, dx1, dscale, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1658,8 +1688,8 @@ class MaskedPool(Function):
 
 # the refinement loop's glue as one launch per iteration (rpnet_refine_glue_fwd / _bwd, csrc/refine.hip): BatchNorm + ReLU of
 # cre.q, cosine match, bilinear x4, softmax / threshold / 4x4 average and the next call's masked operand planes.
-# RPNET_GLUE_FUSE=0: the separate launches of rounds 1 - 4 (A/B switch; same bits)
-_GLUE_FUSE = os.environ.get("RPNET_GLUE_FUSE", "1") == "1"
+# _GLUE_FUSE = False: the separate launches of rounds 1 - 4 (A/B switch; same bits)
+_GLUE_FUSE = True
 
 
 def glue_supported(K, h, w, H, W, F, C=0, planes=0):
@@ -1808,7 +1838,7 @@ def dice_ce(logits, true, eps=1e-7):
     return DiceCE.apply(logits, true, True, -1, False, None)
 
 
-_DICE_MULTI = os.environ.get("RPNET_DICE_MULTI", "1") == "1"
+_DICE_MULTI = True
 
 
 class DiceCESum(Function):

@@ -15,15 +15,16 @@ import torch
 import torch.nn as nn
 
 from . import functional as RF
+from .schedule import Schedule
 
-# one-pass gradient fan-in for the feature maps with many consumers; RPNET_FANIN=0 leaves the fan-in to autograd's pairwise
+# one-pass gradient fan-in for the feature maps with many consumers; _FANIN = 0 (or Schedule.fanin) leaves the fan-in to autograd's pairwise
 # adds, 1 = RF.FanOut / RF.SplitRows only (round 4), 2 (default) = + both halves of the encoder output summed straight into
 # their rows (RF.SplitFan) and the skip-connection gradients added inside the max-pool backward (RF.PoolSkip) (A/B switch)
-_FANIN = int(os.environ.get("RPNET_FANIN", "2"))
+_FANIN = 2
 # A/B switches of two launch / traffic savings (both on by default): all operand packs of a forward in one launch, and
 # no fp32 output for conv_block's first layer when its consumer reads fp16 planes
-_PREPACK = os.environ.get("RPNET_PREPACK", "1") == "1"
-_ZSKIP = os.environ.get("RPNET_ZSKIP", "1") == "1"
+_PREPACK = True
+_ZSKIP = True
 # f16x2 mode: encoder input pixels per call from which the fp16 planes are used (below: three bf16 planes; see
 # RF.set_f16_active).  262144 = batch 2 at 256^2, where the two arithmetics are level.
 _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
@@ -32,8 +33,8 @@ _F16_MIN_PIXELS = int(os.environ.get("RPNET_F16_MIN_PIXELS", "262144"))
 # 5.07 ms), batch 8 is 20 % faster (9.8 vs 11.8 ms), batch 32 37 % (32.5 vs 44.5 ms).  0 = as in training.
 _F16_MIN_PIXELS_EVAL = int(os.environ.get("RPNET_F16_MIN_PIXELS_EVAL", "524288"))
 # eval-mode CRE: w_q on a second HIP stream beside w_k while a call has at most this many feature pixels (B h w)
-_CRE_STREAMS = os.environ.get("RPNET_CRE_STREAMS", "1") != "0"
-_CRE_STREAMS_MAX_PIXELS = int(os.environ.get("RPNET_CRE_STREAMS_MAX_PIXELS", "16384"))
+_CRE_STREAMS = True
+_CRE_STREAMS_MAX_PIXELS = 16384
 # train-mode CRE: w_q (convolution, BatchNorm + ReLU and, through autograd, their backward) on its own HIP stream beside
 # w_k: each branch's HBM-bound BatchNorm passes run beside the other branch's convolution — 18.11 -> 17.87 ms per batch-8
 # step, configs[4] 33.65 -> 33.34 ms (two alternations on one box, round 3); same kernels, same bits.
@@ -232,7 +233,8 @@ class U_Net(Unet_2D):
         else:
             x3 = self.Conv3.forward_nhwc(p2, cache, groups=groups, out_split=sk)
         # x3 and x4 feed their pool AND a skip connection: one backward pass for both gradients (RF.PoolSkip)
-        fan = _FANIN >= 2 and torch.is_grad_enabled() and x3.x.requires_grad
+        sch = getattr(self, "schedule", None)      # (the owning RP_Net's options; a stand-alone encoder follows the process defaults)
+        fan = (_FANIN if sch is None else sch.get("fanin", _FANIN)) >= 2 and torch.is_grad_enabled() and x3.x.requires_grad
         x3, p3 = RF.pool_skip(x3) if fan else (x3, pool(x3))
         x4 = self.Conv4.forward_nhwc(p3, cache, groups=groups, out_split=sk)
         x4, p4 = RF.pool_skip(x4) if fan else (x4, pool(x4))
@@ -356,8 +358,11 @@ class ContextCorrelationEncoder(nn.Module):
         # inference on a few slices (test_rpnet.py: 2 per call): either convolution is 256 four-wave blocks of a machine
         # that holds 512 — the two are independent, so w_q runs on the side stream beside w_k (one block of each per CU)
         pixels = fk.shape[0] * fk.shape[1] * fk.shape[2]
-        two_eval = _CRE_STREAMS and not t and not torch.is_grad_enabled() and fk.is_cuda and pixels <= _CRE_STREAMS_MAX_PIXELS
-        two_train = _CRE_STREAMS_TRAIN and t and fk.is_cuda
+        sch = getattr(self, "schedule", None)          # (set by the owning RP_Net; a stand-alone encoder follows the process defaults)
+        cre_eval = _CRE_STREAMS if sch is None else sch.get("cre_streams_eval", _CRE_STREAMS)
+        cre_train = _CRE_STREAMS_TRAIN if sch is None else sch.get("cre_streams_train", _CRE_STREAMS_TRAIN)
+        two_eval = cre_eval and not t and not torch.is_grad_enabled() and fk.is_cuda and pixels <= _CRE_STREAMS_MAX_PIXELS
+        two_train = cre_train and t and fk.is_cuda
         if two_eval or two_train:
             main = torch.cuda.current_stream(fk.device)
             side = RF._cre_stream(fk.device) if two_train else RF._side_stream(fk.device)
@@ -440,12 +445,24 @@ class RP_Net(nn.Module):
         if self.scale != 4:
             raise NotImplementedError("scale != 4: the UNet d4 map is 1/4 resolution")
         self.cre = ContextCorrelationEncoder(backbone_cfg, in_channels=num_feat)
+        # this model's own execution options (arithmetic, stream layout, fan-in, zero-tile skip); every field None = the
+        # process-wide default at call time.  See rpnet_amd/schedule.py
+        self.schedule = Schedule()
+        for m in (self.cre, self.encoder):
+            object.__setattr__(m, "schedule", self.schedule)         # (shared object, not a registered sub-module / buffer)
         self._cache = RF.WeightCache()
         self._serial = next(_NET_SERIAL)      # part of the key of this module's eval-mode fp16 scale history (RF.pred_*)
 
     # ---------------------------------------------------------------- forward
     def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, registration_field=None, grid=None,
                 query_labels=None, appr_query_labels=None):
+        sch = self.schedule
+        with RF.scope(conv_math=sch.conv_math, async_wgrad=sch.async_wgrad, mask_skip=sch.mask_skip):
+            return self._forward(supp_imgs, fore_mask, back_mask, qry_imgs, registration_field, grid, query_labels, appr_query_labels)
+
+    def _forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, registration_field=None, grid=None,
+                 query_labels=None, appr_query_labels=None):
+        sch = self.schedule
         n_ways, n_shots, n_queries = len(supp_imgs), len(supp_imgs[0]), len(qry_imgs)
         if n_queries != 1:
             raise NotImplementedError("n_queries != 1 (the reference's reader only produces one, few_shot_reader.py:80)")
@@ -465,8 +482,9 @@ class RP_Net(nn.Module):
         qry = qry_imgs[0].float()
         ns = supp.shape[0]
         # eval mode: with predicted scales (RF.pred_*: the previous call's maxima) the fp16 planes cost no extra pass, so they
-        # pay from the training threshold on; RPNET_EVAL_PREDICT=0 keeps round 2's measured scales and their higher threshold
-        thr = _F16_MIN_PIXELS if (self.training or not _F16_MIN_PIXELS_EVAL or not _F16_MIN_PIXELS or RF._EVAL_PREDICT) else _F16_MIN_PIXELS_EVAL
+        # pay from the training threshold on; RF._EVAL_PREDICT = False keeps round 2's measured scales and their higher threshold
+        f16_min, f16_min_eval = sch.get("f16_min_pixels", _F16_MIN_PIXELS), sch.get("f16_min_pixels_eval", _F16_MIN_PIXELS_EVAL)
+        thr = f16_min if (self.training or not f16_min_eval or not f16_min or RF._EVAL_PREDICT) else f16_min_eval
         RF.set_f16_active((ns + B) * H * W >= thr)      # f16x2 mode: fp16 planes only where they pay
         pred_key = None
         if RF.f16_mode():
@@ -492,8 +510,9 @@ class RP_Net(nn.Module):
         # two chains on two HIP streams — each chain's statistics-finalize and BatchNorm + ReLU passes run beside the other
         # chain's convolution, in backward likewise; the launches that touch a BatchNorm module's running statistics or
         # parameter gradients keep the order of the two calls (RF.order_begin).  Policy and measurements: _ENC_STREAMS
+        enc_streams, fanin = sch.get("enc_streams", _ENC_STREAMS), sch.get("fanin", _FANIN)
         two_chains = (self.training and supp.is_cuda and enc_mask is None and
-                      (_ENC_STREAMS == 2 or (_ENC_STREAMS == 1 and ns != B and ns <= 2 * B)))
+                      (enc_streams == 2 or (enc_streams == 1 and ns != B and ns <= 2 * B)))
         RF.order_begin(two_chains)
         split_fan = False
         if ns == B and not two_chains:
@@ -503,16 +522,16 @@ class RP_Net(nn.Module):
             d4 = d4.x
             # with the gradient fan-in of both halves (RF.SplitFan): the two 3x3 convolutions of the support CRE call, the
             # 2 T of the refinement loop (1-way 1-shot: ns == B, one CRE call on the support features)
-            split_fan = d4.requires_grad and _FANIN >= 2 and n_ways * n_shots == 1
+            split_fan = d4.requires_grad and fanin >= 2 and n_ways * n_shots == 1
             if split_fan:
                 uses = RF.SplitFan.apply(d4, ns, 2, 2 * self.num_iter)
                 supp_d4, qry_d4, fan_supp, fan_qry = uses[0], uses[2], uses[:2], uses[2:]
             else:
-                supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and _FANIN) else (d4[:ns], d4[ns:])
+                supp_d4, qry_d4 = RF.SplitRows.apply(d4, ns) if (d4.requires_grad and fanin) else (d4[:ns], d4[ns:])
         elif two_chains:
             main, side = torch.cuda.current_stream(supp.device), RF._cre_stream(supp.device)
             qin = qry.reshape(B, H, W, 1)
-            # both chains read the SAME cached packs: whatever the prepack above did not make (fp32 arithmetic, RPNET_PREPACK=0)
+            # both chains read the SAME cached packs: whatever the prepack above did not make (fp32 arithmetic, _PREPACK = False)
             # is made here, on the main stream, in front of the fork
             cache.materialize([w for w in self._pack_weights() if w is not self.cre.w_k[0].weight and w is not self.cre.w_q[0].weight],
                               planes)
@@ -573,13 +592,13 @@ class RP_Net(nn.Module):
         if split_fan:
             qry_uses = fan_qry
         else:
-            qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and _FANIN) else (qry_d4,) * (2 * T)
+            qry_uses = RF.FanOut.apply(qry_d4, 2 * T) if (qry_d4.requires_grad and fanin) else (qry_d4,) * (2 * T)
         # the loop's glue — cre.q's BatchNorm + ReLU, the cosine match, the bilinear x4, softmax / threshold / 4x4 average and the
         # operand planes of qry * mask, qry * (1 - mask) for the next iteration — is ONE launch per iteration where the shapes
         # fit (RF.CosineMatchUp / rpnet_refine_glue_fwd); a differentiable mask (soft_mask in training) keeps the separate path
         K = 1 + n_ways
         # the prototypes feed the T matches of the loop: one-pass gradient fan-in as for the query features
-        proto_uses = RF.FanOut.apply(protos, T) if (T > 1 and protos.requires_grad and _FANIN) else (protos,) * T
+        proto_uses = RF.FanOut.apply(protos, T) if (T > 1 and protos.requires_grad and fanin) else (protos,) * T
         soft_grad = soft and torch.is_grad_enabled()
         cq = self.cre.q[0].out_channels           # width of the relation features the glue matches against the prototypes
         fuse = qry_d4.is_cuda and RF.glue_supported(K, h, w, H, W, cq) and not soft_grad

@@ -1184,3 +1184,70 @@ def test_graphed_train_step_matches_eager(shots, ways, B, size):
         assert len(g._graphs) == 1
     finally:
         RF.set_async_wgrad(False)
+
+
+def test_two_models_with_their_own_schedules_in_one_process():
+    """rpnet_amd.schedule: two RP_Net instances of ONE process on different arithmetic / stream layout / zero-tile
+    skip — model A on the process defaults with async weight gradients into its bucket, model B with Schedule(conv_math="f32",
+    async_wgrad=False, mask_skip=False, cre_streams_train=False, fanin=0) — forward and backward INTERLEAVED (A fwd, B fwd, A bwd,
+    B bwd).  Each model's launches run on its own arithmetic (arith_counts), each model's result is bit-identical to that model run
+    alone, and the process-wide defaults are what they were."""
+    import rpnet_amd.functional as RF
+    import rpnet_amd.modules as RM
+    from rpnet_amd.parallel import FlatGradBucket
+    from rpnet_amd.schedule import Schedule
+    RM._F16_MIN_PIXELS = 0
+    RF.set_conv_math("f16x2")
+    RF.set_async_wgrad(False)
+    cfg = load_cfg(2)
+    (si, fg, bg, qi, ql, appr), _ = episode_tensors(77, 2, 64, DEV)
+
+    def make(kind):
+        net = build(cfg, True)
+        if kind == "A":
+            net.schedule.async_wgrad = True
+            return net, FlatGradBucket(net)
+        net.schedule = Schedule(conv_math="f32", async_wgrad=False, mask_skip=False, cre_streams_train=False, fanin=0)
+        for m in (net.cre, net.encoder):
+            object.__setattr__(m, "schedule", net.schedule)
+        return net, None
+
+    def grads(net, bucket):
+        if bucket is not None:
+            bucket.allreduce()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    def alone(kind):
+        net, bucket = make(kind)
+        if bucket is not None:
+            bucket.zero()
+        out = net(si, fg, bg, qi, appr_query_labels=appr)
+        total_loss(out, ql, 1.0).backward()
+        return out["output"].detach().clone(), grads(net, bucket)
+
+    ref_a, ref_b = alone("A"), alone("B")
+    (na, ba), (nb, _) = make("A"), make("B")
+    ba.zero()
+    base = (RF.conv_math(), RF._ASYNC["on"], RF._MASK_SKIP)
+    RF.reset_arith()
+    oa = na(si, fg, bg, qi, appr_query_labels=appr)
+    ca = RF.arith_counts()
+    RF.reset_arith()
+    ob = nb(si, fg, bg, qi, appr_query_labels=appr)
+    cb = RF.arith_counts()
+    assert (RF.conv_math(), RF._ASYNC["on"], RF._MASK_SKIP) == base
+    assert set(ca["conv3x3"]) == {"f16x2"} and set(cb["conv3x3"]) == {"f32"}, (ca, cb)
+    RF.reset_arith()
+    total_loss(oa, ql, 1.0).backward()          # A's backward after B's forward: its nodes carry A's options
+    wa = RF.arith_counts()
+    RF.reset_arith()
+    total_loss(ob, ql, 1.0).backward()
+    wb = RF.arith_counts()
+    assert set(wa["wgrad3x3"]) == {"f16x2"} and set(wb["wgrad3x3"]) == {"f32"}, (wa, wb)
+    ga, gb = grads(na, ba), grads(nb, None)
+    assert torch.equal(oa["output"], ref_a[0]) and torch.equal(ob["output"], ref_b[0])
+    assert ga.keys() == ref_a[1].keys() and all(torch.equal(ga[k], ref_a[1][k]) for k in ga)
+    assert gb.keys() == ref_b[1].keys() and all(torch.equal(gb[k], ref_b[1][k]) for k in gb)
+    # the two arithmetics agree to the bar of the fixtures (they are both fp32-equivalent)
+    assert rel_err(oa["output"], ob["output"]) < TOL

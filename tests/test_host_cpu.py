@@ -63,6 +63,49 @@ def test_no_cpu_fallback():
     assert "oracle" not in src.replace("CPU oracle", "").replace("oracle/", "")
 
 
+def test_schedule_scope_restores_process_defaults():
+    """rpnet_amd.schedule.Schedule / functional.scope (round 6): a model's own options are active only inside its forward call —
+    also when the call raises — and an unset field means the process-wide default."""
+    import rpnet_amd.functional as RF
+    from rpnet_amd.modules import RP_Net
+    from rpnet_amd.schedule import Schedule
+    base = (RF.conv_math(), RF._ASYNC["on"], RF._MASK_SKIP)
+    with RF.scope(conv_math="f32", async_wgrad=not base[1], mask_skip=not base[2]):
+        assert (RF.conv_math(), RF._ASYNC["on"], RF._MASK_SKIP) == ("f32", not base[1], not base[2])
+        with RF.scope():                                     # all None: nothing changes, nothing is restored to something else
+            assert RF.conv_math() == "f32"
+        assert RF.conv_math() == "f32"
+    assert (RF.conv_math(), RF._ASYNC["on"], RF._MASK_SKIP) == base
+    with pytest.raises(ZeroDivisionError):
+        with RF.scope(conv_math="bf16x3"):
+            1 / 0
+    assert RF.conv_math() == base[0]
+    sch = Schedule(conv_math="f16", fanin=0)
+    assert sch.get("fanin", 2) == 0 and sch.get("enc_streams", 1) == 1 and sch.overrides() == {"conv_math": "f16", "fanin": 0}
+    net = RP_Net(cfg={"align": False, "backbone": "UNet"}, backbone_cfg=load_cfg(1))
+    assert net.schedule.overrides() == {} and net.cre.schedule is net.schedule and net.encoder.schedule is net.schedule
+    assert "schedule" not in "".join(net.state_dict().keys())            # an attribute, not state
+    net.schedule.conv_math = "f32"
+    x, m = torch.zeros(1, 1, 32, 32), torch.zeros(1, 32, 32)
+    with pytest.raises(RuntimeError):                                     # (CPU tensors: the call fails inside the scope ...)
+        net([[x]], [[m]], [[1 - m]], [x], appr_query_labels=m)
+    assert RF.conv_math() == base[0]                                      # ... and the process default is back
+
+
+def test_environment_switch_budget():
+    """at most 25 RPNET_* environment variables are read by the product (library, bench.py, train_rpnet.py, C++)."""
+    import re
+    names = set()
+    for root in ("rpnet_amd", "bench.py", "train_rpnet.py", "__graft_entry__.py"):
+        path = os.path.join(ROOT, root)
+        files = [path] if os.path.isfile(path) else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs
+                                                     if f.endswith((".py", ".hip", ".h")) and "__pycache__" not in d]
+        for f in files:
+            src = open(f).read()
+            names |= set(re.findall(r"environ(?:\.get)?\(?\[?\s*\"(RPNET_[A-Z0-9_]+)\"", src)) | set(re.findall(r"getenv\(\"(RPNET_[A-Z0-9_]+)\"", src))
+    assert 0 < len(names) <= 25, sorted(names)
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

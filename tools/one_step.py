@@ -13,6 +13,8 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--conv-math", default="f16x2")
 ap.add_argument("--serial", action="store_true", help="everything on one stream")
+ap.add_argument("--mask-skip", action="store_true", help="zero-tile skip of the masked CRE convolutions ON (the library's default; bench.py's "
+                "headline and every roofline figure are measured with it OFF, and so is this script unless asked)")
 a = ap.parse_args()
 if a.serial:
     os.environ.update(RPNET_ASYNC_WGRAD="0", RPNET_CRE_STREAMS_TRAIN="0", RPNET_ENC_STREAMS="0")
@@ -30,6 +32,7 @@ torch.cuda.set_device(0)
 cfg = yaml.load(open(os.path.join(ROOT, "yamls", "example.yml")), Loader=yaml.FullLoader)
 cfg["n_iter_refinement"] = a.iters
 RF.set_conv_math(a.conv_math)
+RF._MASK_SKIP = bool(a.mask_skip)          # dense launches, as in bench.py's headline
 # bench.py's default schedule: weight gradients on their side stream (RPNET_ASYNC_WGRAD=0 / --serial: through autograd on the main one)
 RF.set_async_wgrad(not a.serial and os.environ.get("RPNET_ASYNC_WGRAD", "1") == "1")
 net = bench.build_model(cfg, dev)
