@@ -533,6 +533,13 @@ int rpnet_objective_bwd(const float* const* logits, float* const* dlogits, const
 int rpnet_argmax_masks(const float* pred, float* masks, float* counts, float* keep, int B, int K, int hw, rpnet_stream_t stream);
 int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, size_t n, rpnet_stream_t stream);
 
+/* ------------------------------------------------- diagnostics (not on the hot path)
+ * LDS canary (csrc/debug_probe.hip): `blocks` workgroups fill `lds_bytes` (1 KB .. 64 KB) of LDS with a pattern, re-read it for
+ * `spin_ticks` ticks of the 100 MHz wall clock and count changed words.  Launched beside the LDS-DMA kernels with an allocation that
+ * fits on their CUs it tests whether a neighbouring workgroup's `buffer_load ... lds` ever writes outside its own allocation
+ * (tools/lds_canary.py; the pooled-pass fault, lds_dma.h).  mismatches[3] (caller-zeroed): changed words, blocks run, sweeps. */
+int rpnet_debug_lds_canary(int blocks, int lds_bytes, long long spin_ticks, unsigned* mismatches, rpnet_stream_t stream);
+
 /* ------------------------------------------------- registration pre-step
  * dataset/few_shot_reader.py:109-198 get_registration_field with do_deformable=False (yamls/example.yml:101):
  * per slice, AffineRegistration (net/registration.py:316-357): theta [2][3] from identity by `iters` steps of

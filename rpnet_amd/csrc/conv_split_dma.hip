@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "conv_epilogue.h"
+#include "lds_dma.h"
 #include "split_bf16.h"
 
 namespace rpnet {
@@ -50,7 +51,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_split_dma_kernel(const rpne
     constexpr int NS = 4;                          // weight ring: K-steps k .. k+3
     constexpr int NW = WN * NP;                    // weight DMAs per wave and K-step (16 WN rows x NP planes)
     static_assert(HPW <= 6, "halo pieces are issued during taps 0 .. HPW-1; the wait counts below assume HPW <= 6");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>())];
+    // (the smallest form — 128-pixel patches x 64 columns, variant 14 — needs less than a CU's LDS minus the guarded passes' reservation:
+    // its allocation is padded up to that line, so that NO form of this kernel fits beside a guarded pooled BatchNorm block; lds_dma.h)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>()),
+                                                                       kLdsPerCu - kGuardedPassLds + 1024)];
+    RPNET_ASSERT_NO_CORESIDENCE(sizeof(smem));
     constexpr int WOFF = 2 * HBUF;                 // weight ring behind the two halo buffers
 
     const int t = threadIdx.x;

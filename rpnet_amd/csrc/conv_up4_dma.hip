@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "conv_epilogue.h"
+#include "lds_dma.h"
 #include "split_bf16.h"
 
 namespace rpnet {
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256, 1) void conv_up4_dma_kernel(const rpnet_conv_d
     constexpr int NPOS0 = (HPW + 1) / 2, NPOS1 = HPW - NPOS0;      // halo piece positions issued in steps 0 / 1 of a chunk
     static_assert(HPW <= 6, "halo piece positions per wave");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[cmax(2 * HBUF + NS * STAGE, epilogue_lds_bytes<WN, 2>())];
+    RPNET_ASSERT_NO_CORESIDENCE(sizeof(smem));
     constexpr int WOFF = 2 * HBUF;
 
     const int t = threadIdx.x;

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
     constexpr int NS = NSY, BOFF = ZOFF + A_STRIP;                 // NSY dy stages of 12 KB
     static_assert(LA >= 2 && LA <= 5 && LA % NSY >= 2, "the DMAs of step st + LA must not land in a slot / stage that step st or st + 1 reads");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BOFF + NS * B_STAGE];      // 72 + 72 KB (NSY = 6)
+    RPNET_ASSERT_NO_CORESIDENCE(sizeof(smem));
     constexpr int PXS = K64 ? 64 : BK;                             // pixels per K-step
 
     const int t = threadIdx.x;

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_dma_kernel(const rpnet_con
     // (slice, tap column, row half) registers that also carry the image-border redirects.
     constexpr int BOFF = NS * A_STAGE;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BOFF + NS * B_STAGE];
+    RPNET_ASSERT_NO_CORESIDENCE(sizeof(smem));
     static_assert(NP == 2, "two plane slots: two fp16 planes, or the two halves of a 64-pixel step of one plane (K64)");
     static_assert(!K64 || FAST, "the one-plane form needs a whole 64-pixel step in one image row");
     constexpr int PXS = K64 ? 64 : BK;                              // pixels per K-step

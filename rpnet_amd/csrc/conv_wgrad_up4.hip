@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_up4_kernel(const rpnet_conv
     constexpr int NS = 4;
     constexpr int BOFF = NS * A_STAGE;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BOFF + NS * B_STAGE];
+    RPNET_ASSERT_NO_CORESIDENCE(sizeof(smem));
 
     const int t = threadIdx.x;
     const int lane = t & 63;

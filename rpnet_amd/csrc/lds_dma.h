@@ -13,6 +13,17 @@
 
 namespace rpnet {
 
+// The pooled BatchNorm passes (bn.hip: bn_relu_pool_split_kernel, bn_bwd_apply_pool_split) made wrong 2 x 2 window decisions when their
+// blocks shared a CU with a block of an LDS-DMA kernel (profiles/r04_pool_apply_fault.txt, r05_pool_fault_repro.txt, r06_pool_fault.txt:
+// mechanism unknown; not a host-side lifetime race).  The guard is STRUCTURAL: those passes reserve kGuardedPassLds bytes of LDS they do
+// not use, and every kernel that issues `buffer_load ... lds` asserts at compile time (RPNET_ASSERT_NO_CORESIDENCE) that its own
+// allocation plus that reservation exceeds a CU's LDS — a new tile variant that would fit beside a guarded block does not build.
+constexpr int kLdsPerCu = 160 * 1024;
+constexpr int kGuardedPassLds = 52 * 1024;
+#define RPNET_ASSERT_NO_CORESIDENCE(lds_bytes)                                                                                    \
+    static_assert((lds_bytes) + rpnet::kGuardedPassLds > rpnet::kLdsPerCu,                                                         \
+                  "an LDS-DMA kernel form that fits on a CU beside a guarded pooled BatchNorm block (bn.hip pool_alone_bytes)")
+
 using srd_t = __attribute__((ext_vector_type(4))) unsigned;
 
 // raw buffer descriptor over `bytes` bytes at p (stride 0, bounds-checked: offsets >= bytes read as zero)

@@ -73,7 +73,7 @@ def scope(conv_math=None, async_wgrad=None, mask_skip=None):
     process-wide default.  Restores the defaults afterwards (also on an exception): nothing leaks into the next model's call.
     The backward pass does not need the scope: every autograd node captured the options it needs when it was created."""
     global _MASK_SKIP
-    saved = (_MATH["mode"], _MATH.get("f16_on", True), _ASYNC["on"], _MASK_SKIP)
+    saved = (_MATH["mode"], None, _ASYNC["on"], _MASK_SKIP)
     try:
         if conv_math is not None and conv_math != saved[0]:
             set_conv_math(conv_math)
@@ -85,7 +85,7 @@ def scope(conv_math=None, async_wgrad=None, mask_skip=None):
     finally:
         if _MATH["mode"] != saved[0]:
             set_conv_math(saved[0])
-        _MATH["f16_on"] = saved[1]
+        # (the per-forward fp16-planes flag, set_f16_active, is the LAST call's decision until the next forward makes its own)
         _ASYNC["on"] = saved[2]
         _MASK_SKIP = saved[3]
 

@@ -121,6 +121,7 @@ _SIGS = {
     "rpnet_objective_bwd": (ci, [C.POINTER(vp), C.POINTER(vp), C.POINTER(cf), ci, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp]),
     "rpnet_argmax_masks": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
     "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
+    "rpnet_debug_lds_canary": (ci, [ci, ci, C.c_longlong, vp, vp]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 ABI_VERSION = 106      # RPNET_ABI_VERSION of include/rpnet_abi.h
