@@ -121,7 +121,9 @@ def step(net, bucket, inp, scaler, exposed=None):
         exposed.append((a, b))
     else:
         bucket.allreduce()
-    return loss
+    # (detached: a loss tensor that outlives the step keeps the step's autograd nodes — among them every parameter's AccumulateGrad
+    # node, stamped with the stream it first ran on — alive into a later leg that runs the same layers on another stream layout)
+    return loss.detach()
 
 
 def mask_skip_leg(net, bucket, inp, scaler, batch, fence, RF, dense_value):

@@ -62,6 +62,17 @@ class FlatGradBucket:
         self.split = cuts[-1] if cuts else None           # start of the last (first finished) segment
         self._work = {}                                   # segment index -> in-flight all-reduce
         self._hooks = []
+        self._hook = None
+        self._tail_work = None
+        self._ensure_hooks()
+
+    def _ensure_hooks(self):
+        """Register the post-accumulate hooks that launch a finished segment's all-reduce — only once there IS an exchange (a process
+        group of more than one rank, or force_active): a hook keeps its parameter's AccumulateGrad node alive from the stream it was
+        registered on, which a single-GPU run that later steps on another stream (graph capture warm-up, the serialised profiling
+        step) reports as "AccumulateGrad node's stream does not match" and pays for with a synchronisation."""
+        if self._hooks or not self._active():
+            return
         # the last parameter (module order) of segment i-1 is the FIRST gradient of that segment backward produces:
         # when it lands, segment i (everything behind it) is complete
         for i in range(1, len(self.bounds) - 1):
@@ -74,7 +85,6 @@ class FlatGradBucket:
                 last._rpnet_autograd_grad = self          # keep this one on AccumulateGrad so that the hook fires (while wants_hooks())
                 self._hooks.append(last.register_post_accumulate_grad_hook(self._launcher(i)))
         self._hook = self._hooks[-1] if self._hooks else None
-        self._tail_work = None
 
     def wants_hooks(self):
         """True while a tagged parameter's gradient has to pass AccumulateGrad for its hook to launch an exchange (functional._direct)"""
@@ -104,6 +114,7 @@ class FlatGradBucket:
     def zero(self):
         from .functional import reset_async
         reset_async()                # no side-stream accumulation may still be in flight into the buffer
+        self._ensure_hooks()         # (a process group created, or force_active set, after construction)
         self._work = {}
         self._tail_work = None
         self.flat.zero_()
