@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
 // depending on what else is resident; with the full wait: 0 of 16.  The wrong decisions moved the gradients of the
 // layers below by 1e-4 ... 5e-2 (relative, max norm) in those steps.
 template <int NP, bool DRAIN = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const YSrc ysrc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void bn_bwd_apply_pool_split(const float* __restrict__ dp, const YSrc ysrc,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, float* __restrict__ dy,

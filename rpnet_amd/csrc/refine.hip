@@ -175,7 +175,10 @@ struct RefineBwd {
     float scaler; int K, h, w;
 };
 
-__global__ __launch_bounds__(256) void refine_glue_bwd_kernel(const RefineBwd a) {
+// <= 128 registers per lane (round 6: 130 before): a wave of this pass then fits on a SIMD beside a wave of the LDS-DMA convolution kernel
+// (384 of the 512 registers).  With 130 its blocks waited for the other branch's input gradient and the weight gradient to leave the CUs:
+// 100 - 190 us per launch inside the step against 26 alone (profiles/r06_timeline.txt), on the backward chain of every refinement iteration.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void refine_glue_bwd_kernel(const RefineBwd a) {
     __shared__ float dps[kMaxK][RT * RT];
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const int t = threadIdx.x, b = blockIdx.y, K = a.K, h = a.h, w = a.w, H = 4 * h, W = 4 * w;

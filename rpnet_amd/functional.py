@@ -923,8 +923,20 @@ class ConvBnRelu(Function):
                      None, 1)
             elif _use_split(pw, x0, x1):
                 f16 = _f16_sources(op0, op1, in_scale, in_mode, pw.taps == 1) if f16_mode() else None
+                up4e = False
                 if f16 is not None:      # fp16 planes of the sources (their scales measured by their own launches)
                     fp = _MATH["f16_planes"]
+                    # up_conv in eval mode on its collapsed four-tap form too (round 6; training: round 5): the folded BatchNorm affine,
+                    # ReLU and the measured maximum are the up4 kernel's plain epilogue; its output feeds a concatenation, which
+                    # splits the fp32 tensor itself (out_split "scale": no planes wanted from this launch)
+                    up4e = out_split in ("scale", False) and _up4_ok(pw, fp, upsample, x1, in_scale, f16[0], N, H, W, cout)
+                if up4e:
+                    pk4 = pw.up4_packs(fp)
+                    d = _desc(f16[0], None, pk4[0], bias, None, 0, z, None, N, H, W, pw.taps, 1, 1, scale, shift, 1)
+                    d.split_planes = fp
+                    d.acc_scale_col, d.acc_scale_x = ptr(pk4[2]), ptr(f16[2])
+                    d._keep = (f16, pk4)
+                elif f16 is not None:
                     wps, _, t_row, _ = pw.split_packs(fp)
                     d = _desc(f16[0], f16[1], wps, bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                     d.split_planes = fp
@@ -937,20 +949,26 @@ class ConvBnRelu(Function):
                     d = _desc(_split_operand(op0, np_, in_scale, in_mode), None if x1 is None else _split_operand(op1, np_),
                               pw.split_packs(np_)[0], bias, None, 0, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                     d.split_planes = np_
-                d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)
-                if sp is not None and out_split in (True, "corr"):
+                if up4e:
+                    d.out_absmax = ptr(mx)
+                else:
+                    d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)
+                if sp is not None and out_split in (True, "corr") and not up4e:
                     # the fp16 planes of output / predicted scale straight out of the epilogue: no second pass over z
                     fpo = _MATH["f16_planes"]
                     z16 = torch.empty((fpo, N, H, W, cout), device=x0.device, dtype=torch.float16)
                     d.y_split, d.split_out_planes, d.y_split_scale = ptr(z16), fpo, ptr(sp)
-                if _EVAL_SPLITK and d.split_planes == 2 and pw.taps == 9 and N * H * W * cout <= 128 * 256 * 64:
-                    # a grid that would leave half of the CUs idle (batch-2 calls): lend the workspace that lets the launch
-                    # cut its K range into parts (rpnet_conv_desc.splitk_ws)
-                    nb = query("rpnet_conv_splitk_workspace_bytes", C.byref(d))
-                    if nb:
-                        d._ws = _ws(nb, x0)
-                        d.splitk_ws, d.splitk_ws_bytes = ptr(d._ws), nb
-                _cconv("rpnet_conv_fwd", d)
+                if up4e:
+                    _cup4(d, 1)
+                else:
+                    if _EVAL_SPLITK and d.split_planes == 2 and pw.taps == 9 and N * H * W * cout <= 128 * 256 * 64:
+                        # a grid that would leave half of the CUs idle (batch-2 calls): lend the workspace that lets the launch
+                        # cut its K range into parts (rpnet_conv_desc.splitk_ws)
+                        nb = query("rpnet_conv_splitk_workspace_bytes", C.byref(d))
+                        if nb:
+                            d._ws = _ws(nb, x0)
+                            d.splitk_ws, d.splitk_ws_bytes = ptr(d._ws), nb
+                    _cconv("rpnet_conv_fwd", d)
             else:
                 d = _desc(x0, x1, pw.wp, bias, in_scale, in_mode, z, None, N, H, W, pw.taps, upsample, 1, scale, shift, 1)
                 d.y_split, d.split_out_planes, d.out_absmax = ptr(zs), np_out, ptr(mx)

@@ -495,8 +495,9 @@ class RP_Net(nn.Module):
         planes = RF.pack_planes()
         if _PREPACK and planes and (self.training or not self.freeze_packs):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
-            # (training: the two up_conv layers on their collapsed four-tap packs, RF._UP4)
-            ups = (self.encoder.Up5.up[1].weight, self.encoder.Up4.up[1].weight) if self.training else ()
+            # (the two up_conv layers on their collapsed four-tap packs, RF._UP4)
+            # (round 6: eval mode too — the collapsed form's epilogue carries the folded BatchNorm affine)
+            ups = (self.encoder.Up5.up[1].weight, self.encoder.Up4.up[1].weight) if (self.training or RF.f16_mode()) else ()
             if self.training and supp.is_cuda:      # the packing on its own stream beside the first-layer convolution
                 cache.prepack_async(self._pack_weights(), planes, supp.device, ups)
             else:
