@@ -7,6 +7,9 @@ from tests.helpers import episode_tensors, load_cfg
 from tests.test_gpu_model import build
 from rpnet_amd.graph import GraphedEval
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if os.environ.get("EVAL_UP4") == "0":         # A/B: the two up_conv layers on the nine-tap form (round 5's eval path)
+    import rpnet_amd.functional as _RF
+    _RF._UP4 = False
 cfg = load_cfg(10); net = build(cfg, False); g = GraphedEval(net)
 (si, fg, bg, qi, ql, appr), _ = episode_tensors(5, B, 256, "cuda:0")
 def run(fn, n=30):
