@@ -51,7 +51,7 @@ enum rpnet_status {
  * rpnet_upconv_collapse_weights added; nothing existing changed).  A caller MUST zero-initialise rpnet_conv_desc (fields added
  * later are optional features that are off at zero) and SHOULD compare rpnet_version() with the RPNET_ABI_VERSION it was built
  * against. */
-#define RPNET_ABI_VERSION 106
+#define RPNET_ABI_VERSION 107
 int rpnet_version(void);
 const char* rpnet_last_error_string(void);
 
@@ -408,7 +408,11 @@ int rpnet_local_corr_split_fwd(const void* f1_split, const void* f2_split, float
                                int cstride, int planes, const float* scale1, const float* scale2,
                                float* out_absmax /* may be NULL; as rpnet_conv_desc.out_absmax: the correlation's own fp16
                                                     planes (operand of the 1x1 convolution) are scaled by this bound */,
-                               rpnet_stream_t stream);
+                               void* corr_planes /* optional (planes 1 / 2; round 6): the correlation also as fp16 planes
+                                                    [planes][B][h][w][cstride] of corr / *corr_plane_scale, a power-of-two scale the CALLER
+                                                    predicted (rpnet_predict_scales; out_absmax of the same launch is the check) — the
+                                                    eval-mode call then needs no split pass over the tensor */,
+                               const float* corr_plane_scale, rpnet_stream_t stream);
 int rpnet_local_corr_split_bwd(const void* f1_split, const void* f2_split, const float* dcorr, float* df1, float* df2,
                                int B, int h, int w, int C, int r, int cstride, int planes, const float* scale1,
                                const float* scale2, const float* df1_add, void* workspace, size_t workspace_bytes,

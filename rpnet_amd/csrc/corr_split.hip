@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                                                                       float* __restrict__ corr, const int B, const int h,
                                                                       const int w, const int C, const int cstride,
                                                                       const float inv_sqrt_c_in, const float* __restrict__ s1,
-                                                                      const float* __restrict__ s2, float* __restrict__ out_absmax) {
+                                                                      const float* __restrict__ s2, float* __restrict__ out_absmax,
+                                                                      unsigned short* __restrict__ cplanes,
+                                                                      const float* __restrict__ cscale) {
     // NP <= 2: fp16 planes of f / s with the producers' tensor scales (rpnet_bn_relu); the scores are multiplied by s1 s2
     const float inv_sqrt_c = NP <= 2 ? inv_sqrt_c_in * (*s1 * *s2) : inv_sqrt_c_in;
     constexpr int K = 2 * R + 1, KK = K * K, HT = 8 + 2 * R, NQ = HT * HT, NT_N = (NQ + 31) / 32, NQP = NT_N * 32;
@@ -143,6 +145,12 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
     // gather the (2R+1)^2 window of every pixel out of S, half a tile (32 pixels) at a time
     float* S = reinterpret_cast<float*>(smem);          // [32][NQP]
     float* cb = corr + (size_t)b * h * w * cstride;
+    // optional (round 6, eval mode): the correlation also as fp16 planes of corr / *cscale — a PREDICTED power-of-two scale (the caller's
+    // rpnet_predict_scales history; out_absmax of this launch is the check), what the 1x1 convolution over cat([corr, fm1]) reads:
+    // no second pass over the tensor
+    unsigned short* cpb = cplanes ? cplanes + (size_t)b * h * w * cstride : nullptr;
+    const size_t cpstride = (size_t)B * h * w * cstride;
+    const float cinv = cplanes ? 1.f / *cscale : 1.f;
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -166,8 +174,15 @@ __global__ __launch_bounds__(256, 2) void local_corr_mfma_fwd_kernel(const unsig
                 v = S[pl * NQP + (py + c) * HT + px + a] * inv_sqrt_c;
             }
             if (y < h && x < w) {
-                cb[((size_t)y * w + x) * cstride + o] = v;
+                const size_t idx = ((size_t)y * w + x) * cstride + o;
+                cb[idx] = v;
                 amax = fmaxf(amax, fabsf(v));
+                if (cpb) {
+                    const float vs = v * cinv;
+                    const unsigned hb = f16_bits(vs);
+                    cpb[idx] = (unsigned short)hb;
+                    if (NP == 2) cpb[cpstride + idx] = (unsigned short)f16_bits(vs - f16_val(hb));
+                }
             }
         }
     }
@@ -410,7 +425,7 @@ int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, i
 
 extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, float* corr, int B, int h, int w, int C, int r,
                                           int cstride, int planes, const float* scale1, const float* scale2, float* out_absmax,
-                                          rpnet_stream_t stream) {
+                                          void* corr_planes, const float* corr_plane_scale, rpnet_stream_t stream) {
     using namespace rpnet;
     RPNET_REQUIRE(f1s && f2s && corr, RPNET_ERR_ARG, "local_corr_split_fwd: null pointer");
     RPNET_REQUIRE(r == 5 && C % 32 == 0 && cstride >= 121 && cstride <= 160 &&
@@ -420,17 +435,20 @@ extern "C" int rpnet_local_corr_split_fwd(const void* f1s, const void* f2s, floa
     RPNET_REQUIRE((size_t)h * w * C * 2 < (1UL << 31), RPNET_ERR_SHAPE, "local_corr_split_fwd: image too large");
     const int tiles = cdiv(h, 8) * cdiv(w, 8);
     const float isc = 1.0f / sqrtf((float)C);
+    RPNET_REQUIRE(!corr_planes || (planes <= 2 && corr_plane_scale), RPNET_ERR_ARG,
+                  "local_corr_split_fwd: output planes are fp16 planes (planes 1 / 2) of corr / *corr_plane_scale");
     const unsigned short* a = (const unsigned short*)f1s;
     const unsigned short* b2 = (const unsigned short*)f2s;
+    unsigned short* cp = (unsigned short*)corr_planes;
     if (planes == 3)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 3>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C, cstride, isc,
-                           (const float*)nullptr, (const float*)nullptr, out_absmax);
+                           (const float*)nullptr, (const float*)nullptr, out_absmax, (unsigned short*)nullptr, (const float*)nullptr);
     else if (planes == 2)
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 2>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
-                           cstride, isc, scale1, scale2, out_absmax);
+                           cstride, isc, scale1, scale2, out_absmax, cp, corr_plane_scale);
     else
         hipLaunchKernelGGL((local_corr_mfma_fwd_kernel<5, 1>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream, a, b2, corr, B, h, w, C,
-                           cstride, isc, scale1, scale2, out_absmax);
+                           cstride, isc, scale1, scale2, out_absmax, cp, corr_plane_scale);
     return check_launch("local_corr_split_fwd");
 }
 

@@ -47,7 +47,9 @@ _ASYNC = {"on": False, "side": {}, "pending": set(), "queued": False, "fifo": []
 # "f16" = ONE fp16 plane of operand / scale (plain fp16 operands, fp32 accumulation, fp32 BatchNorm statistics): the
 # reduced-precision arithmetic of BASELINE configs[4]; NOT fp32-equivalent (tolerances: DESIGN.md §6).
 _MODES = {"f32": (0, False, 0), "bf16x3": (3, False, 0), "f16x2": (3, True, 2), "f16": (3, True, 1)}
-_CORR16 = True   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
+_CORR16 = True
+# eval mode on predicted scales: the correlation kernel writes its own fp16 planes (False: a split pass behind it; A/B switch of round 6)
+_CORR_PRED_PLANES = True   # f16x2: the correlation on fp16 planes too (0: three bf16 planes)
 _MATH = {}
 
 
@@ -1617,15 +1619,21 @@ class LocalCorr(Function):
             ARITH[("corr", _PLANE_NAME[np_])] += 1
             # the correlation has no a-priori bound: the launch measures max |corr|, its planes are scaled by that
             mx = _absmax_slot(f1.device) if (produced is not None and _CONV1X1_SPLIT) else None
+            # eval mode on predicted scales (pred_scale: the previous call's maximum of this very launch x 4): the kernel writes the
+            # correlation's planes itself; otherwise (training, a measuring call) a split pass on the measured bound
+            sp = pred_scale(f1.device) if (mx is not None and _CORR_PRED_PLANES) else None
+            cpl = torch.empty((np_, B, h, w, CORR_STRIDE), device=f1.device, dtype=torch.float16) if sp is not None else None
             call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, ptr(s1), ptr(s2),
-                 ptr(mx))
-            if mx is not None:
+                 ptr(mx), ptr(cpl), ptr(sp))
+            if cpl is not None:
+                produced["p16"], produced["scale"] = cpl, sp
+            elif mx is not None:
                 produced["p16"], produced["scale"] = split_f16(corr, mx, planes=np_, a_is_bound=True)
             ctx.save_for_backward(f1s, f2s, s1, s2)
         elif np_:
             f1s, f2s = _split_operand(o1, np_), _split_operand(o2, np_)
             ARITH[("corr", _PLANE_NAME[np_])] += 1
-            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None, None)
+            call("rpnet_local_corr_split_fwd", ptr(f1s), ptr(f2s), ptr(corr), B, h, w, Cc, r, CORR_STRIDE, np_, None, None, None, None, None)
             ctx.save_for_backward(f1s, f2s)
         else:
             # the fp32 kernels read VALUES: a planes-only operand (a 4-byte placeholder behind f1 / f2) must raise here,

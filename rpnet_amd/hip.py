@@ -87,7 +87,7 @@ _SIGS = {
     "rpnet_local_corr_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "rpnet_local_corr_bwd_workspace_bytes": (cs, [ci, ci, ci, ci]),
     "rpnet_local_corr_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, cs, vp]),
-    "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
+    "rpnet_local_corr_split_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "rpnet_local_corr_split_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, cs, vp]),
     "rpnet_affine_register": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cd, cd, cd, cd, vp]),
     "rpnet_sum_n": (ci, [vp, ci, vp, cs, vp]),
@@ -124,7 +124,7 @@ _SIGS = {
     "rpnet_debug_lds_canary": (ci, [ci, ci, C.c_longlong, vp, vp]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
-ABI_VERSION = 106      # RPNET_ABI_VERSION of include/rpnet_abi.h
+ABI_VERSION = 107      # RPNET_ABI_VERSION of include/rpnet_abi.h
 
 
 def lib_path():

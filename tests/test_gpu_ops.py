@@ -547,6 +547,32 @@ def test_local_correlation_golden(RF, golden):
     assert rel_err(nchw(a.grad), g["corr_r5_g1"]) < 1e-4 and rel_err(nchw(bb.grad), g["corr_r5_g2"]) < 1e-4
 
 
+@pytest.mark.parametrize("planes", [2, 1])
+def test_local_correlation_writes_its_planes_on_a_given_scale(RF, planes):
+    """rpnet_local_corr_split_fwd(corr_planes, corr_plane_scale) (round 6, the eval call on predicted scales): the fp16 planes the kernel
+    writes beside the fp32 correlation are the planes rpnet_split_f16 makes of that tensor on the same scale, bit for bit, pad channels
+    zero; out_absmax still measures the maximum."""
+    from rpnet_amd.hip import call, ptr
+    B, h, w, Cc = 2, 24, 16, 128
+    f1, f2 = torch.relu(nhwc(rnd(71, B, Cc, h, w))).to(DEV), torch.relu(nhwc(rnd(72, B, Cc, h, w))).to(DEV)
+    s_in = torch.tensor([2.0 ** -12], device=DEV)
+    p1 = RF.split_f16(f1, s_in, want_scale=False, planes=planes)[0]
+    p2 = RF.split_f16(f2, s_in, want_scale=False, planes=planes)[0]
+    corr = torch.empty(B, h, w, 128, device=DEV)
+    mx = torch.zeros(1, device=DEV)
+    sc = torch.tensor([2.0 ** -9], device=DEV)                      # a "predicted" power-of-two scale
+    cpl = torch.empty(planes, B, h, w, 128, device=DEV, dtype=torch.float16)
+    call("rpnet_local_corr_split_fwd", ptr(p1), ptr(p2), ptr(corr), B, h, w, Cc, 5, 128, planes, ptr(s_in), ptr(s_in), ptr(mx), ptr(cpl), ptr(sc))
+    want = RF.split_f16(corr, sc, want_scale=False, planes=planes)[0]
+    assert torch.equal(cpl.view(torch.int16), want.view(torch.int16))
+    assert float(cpl[..., 121:].abs().max()) == 0.0
+    assert float(mx) == float(corr.abs().max()) and float(mx) / float(sc) < 65504
+    # and the same launch without planes gives the same fp32 tensor
+    corr2 = torch.empty_like(corr)
+    call("rpnet_local_corr_split_fwd", ptr(p1), ptr(p2), ptr(corr2), B, h, w, Cc, 5, 128, planes, ptr(s_in), ptr(s_in), None, None, None)
+    assert torch.equal(corr, corr2)
+
+
 def test_masked_pool_golden_and_grad(RF, golden):
     from oracle import rpnet_oracle as O
     g = golden("ops")

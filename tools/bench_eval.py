@@ -7,6 +7,9 @@ from tests.helpers import episode_tensors, load_cfg
 from tests.test_gpu_model import build
 from rpnet_amd.graph import GraphedEval
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if os.environ.get("EVAL_CORR_PLANES") == "0":  # A/B: the correlation's planes by a split pass behind the kernel (round 5's eval path)
+    import rpnet_amd.functional as _RF0
+    _RF0._CORR_PRED_PLANES = False
 if os.environ.get("EVAL_UP4") == "0":         # A/B: the two up_conv layers on the nine-tap form (round 5's eval path)
     import rpnet_amd.functional as _RF
     _RF._UP4 = False
