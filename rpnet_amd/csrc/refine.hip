@@ -175,9 +175,7 @@ struct RefineBwd {
     float scaler; int K, h, w;
 };
 
-// <= 128 registers per lane (round 6: 130 before): a wave of this pass then fits on a SIMD beside a wave of the LDS-DMA convolution kernel
-// (384 of the 512 registers).  With 130 its blocks waited for the other branch's input gradient and the weight gradient to leave the CUs:
-// 100 - 190 us per launch inside the step against 26 alone (profiles/r06_timeline.txt), on the backward chain of every refinement iteration.
+// <= 128 registers per lane: a wave of this pass then fits on a SIMD beside a wave of the LDS-DMA convolution kernel (384 of the 512)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void refine_glue_bwd_kernel(const RefineBwd a) {
     __shared__ float dps[kMaxK][RT * RT];
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
@@ -191,15 +189,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float rsy = (float)h / (float)H, rsx = (float)w / (float)W;
         const int Y0 = max(0, (y - 1) * 4 - 1), Y1 = min(H - 1, (y + 1) * 4 + 4 + 1);
         const int X0 = max(0, (x - 1) * 4 - 1), X1 = min(W - 1, (x + 1) * 4 + 4 + 1);
+        // The window of a feature pixel is at most 15 x 15 logit gradients (rows / columns (y - 1) 4 - 1 .. (y + 1) 4 + 5), this lane's share
+        // at most 4 rows.  Round 6: ALL of a lane's loads are issued before the first is used (fixed trip counts, zeros outside the window)
+        // — the launch sits on the backward chain beside two streaming GEMM kernels, where a memory round trip takes microseconds: the
+        // nested loops below it replaced were a chain of ~100 dependent 4-byte loads per lane, 100 - 190 us per launch in the step against
+        // 26 alone (profiles/r06_timeline.txt).  Same products, same order of additions: same bits.
+        constexpr int NRW = 4, NCW = 15;
+        float wx[NCW], wyv[NRW];
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) wx[c] = (X0 + c <= X1) ? bl_weight(X0 + c, x, rsx, w) : 0.f;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) wyv[r] = (Y0 + part + 4 * r <= Y1) ? bl_weight(Y0 + part + 4 * r, y, rsy, h) : 0.f;
         for (int k = 0; k < K; ++k) {
             const float* g = a.dlogits + ((size_t)b * K + k) * H * W;
+            float v[NRW][NCW];
+#pragma unroll
+            for (int r = 0; r < NRW; ++r) {
+                const int Y = Y0 + part + 4 * r;
+                const bool rowok = Y <= Y1 && wyv[r] != 0.f;
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) v[r][c] = (rowok && X0 + c <= X1) ? g[(size_t)Y * W + X0 + c] : 0.f;
+            }
             float acc = 0.f;
-            for (int Y = Y0 + part; Y <= Y1; Y += 4) {
-                const float wy = bl_weight(Y, y, rsy, h);
-                if (wy == 0.f) continue;
+#pragma unroll
+            for (int r = 0; r < NRW; ++r) {
+                if (wyv[r] == 0.f) continue;
                 float row = 0.f;
-                for (int X = X0; X <= X1; ++X) row += g[(size_t)Y * W + X] * bl_weight(X, x, rsx, w);
-                acc += wy * row;
+#pragma unroll
+                for (int c = 0; c < NCW; ++c)
+                    if (X0 + c <= X1) row += v[r][c] * wx[c];
+                acc += wyv[r] * row;
             }
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
