@@ -137,21 +137,17 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const double* __restric
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* running_mean, float* running_var, long long* num_batches_tracked,
                                   float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
-    // ONE WAVE per channel (round 6; four channels per block): the sums over the partial rows are wave shuffles — no block barrier,
-    // no LDS.  The launch sits between every convolution and its BatchNorm + ReLU pass on the step's critical chain (34 per step): the
-    // block-per-channel form spent its 6 us in four barrier-separated block reductions per group.
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += G;  // one "forward call" per group
-    if (c >= C) return;
+    __shared__ double red4[8];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (num_batches_tracked && c == 0 && lane == 0) *num_batches_tracked += G;  // one "forward call" per group
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {  // sequential: one running-stat update per group, in call order
         double s = 0, q = 0;
-        for (int b = lane; b < nblk; b += 64) {
+        for (int b = lane; b < nblk; b += 256) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s += p[0]; q += p[1];
         }
-        s = wave_sum(s); q = wave_sum(q);
+        s = block_sum256(s, red4); q = block_sum256(q, red4 + 4);
         const double m = s / (double)R;
         double var = q / (double)R - m * m;
         if (var < 0) var = 0;
@@ -343,24 +339,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 __global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                 float* coef, float* dgamma, float* dbeta, int accumulate, const float* __restrict__ pmax,
                                 const float* __restrict__ scale, float* __restrict__ bound) {
-    // one wave per channel, four channels per block (see bn_stats_finalize)
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double red4[8];
+    __shared__ float redm[4];
+    const int c = blockIdx.x, lane = threadIdx.x;
     double tg = 0, tb = 0;
     float bnd = 0.f;
     for (int g = 0; g < G; ++g) {
         double s1 = 0, s2 = 0;
         float mx = 0.f;
-        for (int b = lane; b < nblk; b += 64) {
+        for (int b = lane; b < nblk; b += 256) {
             const double* p = partial + ((size_t)(g * nblk + b) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
             if (pmax) mx = fmaxf(mx, pmax[(size_t)(g * nblk + b) * C + c]);
         }
-        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        s1 = block_sum256(s1, red4); s2 = block_sum256(s2, red4 + 4);
         if (pmax) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = block_max256(mx, redm);
             bnd = fmaxf(bnd, fabsf(scale[g * C + c]) * (mx + (float)(fabs(s1) / (double)R) + (float)(fabs(s2) / sqrt((double)R))));
         }
         if (lane == 0) {
@@ -750,7 +744,7 @@ extern "C" int rpnet_bn_stats(const float* y, int N, int HW, int C, int groups, 
     hipStream_t s = (hipStream_t)stream;
     if (bn_lds_window() == 64) hipLaunchKernelGGL(bn_stats_partial<64>, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
     else hipLaunchKernelGGL(bn_stats_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, y, (double*)workspace, R, C, gm);
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)workspace, gm.nblk, R, C,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(256), 0, s, (const double*)workspace, gm.nblk, R, C,
                        groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
                        mean, invstd);
     return check_launch("bn_stats");
@@ -765,7 +759,7 @@ extern "C" int rpnet_bn_stats_from_partial(const double* partial, int nblk, int 
                   "bn_stats_from_partial: null pointer");
     RPNET_REQUIRE(groups >= 1 && N % groups == 0, RPNET_ERR_SHAPE, "bn_stats_from_partial: N=%d groups=%d", N, groups);
     const long R = (long)(N / groups) * HW;
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblk, R, C, groups, gamma,
                        beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
     return check_launch("bn_stats_from_partial");
 }
@@ -884,7 +878,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         else
             hipLaunchKernelGGL(bn_bwd_partial_pool<256>, dim3(gp.nblk, groups), dim3(256), alone, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, Rp, C, gp, pg);
-        hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * HW * C;
         // DRAIN (default; RPNET_BN_POOL_DRAIN=0: the A/B switch that brings the fault back): see bn_bwd_apply_pool_split
@@ -904,7 +898,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         // the caller made the sums itself (the first layer without its pre-BatchNorm tensor: rpnet_conv1_bn_bwd_partial):
         // [groups * given_rows][C][2] sums (and [..][C] maxima for fp16 planes)
         RPNET_REQUIRE(given_rows > 0 && (!f16 || given_pmax), RPNET_ERR_ARG, "bn_bwd: given partial sums need their row count (and maxima for fp16 planes)");
-        hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 3) / 4), dim3(256), 0, s, given_partial, given_rows, R, C, groups, coef, dgamma, dbeta,
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, given_partial, given_rows, R, C, groups, coef, dgamma, dbeta,
                            accumulate, f16 ? given_pmax : (const float*)nullptr, scale, bound);
     } else {
         if (bn_lds_window() == 64)
@@ -913,7 +907,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         else
             hipLaunchKernelGGL(bn_bwd_partial<256>, dim3(gm.nblk, groups), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd, partial,
                                pmax, R, C, gm);
-        hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 3) / 4), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gm.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
     }
     // dy == NULL and dy_split == NULL: reduction pass only — dgamma, dbeta and the coefficients (workspace +
