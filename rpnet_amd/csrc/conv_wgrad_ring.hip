@@ -43,7 +43,10 @@ __device__ __forceinline__ void static_for_r(F&& f) {
 // LA: how many K-steps ahead of their use the DMAs are issued (the group "of step st" = the strip that step st + 1 brings in and the dy
 // tile of step st; a group is waited for two steps before its step, so LA - 2 groups stay in flight across every barrier); NSY: dy stages
 // (LA mod NSY must not be 0 or 1; the strip ring's eight slots allow LA = 2 .. 5)
-template <bool K64, int ABL = 0, int LA = 5, int NSY = 6>
+// BI (diagnostic, rpnet_conv_desc.tune 18; profiles/r06_pool_fault.txt): the DMAs through __builtin_amdgcn_raw_ptr_buffer_load_lds — as the LDS-DMA
+// CONVOLUTION kernels issue them — instead of the inline-asm statement of lds_dma.h.  hipcc then drains vmcnt in front of every transposing
+// read (slow): only there to tell whether the pooled-pass fault needs the inline-asm form.
+template <bool K64, int ABL = 0, int LA = 5, int NSY = 6, bool BI = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_conv_desc d, const unsigned short* __restrict__ dy,
                                                                    float* __restrict__ partial, const int M, const int Cin,
                                                                    const int Cout, const int tiles, const int tiles_n,
@@ -105,6 +108,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
 
     const srd_t rsx = make_srd(src, (K64 ? 1 : NP) * pbx), rsy = make_srd(dy, (K64 ? 1 : NP) * pby);
     const int x_slot1 = K64 ? BK * (Cs * 2) : pbx, y_slot1 = K64 ? BK * (Cout * 2) : pby;
+    const __amdgpu_buffer_rsrc_t bix = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), (short)0, (K64 ? 1 : NP) * pbx, 0x00020000);
+    const __amdgpu_buffer_rsrc_t biy = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dy), (short)0, (K64 ? 1 : NP) * pby, 0x00020000);
+    // one 1 KB DMA piece to LDS byte address `dst` (scalar): the inline-asm statement, or (BI) the builtin
+    auto dma16 = [&](const bool is_x, const unsigned base, auto offc, const int voff, const int soff) {
+        constexpr int OFF = decltype(offc)::value;                  // (compile-time part of the LDS address: one s_add into M0)
+        if constexpr (BI) {
+            auto* lp = (__attribute__((address_space(3))) void*)(smem + (base - lds_addr(smem)) + OFF);
+            if (is_x) __builtin_amdgcn_raw_ptr_buffer_load_lds(bix, lp, 16, voff, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(biy, lp, 16, voff, soff, 0, 0);
+        } else if constexpr (OFF == 0) {
+            lds_dma16(is_x ? rsx : rsy, base, voff, soff);
+        } else {
+            lds_dma16_at<OFF>(is_x ? rsx : rsy, base, voff, soff);
+        }
+    };
     const unsigned lds0 = lds_addr(smem);
     const unsigned ldsw = lds0 + 8 * wv * RB;                       // this wave's 8 rows inside a strip / dy piece wv
     const unsigned lds4 = lds0 + 32 * RB + (wv & 1) * B_PLANE;      // dy piece 4: slot 0 by wave 0, slot 1 by wave 1
@@ -120,8 +138,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
         if constexpr (ABL == 2 || ABL == 4) return;
         const int soff = (q0_of(rs) + 8 * wv) * Cs2 + cc * 2;
         const unsigned dst = ldsw + (slot & (NSX - 1)) * A_STRIP;
-        lds_dma16(rsx, dst, xlane, soff);
-        lds_dma16_at<A_PLANE>(rsx, dst, xlane, soff + x_slot1);
+        dma16(true, dst, std::integral_constant<int, 0>{}, xlane, soff);
+        dma16(true, dst, std::integral_constant<int, A_PLANE>{}, xlane, soff + x_slot1);
     };
     // dy: piece wv (rows 8 wv ..) of both slots; waves 0 / 1 also the fifth piece (rows 32 .. 39) of slot 0 / 1; pixels before 0
     // or past M read as zeros (an offset beyond num_records; the planes share one descriptor, so the bound is checked here)
@@ -137,8 +155,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
         voff = rowb + drow < M ? voff : (int)0x80000000;
         const int soff1 = K64 ? (rowb + BK) * (Cout * 2) + n0 * 2 : soff + y_slot1;
         const int voff1 = K64 ? (rowb + BK + drow < M ? ylane : (int)0x80000000) : voff;
-        lds_dma16_at<DST>(rsy, ldsw, voff, soff);
-        lds_dma16_at<DST + B_PLANE>(rsy, ldsw, voff1, soff1);
+        dma16(false, ldsw, std::integral_constant<int, DST>{}, voff, soff);
+        dma16(false, ldsw, std::integral_constant<int, DST + B_PLANE>{}, voff1, soff1);
     };
     auto dma_y5 = [&](auto stagec, const int st) {                  // waves 0 and 1 only
         constexpr int stage = decltype(stagec)::value;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
         const int rowb = q0_of(st) + 31 + (K64 ? wv * BK : 0);      // (never negative)
         const int soff = rowb * (Cout * 2) + n0 * 2 + (K64 ? 0 : wv * y_slot1);
         const int voff = rowb + drow < M ? ylane : (int)0x80000000;
-        lds_dma16_at<DST>(rsy, lds4, voff, soff);
+        dma16(false, lds4, std::integral_constant<int, DST>{}, voff, soff);
     };
     // the DMAs "of step st": the strip step st + 1 brings in (its own centre row) and the dy tile of step st
     const int xlast = total_steps - 1;
@@ -302,26 +320,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_ring_kernel(const rpnet_co
         unsigned dstx = 0;
         constexpr bool DMA_ON = !(ABL == 2 || ABL == 4);
         auto xa = [&]() { sx = qb * Cs2 + cx; dstx = ldsw + xslot; };
-        auto xd0 = [&]() { if constexpr (DMA_ON) lds_dma16(rsx, dstx, xlane, sx); };
-        auto xd1 = [&]() { if constexpr (DMA_ON) lds_dma16_at<A_PLANE>(rsx, dstx, xlane, sx + x_slot1); };
+        auto xd0 = [&]() { if constexpr (DMA_ON) dma16(true, dstx, std::integral_constant<int, 0>{}, xlane, sx); };
+        auto xd1 = [&]() { if constexpr (DMA_ON) dma16(true, dstx, std::integral_constant<int, A_PLANE>{}, xlane, sx + x_slot1); };
         auto ya1 = [&]() {                                            // first pixel of this wave's piece: -1 for step 0, piece 0
             rowb = qa + c8;
             vy = rowb < 0 ? ylane_m1 : ylane;
         };
         auto ya2 = [&]() { sy = max(rowb, 0) * Cout2 + cy; };
         auto yd0 = [&](auto stagec) {
-            if constexpr (DMA_ON) lds_dma16_at<BOFF + decltype(stagec)::value * B_STAGE>(rsy, ldsw, vy, sy);
+            if constexpr (DMA_ON) dma16(false, ldsw, std::integral_constant<int, BOFF + decltype(stagec)::value * B_STAGE>{}, vy, sy);
         };
         auto yd1 = [&](auto stagec) {
             constexpr int DST = BOFF + decltype(stagec)::value * B_STAGE + B_PLANE;
             if constexpr (!DMA_ON) return;
-            if constexpr (K64) lds_dma16_at<DST>(rsy, ldsw, ylane, (rowb + BK) * Cout2 + cy);
-            else lds_dma16_at<DST>(rsy, ldsw, vy, sy + y_slot1);
+            if constexpr (K64) dma16(false, ldsw, std::integral_constant<int, DST>{}, ylane, (rowb + BK) * Cout2 + cy);
+            else dma16(false, ldsw, std::integral_constant<int, DST>{}, vy, sy + y_slot1);
         };
         auto y5a = [&]() { sy5 = (qa + c5) * Cout2 + cy5; };
         auto y5d = [&](auto stagec) {
             if constexpr (DMA_ON)
-                if (wv < 2) lds_dma16_at<BOFF + decltype(stagec)::value * B_STAGE>(rsy, lds4, ylane, sy5);
+                if (wv < 2) dma16(false, lds4, std::integral_constant<int, BOFF + decltype(stagec)::value * B_STAGE>{}, ylane, sy5);
         };
         auto qs = [&]() { qa = qb; xslot = (xslot + A_STRIP) & (NSX * A_STRIP - 1); };
         auto adv = [&]() {
@@ -453,7 +471,10 @@ int conv_wgrad9_ring(const rpnet_conv_desc* d, const void* dy, float* part9, int
 #define RPNET_W9R(K6, A, SPS)                                                                                                   \
     hipLaunchKernelGGL((conv_wgrad9_ring_kernel<K6, A>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, tiles9, \
                        tiles_n9, ks9, SPS, lw, lh)
-    if (d->split_planes == 2 && (d->tune & 255) == 17) {       // A/B: the shallow pipeline of the row-major kernel (three steps ahead, four dy stages)
+    if (d->split_planes == 2 && (d->tune & 255) == 18) {        // diagnostic: DMAs through the builtin (profiles/r06_pool_fault.txt)
+        hipLaunchKernelGGL((conv_wgrad9_ring_kernel<false, 0, 5, 6, true>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, tiles9,
+                           tiles_n9, ks9, sps9, lw, lh);
+    } else if (d->split_planes == 2 && (d->tune & 255) == 17) {       // A/B: the shallow pipeline of the row-major kernel (three steps ahead, four dy stages)
         hipLaunchKernelGGL((conv_wgrad9_ring_kernel<false, 0, 3, 4>), dim3(tiles9 * ks9), dim3(256), 0, s, *d, dys, part9, M, Cin, Cout, tiles9,
                            tiles_n9, ks9, sps9, lw, lh);
     } else if (d->split_planes == 2) {
