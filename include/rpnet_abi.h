@@ -178,9 +178,11 @@ typedef struct rpnet_conv_desc {
                                           the data-dependent bound from which an eval-mode BatchNorm output gets its fp16
                                           tensor scale (rpnet_pow2_scale) — running statistics give no a-priori bound */
     int tune;                          /* 0: the library picks the tile variant.  Tuning / tests, low byte: v + 1 forces variant v of
-                                          the split forward kernels (where the shape allows it); 4 in rpnet_conv_wgrad: the
-                                          4-wave layout of the split weight gradient.  Bits 8-9: ablation switches of the
-                                          LDS-DMA kernel (tools/bench_conv_split.py: 1 = first channel chunk only, 2 = no
+                                          the split forward kernels (where the shape allows it); in rpnet_conv_wgrad: 4 / 8 = the register-staged
+                                          split weight gradient (4-wave / 12-wave layout), 16 = round 5's row-major LDS-DMA kernel, 17 = the
+                                          ring kernel with the shallow DMA pipeline, 18 = the ring kernel with its DMAs through the compiler's
+                                          builtin (diagnostic, slow); bits 8-10 there: ablation forms of the LDS-DMA weight-gradient kernels.
+                                          Bits 8-9 in rpnet_conv_fwd: ablation switches of the LDS-DMA kernel (tools/bench_conv_split.py: 1 = first channel chunk only, 2 = no
                                           epilogue; results are then meaningless).  Bit 16: the default policy without the
                                           LDS-DMA kernel (A/B).  Carried here, not in the environment: the library keeps no
                                           global state */
