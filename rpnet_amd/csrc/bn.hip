@@ -107,6 +107,7 @@ static int bn_lds_window() {
 template <int WIN>
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ y, double* __restrict__ partial,
                                                          long R, int C, BnGeom gm) {
+    RPNET_PASS_PRIORITY();
     __shared__ double red[WIN * 8];
     const int t = threadIdx.x;
     const int tc = t % gm.C4, tr = t / gm.C4;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const double* __restric
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* running_mean, float* running_var, long long* num_batches_tracked,
                                   float momentum, float eps, float* scale, float* shift, float* mean, float* invstd) {
+    RPNET_PASS_PRIORITY();
     __shared__ double red4[8];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (num_batches_tracked && c == 0 && lane == 0) *num_batches_tracked += G;  // one "forward call" per group
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const YSrc ysrc, const flo
                                                        size_t total4, int C4, size_t group4, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float sqrt_n,
                                                        float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     if (s_out && blockIdx.x == 0) {      // the fp16 tensor scale of this output (see bn_relu_split_kernel), no planes
         __shared__ float red4s[4];
         float m = 0.f;
@@ -223,6 +226,7 @@ __device__ __forceinline__ float block_max256(float m, float* red4) {
 // the scale alone (see bn_relu_split_kernel): for outputs whose consumers split the fp32 tensor themselves
 __global__ __launch_bounds__(256) void bn_act_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const int C, const float sqrt_n, float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     __shared__ float red4[4];
     float m = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_n + fabsf(beta[c]));
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const YSrc ysrc, con
                                                              size_t group8, size_t plane_elems, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float sqrt_n,
                                                              float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     float inv_s = 1.f;
     if (NP <= 2) {
         __shared__ float red4[4];
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        double* __restrict__ partial, float* __restrict__ pmax, long R, int C,
                                                        BnGeom gm) {
+    RPNET_PASS_PRIORITY();
     __shared__ double red[WIN * 8];
     __shared__ float redm[WIN * 4];
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 __global__ __launch_bounds__(256) void bn_bwd_finalize(const double* __restrict__ partial, int nblk, long R, int C, int G,
                                 float* coef, float* dgamma, float* dbeta, int accumulate, const float* __restrict__ pmax,
                                 const float* __restrict__ scale, float* __restrict__ bound) {
+    RPNET_PASS_PRIORITY();
     __shared__ double red4[8];
     __shared__ float redm[4];
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -375,6 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ coef, float* __restrict__ dy,
                                                      size_t total4, int C, size_t group4) {
+    RPNET_PASS_PRIORITY();
     const int C4 = C / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
@@ -410,6 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                            unsigned short* __restrict__ dys, size_t total8, int C,
                                                            size_t group8, size_t plane_elems, const float* __restrict__ bound,
                                                            float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     const int C8 = C / 8;
     float inv_s = 1.f;
     if (NP <= 2) {     // fp16 planes of dy / s, s = pow2ceil(max_c bound[c]) 2^-15 (see bn_bwd_finalize)

@@ -46,6 +46,14 @@ __device__ __forceinline__ double block_sum256(double v, double* smem4) {
     return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// First statement of every HBM-bound pass of the main chain.  A SIMD issues vector instructions of all resident waves through one
+// port: beside a resident GEMM wave — the default schedule runs the weight gradients of a layer on a side stream beside the passes
+// of the layer below — a pass instruction waits for a gap in that wave's MFMA stream, and the pass takes 2.7 x (BatchNorm backward)
+// to 4.9 x (glue backward) its time alone (tools/corun_probe.py; the denser the aggressor's MFMA stream the worse: 3.8 x beside the
+// weight-gradient kernel with its loads and LDS reads ablated, 1.7 x beside the register-staged kernel).  At priority 3 the pass's
+// instruction goes first whenever both are ready; the GEMM waves are off the critical path.
+#define RPNET_PASS_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 // most K splits of the single-tap (1x1) weight gradient: its GEMM is a latency chain of 32-pixel steps over six output
 // tiles, so more and shorter blocks win until the serial walk of the reduce launch takes the gain back
 constexpr int kWgrad1MaxSplits = 128;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void conv1_fwd4_kernel(const float* __restrict
                                                           const float* __restrict__ ep_scale, const float* __restrict__ ep_shift, int N,
                                                           int H, int W, int Cout, float* __restrict__ out_absmax,
                                                           double* __restrict__ stats_partial, const int groups) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int t = threadIdx.x;
     conv1_load_filter(wl, w, bias, Cout);
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                          const float* __restrict__ ep_shift, int N, int H, int W, int Cout,
                                                          float* __restrict__ out_absmax, double* __restrict__ stats_partial,
                                                          const int groups) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cout] + bias [Cout] (+ the statistics reduction)
     const int t = threadIdx.x;
     conv1_load_filter(wl, w, bias, Cout);
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial(const float* __restri
                                                             const float* __restrict__ coef, float* __restrict__ partial,
                                                             int N, int H, int W, int Cout, int groups,
                                                             const float* __restrict__ wf, const float* __restrict__ bf) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float red[];  // [ppb][Cout][9] (RECOMP: + the filter behind it)
     const int t = threadIdx.x;
     float* const wl = red + (256 / (Cout / 4)) * Cout * 9;
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_partial4(const float* __restr
                                                              const float* __restrict__ coef, float* __restrict__ partial, int N, int H,
                                                              int W, int Cout, int groups, const float* __restrict__ wf,
                                                              const float* __restrict__ bf) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float red[];  // [spb][Cout][9] (RECOMP: + the filter behind it)
     const int t = threadIdx.x;
     float* const wl = red + (256 / (Cout / 4)) * Cout * 9;
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(256) void conv1_bn_relu4_kernel(const float* __rest
                                                               unsigned short* __restrict__ zs, const int N, const int H, const int W,
                                                               const int Cout, const int groups, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float sqrt_n, float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];
     __shared__ float red4[4];
     const int t = threadIdx.x;
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_partial4_kernel(const float*
                                                                      const float* __restrict__ stats, double* __restrict__ partial,
                                                                      const int N, const int H, const int W, const int Cout,
                                                                      const int groups) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int t = threadIdx.x;
     conv1_load_filter(wl, w, bias, Cout);
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_kernel(const float* __restr
                                                              const int W, const int Cout, const int groups,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float sqrt_n, float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];
     __shared__ float red4[4];
     const int t = threadIdx.x;
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_partial_kernel(const float* 
                                                                     const float* __restrict__ stats, double* __restrict__ partial,
                                                                     const int N, const int H, const int W, const int Cout,
                                                                     const int groups) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ __attribute__((aligned(16))) float wl[];      // filter, then [256][8] doubles of the reduction
     const int t = threadIdx.x;
     conv1_load_filter(wl, w, bias, Cout);
@@ -621,6 +629,7 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_partial_kernel(const float* 
 }
 
 __global__ __launch_bounds__(64) void conv1_wgrad_final(const float* __restrict__ partial, float* __restrict__ dw, int nblk, int n) {
+    RPNET_PASS_PRIORITY();
     const int i = blockIdx.x, lane = threadIdx.x;
     double s = 0;
     for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * n + i];

@@ -32,6 +32,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const int mode, unsigned short* __restrict__ out,
                                                           const size_t n8, const int C8, const size_t plane_elems) {
+    RPNET_PASS_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
         const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
                                                          float* __restrict__ s_out, unsigned short* __restrict__ out,
                                                          const size_t n8, const int C8, const size_t plane_elems,
                                                          const int a_is_bound) {
+    RPNET_PASS_PRIORITY();
     // a_is_bound: *s_a is a bound of |x| (rpnet_conv_desc.out_absmax), not yet a scale
     const float sc = a_is_bound ? pow2_scale(*s_a) : fmaxf(*s_a, s_b ? *s_b : 0.f);
     if (s_out && blockIdx.x == 0 && threadIdx.x == 0) *s_out = sc;
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     }
 }
 
-__global__ void pow2_scale_kernel(const float* __restrict__ bound, float* __restrict__ s_out) { *s_out = pow2_scale(*bound); }
+__global__ void pow2_scale_kernel(const float* __restrict__ bound, float* __restrict__ s_out) {
+    RPNET_PASS_PRIORITY(); *s_out = pow2_scale(*bound); }
 
 __global__ __launch_bounds__(256) void predict_scales_kernel(const float* __restrict__ measured, float* __restrict__ bound,
                                                               float* __restrict__ scale, const int n, const float safety,

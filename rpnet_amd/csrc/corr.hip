@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void local_corr_fwd_kernel(const float* __rest
 template <int R>
 __global__ void corr_transpose_kernel(const float* __restrict__ dcorr, float* __restrict__ dct, int B, int h, int w,
                                       int cstride) {
+    RPNET_PASS_PRIORITY();
     constexpr int K = 2 * R + 1, KK = K * K;
     const size_t total = (size_t)B * h * w * cstride;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

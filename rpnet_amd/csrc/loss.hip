@@ -16,6 +16,7 @@ struct WeightSet { float w[kMaxLogitSets]; };      // multiplicity of each logit
 // partial[z][b][blk][2K+2] doubles: inter_k, card_k, ce_sum, count (z = blockIdx.z: which logit tensor of the set)
 __global__ __launch_bounds__(256) void dice_ce_partial(const LogitSet set, const int64_t* __restrict__ labels,
                                                         double* __restrict__ partial, int K, int HW, int ignore_index) {
+    RPNET_PASS_PRIORITY();
     __shared__ double sm4[4];
     const int b = blockIdx.y;
     const float* lg = set.p[blockIdx.z] + (size_t)b * K * HW;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(1024) void dice_ce_final(const double* __restrict__
                                                       int per_sample, const float* __restrict__ sample_weight, int n,
                                                       float* __restrict__ total, const WeightSet wts,
                                                       const float* __restrict__ extra, float extra_scale) {
+    RPNET_PASS_PRIORITY();
     extern __shared__ double sums[];  // [B][S]
     const int S = 2 * K + 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const LogitSet set, co
                                                            int ignore_index, int per_sample,
                                                            const float* __restrict__ sample_weight, int accumulate,
                                                            const WeightSet wts, float* __restrict__ dextra, float extra_scale) {
+    RPNET_PASS_PRIORITY();
     const int b = blockIdx.y;
     const int S = 2 * K + 2;
     const float* logits = set.p[blockIdx.z];
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const LogitSet set, co
 // alignLoss pieces (net/rp_net.py:412-417,433-436)
 __global__ __launch_bounds__(256) void argmax_masks_kernel(const float* __restrict__ pred, float* __restrict__ masks,
                                                             float* __restrict__ counts, float* __restrict__ keep, int K, int hw) {
+    RPNET_PASS_PRIORITY();
     __shared__ double sm4[4];
     const int b = blockIdx.x;
     const float* p = pred + (size_t)b * K * hw;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256) void argmax_masks_kernel(const float* __restri
 }
 
 __global__ void align_labels_kernel(const float* __restrict__ fore, const float* __restrict__ back, int64_t* __restrict__ lab, size_t n) {
+    RPNET_PASS_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int64_t v = 255;
         if (fore[i] == 1.f) v = 1;

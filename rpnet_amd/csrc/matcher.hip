@@ -10,6 +10,7 @@ namespace rpnet {
 // am[b,k,y,x] = sum_{Y,X} mask_k[b,Y,X] * wy(Y->y) * wx(X->x)
 __global__ void mask_adjoint_kernel(const float* __restrict__ masks, float* __restrict__ am, int B, int nmask, int H,
                                     int W, int h, int w) {
+    RPNET_PASS_PRIORITY();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * nmask * h * w) return;
     const int x = i % w, y = (i / w) % h, k = (i / (w * h)) % nmask, b = i / (w * h * nmask);
@@ -31,6 +32,7 @@ __global__ void mask_adjoint_kernel(const float* __restrict__ masks, float* __re
 
 __global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__ masks, float* __restrict__ msum, int B,
                                                         int nmask, int HW) {
+    RPNET_PASS_PRIORITY();
     __shared__ double sm4[4];
     const int b = blockIdx.x % B, k = blockIdx.x / B;
     const float* m = masks + ((size_t)k * B + b) * HW;
@@ -56,6 +58,7 @@ constexpr int kMaxMask = 4;
 // partial[b][s][k][C] = sum_{q in chunk s} f[b,q,:] * am[b,k,q]
 __global__ __launch_bounds__(256) void masked_pool_partial(const float* __restrict__ f, const float* __restrict__ am,
                                                             float* __restrict__ partial, int nmask, int hw, int C) {
+    RPNET_PASS_PRIORITY();
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const int t = threadIdx.x, C4 = C / 4, rows = 256 / C4;
     const int c4 = t % C4, qg = t / C4;
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void masked_pool_partial(const float* __restri
 
 __global__ void masked_pool_final(const float* __restrict__ partial, const float* __restrict__ msum,
                                   float* __restrict__ proto, int B, int nmask, int C) {
+    RPNET_PASS_PRIORITY();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * nmask * C) return;
     const int c = i % C, k = (i / C) % nmask, b = i / (C * nmask);
@@ -97,6 +101,7 @@ __global__ void masked_pool_final(const float* __restrict__ partial, const float
 __global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __restrict__ dproto, const float* __restrict__ am,
                                                                const float* __restrict__ msum, float* __restrict__ df,
                                                                int B, int nmask, int hw, int C, int accumulate) {
+    RPNET_PASS_PRIORITY();
     const int C4 = C / 4;
     const size_t total = (size_t)B * hw * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void masked_pool_bwd_kernel(const float* __res
 template <int L>
 __global__ __launch_bounds__(256) void cosine_match_fwd_kernel(const float* __restrict__ f, const float* __restrict__ proto,
                                                                 float* __restrict__ pred, int B, int K, int hw, float scaler) {
+    RPNET_PASS_PRIORITY();
     constexpr int C = L * 4, PPB = 256 / L;
     const int t = threadIdx.x, l = t % L, pl = t / L;
     const int b = blockIdx.y;
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256) void cosine_match_bwd_kernel(const float* __re
                                                                 const float* __restrict__ dpred, float* __restrict__ df,
                                                                 float* __restrict__ dpart, int B, int K, int hw,
                                                                 float scaler, int accumulate_df) {
+    RPNET_PASS_PRIORITY();
     constexpr int C = L * 4, PPB = 256 / L;
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const int t = threadIdx.x, l = t % L, pl = t / L;
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256) void cosine_match_bwd_kernel(const float* __re
 // one block per (episode, prototype): 256 / C row groups share the nblk partial rows, four loads in flight each
 // (one thread per output with a serial loop over 256 rows took 16 us)
 __global__ __launch_bounds__(256) void cosine_dproto_final(const float* __restrict__ dpart, float* __restrict__ dproto, int B, int nblk, int K, int C) {
+    RPNET_PASS_PRIORITY();
     __shared__ float red[256];
     const int b = blockIdx.x / K, k = blockIdx.x - b * K;
     const int t = threadIdx.x;
@@ -243,6 +251,7 @@ static int cos_blocks(int B, int hw) {
 }
 
 __global__ void bilinear_up_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int H, int W) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)planes * H * W;
     const float rsy = (float)h / (float)H, rsx = (float)w / (float)W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -259,6 +268,7 @@ __global__ void bilinear_up_fwd_kernel(const float* __restrict__ in, float* __re
 // gather form (no atomics): four lanes share a low-resolution pixel, each takes every fourth row of the window of
 // high-resolution gradients that touch it, and a two-step shuffle adds them up
 __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int planes, int h, int w, int H, int W) {
+    RPNET_PASS_PRIORITY();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t >> 2, part = t & 3;
     const bool live = i < planes * h * w;
@@ -283,6 +293,7 @@ __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dout, float* __
 
 __global__ void softmax_thresh_pool_kernel(const float* __restrict__ logits, float* __restrict__ mask, int B, int K, int H,
                                            int W, int s, int soft) {
+    RPNET_PASS_PRIORITY();
     const int h = H / s, w = W / s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * h * w) return;
@@ -309,6 +320,7 @@ __global__ void softmax_thresh_pool_kernel(const float* __restrict__ logits, flo
 template <int KT>
 __global__ __launch_bounds__(256) void softmax_thresh_pool4_kernel(const float* __restrict__ logits, float* __restrict__ mask, int B,
                                                                    int K, int H, int W, int soft) {
+    RPNET_PASS_PRIORITY();
     const int h = H / 4, w = W / 4;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * h * w) return;
@@ -342,6 +354,7 @@ __global__ __launch_bounds__(256) void softmax_thresh_pool4_kernel(const float* 
 __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             const float* __restrict__ sc, float* __restrict__ dx,
                                                             float* __restrict__ ds, size_t P, int C, int mode, int accumulate_ds) {
+    RPNET_PASS_PRIORITY();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int C4 = C / 4;
     for (size_t p = (size_t)blockIdx.x * 4 + wv; p < P; p += (size_t)gridDim.x * 4) {
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restri
 // d logits of mask = avg_pool(softmax(logits)[:,1], s):  dl_k = p1 * ([k == 1] - p_k) * dmask / s^2
 __global__ void softmax_pool_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dmask,
                                         float* __restrict__ dlogits, int B, int K, int H, int W, int s) {
+    RPNET_PASS_PRIORITY();
     const size_t plane = (size_t)H * W;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * plane) return;

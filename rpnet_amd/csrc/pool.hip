@@ -8,6 +8,7 @@ namespace rpnet {
 
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ z, float* __restrict__ out,
                                                             int N, int Ho, int Wo, int C4) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool,
                                                             const float* __restrict__ skip, float* __restrict__ dz,
                                                             int N, int Ho, int Wo, int C4) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dyu, float* __restrict__ dx,
                                                              int N, int Ho, int Wo, int C4) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
 }
 
 __global__ void mask_avgpool_kernel(const float* __restrict__ m, float* __restrict__ out, int B, int H, int W, int s) {
+    RPNET_PASS_PRIORITY();
     const int h = H / s, w = W / s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * h * w) return;
@@ -90,6 +94,7 @@ __global__ void mask_avgpool_kernel(const float* __restrict__ m, float* __restri
 // MaxPool2d(3, stride, padding=1): -inf padding, first maximum in (ky, kx) scan order
 __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H,
                                                             int W, int Ho, int Wo, int C4, int stride) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool,
                                                             float* __restrict__ dz, int N, int H, int W, int Ho, int Wo,
                                                             int C4, int stride) {
+    RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                              float* __restrict__ dy, double* __restrict__ partial, size_t P,
                                                              int C) {
+    RPNET_PASS_PRIORITY();
     __shared__ double red[256 * 4];
     const int t = threadIdx.x, C4 = C / 4, rows_it = 256 / C4;
     const int tc = t % C4, tr = t / C4;
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(64) void bias_grad_final(const double* __restrict__ partial, float* __restrict__ db, int nblk, int C) {
+    RPNET_PASS_PRIORITY();
     const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0;
     for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * C + c];
@@ -289,6 +297,7 @@ struct SumSources {
 };
 __global__ __launch_bounds__(256) void sum_n_kernel(const SumSources src, const int n, float* __restrict__ out, const size_t n4,
                                                      const size_t numel) {
+    RPNET_PASS_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 acc = reinterpret_cast<const f32x4*>(src.p[0])[i];
         for (int k = 1; k < n; ++k) acc += reinterpret_cast<const f32x4*>(src.p[k])[i];

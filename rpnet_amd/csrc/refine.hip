@@ -34,6 +34,7 @@ struct RefineFwd {
 
 template <int NP>
 __global__ __launch_bounds__(256) void refine_glue_fwd_kernel(const RefineFwd a) {
+    RPNET_PASS_PRIORITY();
     __shared__ float pred_s[kMaxK][RH * RH];
     __shared__ float sm[RT * RT][17];
     __shared__ float msk[RT * RT];
@@ -177,6 +178,7 @@ struct RefineBwd {
 
 // <= 128 registers per lane: a wave of this pass then fits on a SIMD beside a wave of the LDS-DMA convolution kernel (384 of the 512)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void refine_glue_bwd_kernel(const RefineBwd a) {
+    RPNET_PASS_PRIORITY();
     __shared__ float dps[kMaxK][RT * RT];
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
     const int t = threadIdx.x, b = blockIdx.y, K = a.K, h = a.h, w = a.w, H = 4 * h, W = 4 * w;
