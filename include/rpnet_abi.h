@@ -51,7 +51,7 @@ enum rpnet_status {
  * rpnet_upconv_collapse_weights added; nothing existing changed).  A caller MUST zero-initialise rpnet_conv_desc (fields added
  * later are optional features that are off at zero) and SHOULD compare rpnet_version() with the RPNET_ABI_VERSION it was built
  * against. */
-#define RPNET_ABI_VERSION 107
+#define RPNET_ABI_VERSION 108
 int rpnet_version(void);
 const char* rpnet_last_error_string(void);
 
@@ -545,6 +545,15 @@ int rpnet_align_labels(const float* fore, const float* back, int64_t* labels, si
  * fits on their CUs it tests whether a neighbouring workgroup's `buffer_load ... lds` ever writes outside its own allocation
  * (tools/lds_canary.py; the pooled-pass fault, lds_dma.h).  mismatches[3] (caller-zeroed): changed words, blocks run, sweeps. */
 int rpnet_debug_lds_canary(int blocks, int lds_bytes, long long spin_ticks, unsigned* mismatches, rpnet_stream_t stream);
+/* Host-only self-test of the 32-bit index division the element-wise passes use (csrc/common.h FastDiv: Granlund-Montgomery multiply-shift
+ * with a host-made multiplier) against the C operators: 49 divisors (1, powers of two and their neighbours, up to 2^32 - 1), edge values
+ * and `random_per_divisor` random ones each.  Returns the number of mismatches: 0.  Needs no GPU. */
+long long rpnet_debug_fastdiv_selftest(int random_per_divisor);
+/* MFMA spinner (csrc/debug_probe.hip): `blocks` workgroups of 4 waves issue v_mfma_f32_32x32x16_f16 back to back for `spin_ticks` ticks of
+ * the 100 MHz wall clock (<= 1 s), `lds_bytes` of LDS each (144 KB = one block per CU, as the weight-gradient kernel).  out[3]: shader
+ * cycles, wall ticks, MFMAs per wave.  `blocks` = count + 65536 * pad: pad (0 .. 3) `s_nop 7` statements behind every MFMA.  The aggressor of
+ * tools/corun_probe.py's AGG=spin:<blocks> legs. */
+int rpnet_debug_mfma_spin(int blocks, int lds_bytes, long long spin_ticks, unsigned long long* out, rpnet_stream_t stream);
 
 /* ------------------------------------------------- registration pre-step
  * dataset/few_shot_reader.py:109-198 get_registration_field with do_deformable=False (yamls/example.yml:101):

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const YSrc ysrc, const flo
                                                        const float* __restrict__ shift, float* __restrict__ z,
                                                        size_t total4, int C4, size_t group4, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float sqrt_n,
-                                                       float* __restrict__ s_out) {
+                                                       float* __restrict__ s_out, const FastDiv fc, const FastDiv fg) {
     RPNET_PASS_PRIORITY();
     if (s_out && blockIdx.x == 0) {      // the fp16 tensor scale of this output (see bn_relu_split_kernel), no planes
         __shared__ float red4s[4];
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const YSrc ysrc, const flo
         if (threadIdx.x == 0) *s_out = pow2_scale(fmaxf(fmaxf(red4s[0], red4s[1]), fmaxf(red4s[2], red4s[3])));
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        const int g = (int)(i / group4);
+        const int c4 = (int)fc.mod((unsigned)i);
+        const int g = (int)fg.div((unsigned)i);
         const f32x4 v = load_y4(ysrc, i * 4, c4 * 4);
         const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[g * C4 + c4];
         const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[g * C4 + c4];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const YSrc ysrc, con
                                                              unsigned short* __restrict__ zs, size_t total8, int C8,
                                                              size_t group8, size_t plane_elems, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float sqrt_n,
-                                                             float* __restrict__ s_out) {
+                                                             float* __restrict__ s_out, const FastDiv fc, const FastDiv fg) {
     RPNET_PASS_PRIORITY();
     float inv_s = 1.f;
     if (NP <= 2) {
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const YSrc ysrc, con
         inv_s = 1.f / sc;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        const int g = (int)(i / group8);
+        const int c8 = (int)fc.mod((unsigned)i);
+        const int g = (int)fg.div((unsigned)i);
         const float* sc = scale + (size_t)(g * C8 + c8) * 8;
         const float* sh = shift + (size_t)(g * C8 + c8) * 8;
         float v[8];
@@ -381,12 +381,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ coef, float* __restrict__ dy,
-                                                     size_t total4, int C, size_t group4) {
+                                                     size_t total4, int C, size_t group4, const FastDiv fc, const FastDiv fg) {
     RPNET_PASS_PRIORITY();
-    const int C4 = C / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        const int g = (int)(i / group4);
+        const int c4 = (int)fc.mod((unsigned)i);
+        const int g = (int)fg.div((unsigned)i);
         const int o = g * C + c4 * 4;
         const f32x4 v = load_y4(ysrc, i * 4, c4 * 4);
         const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i];
@@ -394,12 +393,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dz
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+        const f32x4 cf0 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2), cf1 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2 + 4);
+        const float c1[4] = {cf0[0], cf0[2], cf1[0], cf1[2]}, c2[4] = {cf0[1], cf0[3], cf1[1], cf1[3]};
         f32x4 r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
             const float xh = (v[k] - mu[k]) * is[k];
-            r[k] = sc[k] * (dm - coef[(o + k) * 2] - xh * coef[(o + k) * 2 + 1]);
+            r[k] = sc[k] * (dm - c1[k] - xh * c2[k]);
         }
         reinterpret_cast<f32x4*>(dy)[i] = r;
     }
@@ -417,9 +418,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                            const float* __restrict__ coef, float* __restrict__ dy,
                                                            unsigned short* __restrict__ dys, size_t total8, int C,
                                                            size_t group8, size_t plane_elems, const float* __restrict__ bound,
-                                                           float* __restrict__ s_out) {
+                                                           float* __restrict__ s_out, const FastDiv fc, const FastDiv fg) {
     RPNET_PASS_PRIORITY();
-    const int C8 = C / 8;
     float inv_s = 1.f;
     if (NP <= 2) {     // fp16 planes of dy / s, s = pow2ceil(max_c bound[c]) 2^-15 (see bn_bwd_finalize)
         __shared__ float red4[4];
@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         inv_s = 1.f / sc;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        const int g = (int)(i / group8);
+        const int c8 = (int)fc.mod((unsigned)i);
+        const int g = (int)fg.div((unsigned)i);
         float r[8];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -442,12 +442,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + o);
             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + o);
             const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + o);
+            const f32x4 cf0 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2), cf1 = *reinterpret_cast<const f32x4*>(coef + (size_t)o * 2 + 4);
+            const float c1[4] = {cf0[0], cf0[2], cf1[0], cf1[2]}, c2[4] = {cf0[1], cf0[3], cf1[1], cf1[3]};
             f32x4 q;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dm = (v[k] * sc[k] + sh[k] > 0.f) ? d[k] : 0.f;
                 const float xh = (v[k] - mu[k]) * is[k];
-                q[k] = sc[k] * (dm - coef[(o + k) * 2] - xh * coef[(o + k) * 2 + 1]);
+                q[k] = sc[k] * (dm - c1[k] - xh * c2[k]);
                 r[hh * 4 + k] = q[k];
             }
             if (dy) reinterpret_cast<f32x4*>(dy)[i * 2 + hh] = q;
@@ -471,7 +473,14 @@ struct PoolGeom {
     int Ho, Wo, W;          // pooled height / width, input width
     int imgs_per_group;     // N / groups
     size_t img_elems;       // H W C of one input image
+    FastDiv fC8, fWo, fHo, fIpg, fHoWo;     // the index arithmetic of the passes (C / 8, Wo, Ho, imgs_per_group, Ho * Wo)
 };
+static PoolGeom make_pool_geom(int HW, int pool_w, int N, int groups, int C) {
+    PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C, {}, {}, {}, {}, {}};
+    pg.fC8 = FastDiv(C / 8); pg.fWo = FastDiv(pg.Wo); pg.fHo = FastDiv(pg.Ho); pg.fIpg = FastDiv(pg.imgs_per_group);
+    pg.fHoWo = FastDiv((unsigned)pg.Ho * pg.Wo);
+    return pg;
+}
 
 // thread = one pooled pixel x 8 channels; planes [NP][N, Ho, Wo, C] of relu(max) / s (and the fp32 pooled tensor when zp != NULL)
 // DRAIN: as bn_bwd_apply_pool_split below — every load of a half waited for with a full `s_waitcnt vmcnt(0)` before any of its
@@ -496,12 +505,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_split_kernel(const YSrc ysrc
     }
     const size_t rowC = (size_t)pg.W * C8 * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        size_t pp = i / C8;
-        const int ox = (int)(pp % pg.Wo); pp /= pg.Wo;
-        const int oy = (int)(pp % pg.Ho);
-        const int n = (int)(pp / pg.Ho);
-        const int g = n / pg.imgs_per_group;
+        unsigned pp, py, pn;
+        const int c8 = (int)pg.fC8.divmod((unsigned)i, pp);
+        const int ox = (int)pg.fWo.divmod(pp, py);
+        const int oy = (int)pg.fHo.divmod(py, pn);
+        const int n = (int)pn;
+        const int g = (int)pg.fIpg.div(pn);
         const float* sc = scale + (size_t)(g * C8 + c8) * 8;
         const float* sh = shift + (size_t)(g * C8 + c8) * 8;
         const size_t src = (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C8 * 8 + c8 * 8;
@@ -570,10 +579,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool(const float* __restri
         const long r1 = min(r0 + gm.rows_blk, Rp);
         const size_t gbase = (size_t)g * pg.imgs_per_group * pg.img_elems + tc * 4;
         const size_t rowC = (size_t)pg.W * C;
-        const int hw = pg.Ho * pg.Wo;
         for (long r = r0 + tr; r < r1; r += gm.rows_it) {
-            const int nl = (int)(r / hw), rem = (int)(r - (long)nl * hw);
-            const int oy = rem / pg.Wo, ox = rem - oy * pg.Wo;
+            unsigned nq, oq;
+            const unsigned rem = pg.fHoWo.divmod((unsigned)r, nq);
+            const int ox = (int)pg.fWo.divmod(rem, oq);
+            const int nl = (int)nq, oy = (int)oq;
             const size_t src = gbase + (size_t)nl * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C;
             f32x4 v0 = load_y4(ysrc, src, tc * 4), v1 = load_y4(ysrc, src + C, tc * 4);
             f32x4 v2 = load_y4(ysrc, src + rowC, tc * 4), v3 = load_y4(ysrc, src + rowC + C, tc * 4);
@@ -642,12 +652,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     const size_t rowC = (size_t)pg.W * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        size_t pp = i / C8;
-        const int ox = (int)(pp % pg.Wo); pp /= pg.Wo;
-        const int oy = (int)(pp % pg.Ho);
-        const int n = (int)(pp / pg.Ho);
-        const int g = n / pg.imgs_per_group;
+        unsigned pp, py, pn;
+        const int c8 = (int)pg.fC8.divmod((unsigned)i, pp);
+        const int ox = (int)pg.fWo.divmod(pp, py);
+        const int oy = (int)pg.fHo.divmod(py, pn);
+        const int n = (int)pn;
+        const int g = (int)pg.fIpg.div(pn);
         const size_t e00 = (size_t)n * pg.img_elems + ((size_t)(2 * oy) * pg.W + 2 * ox) * C + c8 * 8;
         const size_t offs[4] = {e00, e00 + C, e00 + rowC, e00 + rowC + C};
         float r[4][8];
@@ -795,8 +805,9 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
         RPNET_REQUIRE(z_split && planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_ARG, "bn_relu: the pooled form writes split planes (planes=%d C=%d)", planes, C);
         RPNET_REQUIRE(HW % pool_w == 0 && pool_w % 2 == 0 && (HW / pool_w) % 2 == 0, RPNET_ERR_SHAPE, "bn_relu: pooled image %d x %d", HW / pool_w, pool_w);
         RPNET_REQUIRE(planes == 3 || (gamma && beta && split_scale), RPNET_ERR_ARG, "bn_relu: fp16 planes (1 or 2) need gamma, beta and the scale output");
-        const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
+        const PoolGeom pg = make_pool_geom(HW, pool_w, N, groups, C);
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * (HW / 4) * C;
+        RPNET_REQUIRE(total8 < kIndex32, RPNET_ERR_SHAPE, "bn (pooled): %zu elements do not fit the 32-bit index arithmetic of the passes", total8);
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
         // the guards of the pooled passes (see bn_bwd_apply_pool_split): LDS reservation of the launch, full wait in the kernel
         const size_t alone_f = pool_alone_bytes();
@@ -813,6 +824,7 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
         return check_launch("bn_relu_pool");
     }
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    RPNET_REQUIRE(total4 < kIndex32, RPNET_ERR_SHAPE, "bn: %zu 16-byte elements do not fit the 32-bit index arithmetic of the passes", total4);
     if (z_split) {
         RPNET_REQUIRE(planes >= 1 && planes <= 3 && C % 8 == 0, RPNET_ERR_SHAPE, "bn_relu: split planes=%d C=%d", planes, C);
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
@@ -821,18 +833,19 @@ extern "C" int rpnet_bn_relu(const float* y, const float* scale, const float* sh
         const float sqrt_n = sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f;
         if (planes == 3)
             hipLaunchKernelGGL(bn_relu_split_kernel<3>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
-                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         else if (planes == 2)
             hipLaunchKernelGGL(bn_relu_split_kernel<2>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
-                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         else
             hipLaunchKernelGGL(bn_relu_split_kernel<1>, dim3(elt_grid(total8)), dim3(256), 0, (hipStream_t)stream, ysrc, scale,
-                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale);
+                               shift, z, (unsigned short*)z_split, total8, C / 8, group4 / 2, pe, gamma, beta, sqrt_n, split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         return check_launch("bn_relu_split");
     }
     RPNET_REQUIRE(!split_scale || (gamma && beta), RPNET_ERR_ARG, "bn_relu: the tensor scale needs gamma and beta");
     hipLaunchKernelGGL(bn_relu_kernel, dim3(elt_grid(total4)), dim3(256), 0, (hipStream_t)stream, ysrc, scale, shift, z,
-                       total4, C / 4, group4, gamma, beta, sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f, split_scale);
+                       total4, C / 4, group4, gamma, beta, sqrtf((float)((size_t)(N / groups) * HW)) * 1.0001f, split_scale, FastDiv(C / 4),
+                       FastDiv((unsigned)group4));
     return check_launch("bn_relu");
 }
 
@@ -875,7 +888,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         // again from y; dy comes out at full resolution
         RPNET_REQUIRE(dy_split && !given_partial, RPNET_ERR_ARG, "bn_bwd: the pooled form writes split planes and runs its own reduction");
         RPNET_REQUIRE(HW % pool_w == 0 && pool_w % 2 == 0 && (HW / pool_w) % 2 == 0, RPNET_ERR_SHAPE, "bn_bwd: pooled image %d x %d", HW / pool_w, pool_w);
-        const PoolGeom pg{HW / pool_w / 2, pool_w / 2, pool_w, N / groups, (size_t)HW * C};
+        const PoolGeom pg = make_pool_geom(HW, pool_w, N, groups, C);
         const long Rp = R / 4;
         const BnGeom gp = bn_geom(Rp, C);
         // RPNET_BN_POOL_ALONE (default on): the pooled passes reserve LDS they do not use, so that their blocks never share a CU with
@@ -890,6 +903,7 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
         hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, s, (const double*)partial, gp.nblk, R, C, groups,
                            coef, dgamma, dbeta, accumulate, (const float*)pmax, scale, bound);
         const size_t total8 = (size_t)N * (HW / 4) * C / 8, pe = (size_t)N * HW * C;
+        RPNET_REQUIRE(total8 < kIndex32, RPNET_ERR_SHAPE, "bn (pooled): %zu elements do not fit the 32-bit index arithmetic of the passes", total8);
         // DRAIN (default; RPNET_BN_POOL_DRAIN=0: the A/B switch that brings the fault back): see bn_bwd_apply_pool_split
         static const bool drain = [] { const char* e = getenv("RPNET_BN_POOL_DRAIN"); return !(e && e[0] == '0'); }();
 #define RPNET_BN_POOL_BWD(NP_)                                                                                              \
@@ -923,23 +937,24 @@ extern "C" int rpnet_bn_bwd(const float* dz, const float* y, const float* gamma,
     // rpnet_bn_bwd_coef_offset) for a consumer that forms dy itself (rpnet_conv1_wgrad_bn)
     if (!dy && !dy_split) return check_launch("bn_bwd");
     const size_t total4 = (size_t)N * HW * C / 4, group4 = total4 / groups;
+    RPNET_REQUIRE(total4 < kIndex32, RPNET_ERR_SHAPE, "bn: %zu 16-byte elements do not fit the 32-bit index arithmetic of the passes", total4);
     if (dy_split) {
         const size_t total8 = total4 / 2, pe = (size_t)N * HW * C;
         if (planes == 3)
             hipLaunchKernelGGL(bn_bwd_apply_split<3>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
-                               split_scale);
+                               split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         else if (planes == 2)
             hipLaunchKernelGGL(bn_bwd_apply_split<2>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
-                               split_scale);
+                               split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         else
             hipLaunchKernelGGL(bn_bwd_apply_split<1>, dim3(elt_grid(total8)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
                                (const float*)coef, dy, (unsigned short*)dy_split, total8, C, group4 / 2, pe, (const float*)bound,
-                               split_scale);
+                               split_scale, FastDiv(C / 8), FastDiv((unsigned)(group4 / 2)));
         return check_launch("bn_bwd");
     }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(elt_grid(total4)), dim3(256), 0, s, dz, ysrc, scale, shift, mean, invstd,
-                       (const float*)coef, dy, total4, C, group4);
+                       (const float*)coef, dy, total4, C, group4, FastDiv(C / 4), FastDiv((unsigned)group4));
     return check_launch("bn_bwd");
 }

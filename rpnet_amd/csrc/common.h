@@ -54,6 +54,35 @@ __device__ __forceinline__ double block_sum256(double v, double* smem4) {
 // instruction goes first whenever both are ready; the GEMM waves are off the critical path.
 #define RPNET_PASS_PRIORITY() __builtin_amdgcn_s_setprio(3)
 
+// n / d and n % d of a 32-bit index by a launch constant in 5 (7) vector instructions: Granlund & Montgomery 1994, figure 4.1 —
+// exact for every 32-bit n and every d >= 1; the multiplier is made on the host.  hipcc's own `%` / `/` of a size_t loop index by
+// a kernel argument is a ~130-instruction sequence PER ITERATION, more than the arithmetic of the element-wise passes themselves
+// (the BatchNorm apply passes: 280 instructions of index arithmetic in front of 140 of work) — and beside a GEMM wave these passes
+// are bound by instruction issue (RPNET_PASS_PRIORITY above).  Launchers check that their element counts fit 32 bits.
+struct FastDiv {
+    unsigned m, d, sh1, sh2;
+    FastDiv() = default;
+    explicit FastDiv(unsigned d_) : d(d_) {
+        unsigned l = 0;
+        while (l < 32 && (1ull << l) < (unsigned long long)d_) ++l;           // ceil(log2 d)
+        m = (unsigned)(((((1ull << l) - d_) << 32) / d_) + 1ull);
+        sh1 = l < 1 ? l : 1;
+        sh2 = l ? l - 1 : 0;
+    }
+    __host__ __device__ __forceinline__ unsigned div(const unsigned n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned t = __umulhi(m, n);
+#else
+        const unsigned t = (unsigned)(((unsigned long long)m * n) >> 32);
+#endif
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+    __host__ __device__ __forceinline__ unsigned mod(const unsigned n) const { return n - div(n) * d; }
+    // q = n / d, returns n % d
+    __host__ __device__ __forceinline__ unsigned divmod(const unsigned n, unsigned& q) const { q = div(n); return n - q * d; }
+};
+constexpr size_t kIndex32 = (size_t)1 << 32;
+
 // most K splits of the single-tap (1x1) weight gradient: its GEMM is a latency chain of 32-pixel steps over six output
 // tiles, so more and shorter blocks win until the serial walk of the reduce launch takes the gain back
 constexpr int kWgrad1MaxSplits = 128;

@@ -31,14 +31,14 @@ constexpr bool IGLP = true;
 template <int NP>
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const int mode, unsigned short* __restrict__ out,
-                                                          const size_t n8, const int C8, const size_t plane_elems) {
+                                                          const size_t n8, const FastDiv fC, const size_t plane_elems) {
     RPNET_PASS_PRIORITY();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
         const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (mode) {
-            float s = scale[i / C8];
+            float s = scale[fC.div((unsigned)i)];
             if (mode == 2) s = 1.f - s;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] *= s;
@@ -56,7 +56,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, const float* __restrict__ mask, const int mode,
                                                          const float* __restrict__ s_a, const float* __restrict__ s_b,
                                                          float* __restrict__ s_out, unsigned short* __restrict__ out,
-                                                         const size_t n8, const int C8, const size_t plane_elems,
+                                                         const size_t n8, const FastDiv fC, const size_t plane_elems,
                                                          const int a_is_bound) {
     RPNET_PASS_PRIORITY();
     // a_is_bound: *s_a is a bound of |x| (rpnet_conv_desc.out_absmax), not yet a scale
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
         const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
         float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (mode) {      // x * f(mask) rounded to fp32 as the reference does, then the exact power-of-two scale
-            float f = mask[i / C8];
+            float f = mask[fC.div((unsigned)i)];
             if (mode == 2) f = 1.f - f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] *= f;
@@ -1060,9 +1060,10 @@ extern "C" int rpnet_split_bf16(const float* x, const float* scale, int scale_mo
                   "split_bf16: C=%d planes=%d (3; two planes are fp16 with a tensor scale: rpnet_split_f16) mode=%d", C, planes, scale_mode);
     if (rows == 0) return RPNET_OK;
     const size_t n8 = rows * (size_t)(C / 8);
+    RPNET_REQUIRE(n8 < kIndex32, RPNET_ERR_SHAPE, "split: %zu elements do not fit the 32-bit index arithmetic", n8);
     const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
     hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, scale_mode,
-                       (unsigned short*)out, n8, C / 8, rows * (size_t)C);
+                       (unsigned short*)out, n8, FastDiv(C / 8), rows * (size_t)C);
     return check_launch("split_bf16");
 }
 
@@ -1092,13 +1093,14 @@ extern "C" int rpnet_split_f16(const float* x, const float* mask, int mask_mode,
                   "split_f16: C=%d mode=%d planes=%d", C, mask_mode, planes);
     if (rows == 0) return RPNET_OK;
     const size_t n8 = rows * (size_t)(C / 8);
+    RPNET_REQUIRE(n8 < kIndex32, RPNET_ERR_SHAPE, "split: %zu elements do not fit the 32-bit index arithmetic", n8);
     const int grid = (int)(n8 / 256 + 1 < 16384 ? n8 / 256 + 1 : 16384);
     if (planes == 2)
         hipLaunchKernelGGL(split_f16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C, a_is_bound);
+                           (unsigned short*)out, n8, FastDiv(C / 8), rows * (size_t)C, a_is_bound);
     else
         hipLaunchKernelGGL(split_f16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mask, mask_mode, s_a, s_b, s_out,
-                           (unsigned short*)out, n8, C / 8, rows * (size_t)C, a_is_bound);
+                           (unsigned short*)out, n8, FastDiv(C / 8), rows * (size_t)C, a_is_bound);
     return check_launch("split_f16");
 }
 

@@ -109,16 +109,16 @@ __global__ __launch_bounds__(256) void local_corr_fwd_kernel(const float* __rest
 // dcT[b,q, o] = dcorr[b, q - off(o), o]  (0 outside): the window gradient seen from the f2 pixel
 template <int R>
 __global__ void corr_transpose_kernel(const float* __restrict__ dcorr, float* __restrict__ dct, int B, int h, int w,
-                                      int cstride) {
+                                      int cstride, const FastDiv fS, const FastDiv fW, const FastDiv fH) {
     RPNET_PASS_PRIORITY();
     constexpr int K = 2 * R + 1, KK = K * K;
     const size_t total = (size_t)B * h * w * cstride;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int o = (int)(i % cstride);
-        size_t p = i / cstride;
-        const int x = (int)(p % w); p /= w;
-        const int y = (int)(p % h);
-        const int b = (int)(p / h);
+        unsigned p, py, pb;
+        const int o = (int)fS.divmod((unsigned)i, p);
+        const int x = (int)fW.divmod(p, py);
+        const int y = (int)fH.divmod(py, pb);
+        const int b = (int)pb;
         float v = 0.f;
         if (o < KK) {
             const int a = o / K, c = o - a * K;
@@ -228,7 +228,8 @@ int launch_corr_transpose(const float* dcorr, float* dct, int B, int h, int w, i
     int nb = (int)((total + 255) / 256);
     if (nb > 16384) nb = 16384;
     if (r != 5) { set_error("corr_transpose: radius %d", r); return RPNET_ERR_SHAPE; }
-    hipLaunchKernelGGL((corr_transpose_kernel<5>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
+    if (total >= kIndex32) { set_error("corr_transpose: %zu elements do not fit the 32-bit index arithmetic", total); return RPNET_ERR_SHAPE; }
+    hipLaunchKernelGGL((corr_transpose_kernel<5>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride, FastDiv(cstride), FastDiv(w), FastDiv(h));
     return check_launch("corr_transpose");
 }
 
@@ -285,7 +286,7 @@ extern "C" int rpnet_local_corr_bwd(const float* f1, const float* f2, const floa
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, 1, BCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_bwd_kernel<RR, -1, BCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((local_corr_bwd_kernel<RR, 1, BCT>), dim3(tiles, B), dim3(256), lds, s, dcorr, f2, df1, h, w, C, cstride, isc, df1_add);
-        hipLaunchKernelGGL((corr_transpose_kernel<RR>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride);
+        hipLaunchKernelGGL((corr_transpose_kernel<RR>), dim3(nb), dim3(256), 0, s, dcorr, dct, B, h, w, cstride, FastDiv(cstride), FastDiv(w), FastDiv(h));
         hipLaunchKernelGGL((local_corr_bwd_kernel<RR, -1, BCT>), dim3(tiles, B), dim3(256), lds, s, (const float*)dct, f1, df2, h, w, C, cstride, isc, (const float*)nullptr);
     });
     return check_launch("local_corr_bwd");

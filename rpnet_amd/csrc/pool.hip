@@ -7,16 +7,16 @@
 namespace rpnet {
 
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ z, float* __restrict__ out,
-                                                            int N, int Ho, int Wo, int C4) {
+                                                            int N, int Ho, int Wo, int C4, const FastDiv fC, const FastDiv fW, const FastDiv fH) {
     RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+        unsigned p, py, pn;
+        const int c4 = (int)fC.divmod((unsigned)i, p);
+        const int ox = (int)fW.divmod(p, py);
+        const int oy = (int)fH.divmod(py, pn);
+        const int n = (int)pn;
         const f32x4* src = reinterpret_cast<const f32x4*>(z) + (((size_t)n * Ho * 2 + oy * 2) * W + ox * 2) * C4 + c4;
         const f32x4 a = src[0], b = src[C4], c = src[(size_t)W * C4], d = src[(size_t)W * C4 + C4];
         f32x4 o;
@@ -29,16 +29,16 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 // dz[window] = (first max of the window ? dpool : 0) + skip
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpool,
                                                             const float* __restrict__ skip, float* __restrict__ dz,
-                                                            int N, int Ho, int Wo, int C4) {
+                                                            int N, int Ho, int Wo, int C4, const FastDiv fC, const FastDiv fW, const FastDiv fH) {
     RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+        unsigned p, py, pn;
+        const int c4 = (int)fC.divmod((unsigned)i, p);
+        const int ox = (int)fW.divmod(p, py);
+        const int oy = (int)fH.divmod(py, pn);
+        const int n = (int)pn;
         const size_t o00 = (((size_t)n * Ho * 2 + oy * 2) * W + ox * 2) * C4 + c4;
         const size_t offs[4] = {o00, o00 + C4, o00 + (size_t)W * C4, o00 + (size_t)W * C4 + C4};
         f32x4 v[4];
@@ -63,16 +63,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dyu, float* __restrict__ dx,
-                                                             int N, int Ho, int Wo, int C4) {
+                                                             int N, int Ho, int Wo, int C4, const FastDiv fC, const FastDiv fW, const FastDiv fH) {
     RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     const int W = Wo * 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+        unsigned p, py, pn;
+        const int c4 = (int)fC.divmod((unsigned)i, p);
+        const int ox = (int)fW.divmod(p, py);
+        const int oy = (int)fH.divmod(py, pn);
+        const int n = (int)pn;
         const f32x4* src = reinterpret_cast<const f32x4*>(dyu) + (((size_t)n * Ho * 2 + oy * 2) * W + ox * 2) * C4 + c4;
         reinterpret_cast<f32x4*>(dx)[i] = (src[0] + src[C4]) + (src[(size_t)W * C4] + src[(size_t)W * C4 + C4]);
     }
@@ -93,15 +93,15 @@ __global__ void mask_avgpool_kernel(const float* __restrict__ m, float* __restri
 
 // MaxPool2d(3, stride, padding=1): -inf padding, first maximum in (ky, kx) scan order
 __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int N, int H,
-                                                            int W, int Ho, int Wo, int C4, int stride) {
+                                                            int W, int Ho, int Wo, int C4, int stride, const FastDiv fC, const FastDiv fW, const FastDiv fH) {
     RPNET_PASS_PRIORITY();
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+        unsigned p, py, pn;
+        const int c4 = (int)fC.divmod((unsigned)i, p);
+        const int ox = (int)fW.divmod(p, py);
+        const int oy = (int)fH.divmod(py, pn);
+        const int n = (int)pn;
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * stride - 1 + ky;
@@ -236,7 +236,9 @@ extern "C" int rpnet_maxpool3_fwd(const float* z, float* out, int N, int H, int 
     RPNET_REQUIRE(C % 4 == 0 && (stride == 1 || stride == 2), RPNET_ERR_SHAPE, "maxpool3_fwd: C=%d stride=%d", C, stride);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, Ho, Wo, C / 4, stride);
+    RPNET_REQUIRE(total < kIndex32, RPNET_ERR_SHAPE, "maxpool3_fwd: %zu elements do not fit the 32-bit index arithmetic", total);
+    hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, out, N, H, W, Ho, Wo, C / 4, stride,
+                       FastDiv(C / 4), FastDiv(Wo), FastDiv(Ho));
     return check_launch("maxpool3_fwd");
 }
 
@@ -256,7 +258,8 @@ extern "C" int rpnet_maxpool2_fwd(const float* z, float* out, int N, int H, int 
     RPNET_REQUIRE(z && out, RPNET_ERR_ARG, "maxpool2_fwd: null pointer");
     RPNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, RPNET_ERR_SHAPE, "maxpool2_fwd: H=%d W=%d C=%d", H, W, C);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, out, N, H / 2, W / 2, C / 4);
+    RPNET_REQUIRE(total < kIndex32, RPNET_ERR_SHAPE, "maxpool2_fwd: %zu elements do not fit the 32-bit index arithmetic", total);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, out, N, H / 2, W / 2, C / 4, FastDiv(C / 4), FastDiv(W / 2), FastDiv(H / 2));
     return check_launch("maxpool2_fwd");
 }
 
@@ -266,7 +269,8 @@ extern "C" int rpnet_maxpool2_bwd(const float* z, const float* dpool, const floa
     RPNET_REQUIRE(z && dpool && dz, RPNET_ERR_ARG, "maxpool2_bwd: null pointer");
     RPNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, RPNET_ERR_SHAPE, "maxpool2_bwd: H=%d W=%d C=%d", H, W, C);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, dpool, skip, dz, N, H / 2, W / 2, C / 4);
+    RPNET_REQUIRE(total < kIndex32, RPNET_ERR_SHAPE, "maxpool2_bwd: %zu elements do not fit the 32-bit index arithmetic", total);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, z, dpool, skip, dz, N, H / 2, W / 2, C / 4, FastDiv(C / 4), FastDiv(W / 2), FastDiv(H / 2));
     return check_launch("maxpool2_bwd");
 }
 
@@ -275,7 +279,8 @@ extern "C" int rpnet_upsample2_bwd(const float* dyu, float* dx, int N, int H, in
     RPNET_REQUIRE(dyu && dx, RPNET_ERR_ARG, "upsample2_bwd: null pointer");
     RPNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, RPNET_ERR_SHAPE, "upsample2_bwd: H=%d W=%d C=%d", H, W, C);
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, dyu, dx, N, H / 2, W / 2, C / 4);
+    RPNET_REQUIRE(total < kIndex32, RPNET_ERR_SHAPE, "upsample2_bwd: %zu elements do not fit the 32-bit index arithmetic", total);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, dyu, dx, N, H / 2, W / 2, C / 4, FastDiv(C / 4), FastDiv(W / 2), FastDiv(H / 2));
     return check_launch("upsample2_bwd");
 }
 

@@ -122,9 +122,11 @@ _SIGS = {
     "rpnet_argmax_masks": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
     "rpnet_align_labels": (ci, [vp, vp, vp, cs, vp]),
     "rpnet_debug_lds_canary": (ci, [ci, ci, C.c_longlong, vp, vp]),
+    "rpnet_debug_fastdiv_selftest": (C.c_longlong, [ci]),
+    "rpnet_debug_mfma_spin": (ci, [ci, ci, C.c_longlong, vp, vp]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
-ABI_VERSION = 107      # RPNET_ABI_VERSION of include/rpnet_abi.h
+ABI_VERSION = 108      # RPNET_ABI_VERSION of include/rpnet_abi.h
 
 
 def lib_path():

@@ -31,6 +31,17 @@ def test_abi_exports_every_declared_symbol():
     assert lib.rpnet_version() == _hip.ABI_VERSION == int(re.search(r"#define RPNET_ABI_VERSION (\d+)", hdr).group(1))   # no compute call without a GPU
 
 
+def test_index_division_of_the_passes_is_exact():
+    """csrc/common.h FastDiv (round 6: the element-wise passes divide their 32-bit element index by launch constants with a host-made
+    multiplier instead of hipcc's 64-bit division sequence): the library's host-only self-test — 49 divisors, edge values around their
+    multiples and around powers of two, 20 000 random values each — against the C operators."""
+    from rpnet_amd import hip
+    lib = ctypes.CDLL(hip.lib_path())
+    lib.rpnet_debug_fastdiv_selftest.restype = ctypes.c_longlong
+    lib.rpnet_debug_fastdiv_selftest.argtypes = [ctypes.c_int]
+    assert lib.rpnet_debug_fastdiv_selftest(20000) == 0
+
+
 def test_module_surface_and_state_dict():
     from net.model import model_factory
     from oracle.rpnet_oracle import param_shapes

@@ -74,22 +74,46 @@ torch.cuda.synchronize()
 RF.call = orig
 for e in log:
     e["insitu"] = e["ev"][0].elapsed_time(e["ev"][1]) * 1e3
+SPIN = None
+if os.environ.get("AGG", "").startswith("spin"):      # AGG=spin:<blocks>[:<lds bytes>]: the MFMA spinner instead of a weight gradient
+    f = os.environ.pop("AGG").split(":")
+    SPIN = (int(f[1]) if len(f) > 1 else 256, int(f[2]) if len(f) > 2 else 144 * 1024)
+    spin_out = torch.zeros(4, device=dev, dtype=torch.int64)
+    spin_log = []
 wg = [i for i, e in enumerate(log) if e["name"] == "rpnet_conv_wgrad" and e["args"][1] is not None and e["desc"].taps == 9]
 agg = int(os.environ["AGG"]) if os.environ.get("AGG") else max(wg, key=lambda i: log[i]["insitu"])
 A = log[agg]
 d = A["desc"]
 if os.environ.get("AGG_TUNE"):      # another kernel form / an ablation of the aggressor (rpnet_conv_desc.tune; csrc/conv_wgrad_ring.hip)
     d.tune = int(os.environ["AGG_TUNE"], 0)
-print(f"# tools/corun_probe.py: B={B} SIZE={SIZE} T={cfg['n_iter_refinement']} {RF.conv_math()}; aggressor = weight gradient #{agg}: "
-      f"{d.N}x{d.H}x{d.W}, {d.C0 + d.C1} -> {d.Co0 + d.Co1} channels, tune {d.tune:#x}, {A['insitu']:.0f} us in the serialised step; {REPS} repeats per victim call",
-      file=out, flush=True)
+if SPIN:
+    print(f"# tools/corun_probe.py: B={B} SIZE={SIZE} T={cfg['n_iter_refinement']} {RF.conv_math()}; aggressor = MFMA spinner, {SPIN[0]} blocks of 4 waves, "
+          f"{SPIN[1]} bytes of LDS each (rpnet_debug_mfma_spin); {REPS} repeats per victim call", file=out, flush=True)
+else:
+    print(f"# tools/corun_probe.py: B={B} SIZE={SIZE} T={cfg['n_iter_refinement']} {RF.conv_math()}; aggressor = weight gradient #{agg}: "
+          f"{d.N}x{d.H}x{d.W}, {d.C0 + d.C1} -> {d.Co0 + d.Co1} channels, tune {d.tune:#x}, {A['insitu']:.0f} us in the serialised step; {REPS} repeats per victim call",
+          file=out, flush=True)
 side, main = torch.cuda.Stream(device=dev), torch.cuda.current_stream(dev)
+if SPIN:
+    for nb in (1, 64, 128, 256):
+        for _ in range(2):
+            orig("rpnet_debug_mfma_spin", nb, SPIN[1], 200000, RF.ptr(spin_out))      # 2 ms
+        torch.cuda.synchronize()
+        c, t, n = (int(v) for v in spin_out[:3].tolist())
+        print(f"# spinner alone, {nb:3d} blocks, 2 ms: shader clock {c / t * 100.0:.0f} MHz, MFMA issue {n * 32.0 / max(c, 1):.2f} of back-to-back", file=out, flush=True)
 
 
 def timed(e, corun):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if corun:
+    if corun and SPIN:
+        started = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            orig("rpnet_debug_mfma_spin", SPIN[0], SPIN[1], 300, RF.ptr(spin_out))          # 3 us: the kernel is loaded and the stream busy
+            started.record(side)
+            orig("rpnet_debug_mfma_spin", SPIN[0], SPIN[1], int(REPS * 6 * max(e["insitu"], 20.0) * 100), RF.ptr(spin_out))
+        main.wait_event(started)
+    elif corun:
         started = torch.cuda.Event()
         with torch.cuda.stream(side):
             orig(A["name"], *A["args"])
@@ -103,6 +127,9 @@ def timed(e, corun):
         orig(e["name"], *e["args"])
     b.record()
     torch.cuda.synchronize()
+    if corun and SPIN:
+        c, t, n = (int(v) for v in spin_out[:3].tolist())
+        spin_log.append((c / t * 100.0, n * 32.0 / max(c, 1)))      # shader MHz; MFMA-busy fraction at 32 cycles per 32x32x16
     return a.elapsed_time(b) * 1e3 / REPS
 
 
@@ -119,3 +146,8 @@ for i, e in enumerate(log):
     print(f"{i:4d} {e['name']:32s} {e['insitu']:10.1f} {al:9.1f} {co:10.1f} {co / al:6.2f}", file=out, flush=True)
 for n, (k, al, co) in tot.items():
     print(f"# {n}: {k} calls, alone {al / 1e3:.3f} ms, beside the weight gradient {co / 1e3:.3f} ms ({co / al:.2f} x)", file=out)
+if SPIN and spin_log:
+    mhz = sorted(x[0] for x in spin_log)
+    busy = sorted(x[1] for x in spin_log)
+    print(f"# the spinner's shader clock while the victims ran: median {mhz[len(mhz) // 2]:.0f} MHz (min {mhz[0]:.0f}, max {mhz[-1]:.0f}); "
+          f"its waves' MFMA issue: median {busy[len(busy) // 2]:.2f} of back-to-back", file=out)
