@@ -323,6 +323,22 @@ def _up4_ok(pw, planes, upsample, x1, in_scale, xs0, N, H, W, cout):
     return bool(query("rpnet_conv_up4_supported", C.byref(probe), 1))
 
 
+def up4_layer_ok(weight, planes, calls):
+    """WeightCache.prepack's question: will EVERY encoder call of this forward run this up_conv layer on the collapsed form?
+    calls: (N, H, W) of the layer's OUTPUT per call.  A layer that would fall back (maps below 16 x 16, ...) belongs into the batched
+    nine-tap prepack, not into a per-layer pack on first use."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if not (_UP4 and planes in (1, 2) and cin % 32 == 0 and cout % 64 == 0):
+        return False
+    for N, H, W in calls:
+        probe = ConvDesc()
+        probe.N, probe.H, probe.W, probe.C0, probe.Co0, probe.split_planes = N, H, W, cin, cout, planes
+        probe.x0 = probe.y0 = ptr(weight)
+        if not query("rpnet_conv_up4_supported", C.byref(probe), 1):
+            return False
+    return True
+
+
 # zeroed device scalars for rpnet_conv_desc.out_absmax (eval-mode f16 scales): one pool per device, handed out slot by slot,
 # re-zeroed with ONE fill at the start of every RP_Net.forward (reset_absmax_pool); a call outside a forward that runs
 # out of slots gets a fresh pool

@@ -497,7 +497,12 @@ class RP_Net(nn.Module):
             # every 3x3 layer's operand pack of this forward in one launch per kernel instead of two launches per layer
             # (the two up_conv layers on their collapsed four-tap packs, RF._UP4)
             # (round 6: eval mode too — the collapsed form's epilogue carries the folded BatchNorm affine)
-            ups = (self.encoder.Up5.up[1].weight, self.encoder.Up4.up[1].weight) if (self.training or RF.f16_mode()) else ()
+            ups = ()
+            if self.training or RF.f16_mode():
+                # only where every encoder call of this forward takes the collapsed form (the calls see ns + B images, or ns and B)
+                enc_n = (ns + B,) if ns == B else (ns, B)
+                ups = tuple(m.up[1].weight for m, f in ((self.encoder.Up5, 8), (self.encoder.Up4, 4))
+                            if RF.up4_layer_ok(m.up[1].weight, planes, [(n, H // f, W // f) for n in enc_n + ((ns, B) if ns == B else ())]))
             if self.training and supp.is_cuda:      # the packing on its own stream beside the first-layer convolution
                 cache.prepack_async(self._pack_weights(), planes, supp.device, ups)
             else:

@@ -42,6 +42,18 @@ def test_index_division_of_the_passes_is_exact():
     assert lib.rpnet_debug_fastdiv_selftest(20000) == 0
 
 
+def test_prepack_asks_the_library_which_up_conv_layers_collapse():
+    """RF.up4_layer_ok (an up_conv layer whose shape the collapsed kernel rejects belongs into the batched nine-tap prepack,
+    not into a per-layer pack on first use): the answer comes from rpnet_conv_up4_supported — host logic, no GPU."""
+    import torch
+    from rpnet_amd import functional as RF
+    w5, w4 = torch.zeros(512, 1024, 3, 3), torch.zeros(256, 512, 3, 3)
+    got = {H: [RF.up4_layer_ok(w, 2, [(16, H // f, H // f)]) for w, f in ((w5, 8), (w4, 4))] for H in (64, 128, 256)}
+    assert got == {64: [False, False], 128: [False, True], 256: [True, True]}
+    assert not RF.up4_layer_ok(w5, 3, [(16, 32, 32)])                      # three bf16 planes: the nine-tap form
+    assert not RF.up4_layer_ok(w4, 2, [(16, 64, 64), (16, 8, 8)])          # every call of the forward must fit
+
+
 def test_module_surface_and_state_dict():
     from net.model import model_factory
     from oracle.rpnet_oracle import param_shapes
