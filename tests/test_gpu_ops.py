@@ -573,6 +573,64 @@ def test_local_correlation_writes_its_planes_on_a_given_scale(RF, planes):
     assert torch.equal(corr, corr2)
 
 
+@pytest.mark.parametrize("N,H,W,C,G,planes", [(2, 12, 20, 192, 1, 2), (4, 6, 10, 72, 2, 3), (2, 8, 24, 64, 2, 1)])
+def test_pooled_batchnorm_passes_on_odd_shapes(N, H, W, C, G, planes):
+    """rpnet_bn_relu(pool_w) / rpnet_bn_bwd(pool_w) through the C ABI where no extent is a power of two (the passes' index arithmetic
+    is a multiply-shift division by C / 8, Wo, Ho, images per group and Ho * Wo: csrc/common.h FastDiv): the pooled planes are the planes
+    of max_pool2d(relu(bn(y))), bit for bit against rpnet_bn_relu + rpnet_maxpool2_fwd + a split of the result on the same scale; the
+    backward against torch autograd of the same expression."""
+    from rpnet_amd.hip import call, ptr, query
+    g = torch.Generator().manual_seed(17 + C)
+    y = (torch.randn(N, H, W, C, generator=g) * 1.3 + 0.2).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    yg = y.view(G, -1, C)
+    mean, var = yg.mean(1), yg.var(1, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale = (gamma[None] * invstd).contiguous()
+    shift = (beta[None] - mean * scale).contiguous()
+    mean, invstd = mean.contiguous(), invstd.contiguous()
+    Ho, Wo = H // 2, W // 2
+    # forward: fused
+    zp = torch.empty(N, Ho, Wo, C, device=DEV)
+    zs = torch.full((planes, N, Ho, Wo, C), 3.0, device=DEV, dtype=torch.bfloat16)
+    sc = torch.zeros(1, device=DEV)
+    call("rpnet_bn_relu", ptr(y), ptr(scale), ptr(shift), ptr(zp), ptr(zs), planes, ptr(gamma), ptr(beta), ptr(sc) if planes <= 2 else None,
+         N, H * W, C, G, W, None, 0)
+    # forward: the three separate launches
+    z = torch.empty_like(y)
+    call("rpnet_bn_relu", ptr(y), ptr(scale), ptr(shift), ptr(z), None, 0, None, None, None, N, H * W, C, G, 0, None, 0)
+    want = torch.empty_like(zp)
+    call("rpnet_maxpool2_fwd", ptr(z), ptr(want), N, H, W, C)
+    assert torch.equal(zp, want)
+    ref = F.max_pool2d(torch.relu(y.view(G, -1, C) * scale[:, None] + shift[:, None]).view(N, H, W, C).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert rel_err(zp, ref) < 1e-6
+    if planes <= 2:
+        wantp = torch.empty_like(zs)
+        call("rpnet_split_f16", ptr(want), None, 0, ptr(sc), None, None, ptr(wantp), N * Ho * Wo, C, planes, 0)
+    else:
+        wantp = torch.empty_like(zs)
+        call("rpnet_split_bf16", ptr(want), None, 0, ptr(wantp), N * Ho * Wo, C, 3)
+    assert torch.equal(zs.view(torch.int16), wantp.view(torch.int16))
+    # backward: fused against autograd of the expression
+    dp = torch.randn(N, Ho, Wo, C, generator=g).to(DEV)
+    wsb = query("rpnet_bn_workspace_bytes", C, G)
+    ws = torch.zeros(wsb, device=DEV, dtype=torch.uint8)
+    dy = torch.empty_like(y)
+    dys = torch.empty((planes,) + tuple(y.shape), device=DEV, dtype=torch.bfloat16)
+    sdy, dg, db = torch.zeros(1, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("rpnet_bn_bwd", ptr(dp), ptr(y), ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dy), ptr(dys), planes,
+         ptr(sdy) if planes <= 2 else None, ptr(dg), ptr(db), N, H * W, C, G, 0, None, None, 0, W, ptr(ws), wsb, None, 0)
+    yr = y.double().clone().requires_grad_(True)
+    gm, bt = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    ygr = yr.view(G, -1, C)
+    mu, vr = ygr.mean(1, keepdim=True), ygr.var(1, unbiased=False, keepdim=True)
+    zr = torch.relu((ygr - mu) * (vr + 1e-5).rsqrt() * gm + bt).view(N, H, W, C)
+    F.max_pool2d(zr.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).backward(dp.double())
+    assert rel_err(dy, yr.grad) < 2e-5 and rel_err(dg, gm.grad) < 2e-5 and rel_err(db, bt.grad) < 2e-5
+    back = (dys.view(torch.float16).float().sum(0) * float(sdy)) if planes <= 2 else dys.float().sum(0)     # fp16 planes of dy / s; bf16 planes of dy
+    assert rel_err(back, dy) < (2e-3 if planes == 1 else 2e-5)
+
+
 def test_masked_pool_golden_and_grad(RF, golden):
     from oracle import rpnet_oracle as O
     g = golden("ops")
