@@ -631,6 +631,28 @@ def test_pooled_batchnorm_passes_on_odd_shapes(N, H, W, C, G, planes):
     assert rel_err(back, dy) < (2e-3 if planes == 1 else 2e-5)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_masked_split_on_a_channel_count_that_is_no_power_of_two(RF, mode):
+    """rpnet_split_f16 / rpnet_split_bf16 with a row factor (x * mask, x * (1 - mask)) at C = 72: the row of an element is its index
+    divided by C / 8 = 9 (csrc/common.h FastDiv) — against the planes of the product formed in torch."""
+    from rpnet_amd.hip import call, ptr
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(3, 10, 14, 72, generator=g).to(DEV)
+    m = torch.rand(3, 10, 14, generator=g).to(DEV)
+    f = m if mode == 1 else 1 - m
+    prod = (x * f[..., None]).contiguous()
+    sc = torch.tensor([2.0 ** -10], device=DEV)
+    got, _ = RF.split_f16(x, sc, mask=m, mode=mode, want_scale=False, planes=2)
+    want, _ = RF.split_f16(prod, sc, want_scale=False, planes=2)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    got3 = torch.empty(3, *x.shape, device=DEV, dtype=torch.bfloat16)
+    want3 = torch.empty_like(got3)
+    call("rpnet_split_bf16", ptr(x), ptr(m), mode, ptr(got3), x.numel() // 72, 72, 3)
+    call("rpnet_split_bf16", ptr(prod), None, 0, ptr(want3), x.numel() // 72, 72, 3)
+    assert torch.equal(got3.view(torch.int16), want3.view(torch.int16))
+    assert rel_err(got3.float().sum(0), prod) < 1e-6
+
+
 def test_masked_pool_golden_and_grad(RF, golden):
     from oracle import rpnet_oracle as O
     g = golden("ops")
